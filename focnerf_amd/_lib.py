@@ -1,0 +1,118 @@
+"""ctypes binding of libfocnerf_hip.so (the C ABI declared in include/focnerf.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this
+module raises ImportError, and every op raises RuntimeError when the library reports an
+error. PyTorch is used only for device memory and streams (tensor.data_ptr(),
+torch.cuda.current_stream()).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: the library then binds to torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfocnerf_hip.so")
+
+c_u8p = ctypes.c_void_p
+c_vp = ctypes.c_void_p
+u32 = ctypes.c_uint32
+u64 = ctypes.c_uint64
+f32 = ctypes.c_float
+i32 = ctypes.c_int
+
+FOC_F32 = 0
+FOC_F16 = 1
+
+# name -> (restype, [argtypes]) — one entry per declaration in include/focnerf.h
+SIGNATURES = {
+    "foc_abi_version": (i32, []),
+    "foc_last_error": (ctypes.c_char_p, []),
+    "foc_arch": (ctypes.c_char_p, []),
+    "foc_near_far_from_aabb": (i32, [c_vp, c_vp, c_vp, u32, f32, c_vp, c_vp, c_vp]),
+    "foc_sph_from_ray": (i32, [c_vp, c_vp, f32, u32, c_vp, c_vp]),
+    "foc_morton3D": (i32, [c_vp, u32, c_vp, c_vp]),
+    "foc_morton3D_invert": (i32, [c_vp, u32, c_vp, c_vp]),
+    "foc_packbits": (i32, [c_vp, u32, f32, c_vp, c_vp]),
+    "foc_march_rays_train": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "foc_march_rays_train_scratch_bytes": (u64, [u32]),
+    "foc_composite_rays_train_forward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp]),
+    "foc_composite_rays_train_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32,
+                                                c_vp, c_vp, c_vp]),
+    "foc_march_rays": (i32, [u32, u32, c_vp, c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, c_vp, c_vp, c_vp,
+                             c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "foc_composite_rays": (i32, [u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "foc_compact_alive": (i32, [c_vp, u32, c_vp, c_vp, c_vp, c_vp]),
+    "foc_grid_encode_forward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, u32, i32, u32,
+                                      i32, c_vp, c_vp]),
+    "foc_grid_encode_forward_bl": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, u32, i32, u32,
+                                         i32, c_vp, c_vp]),
+    "foc_grid_encode_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
+                                       u32, i32, u32, i32, i32, c_vp, c_vp]),
+    "foc_grad_total_variation": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, c_vp]),
+    "foc_freq_encode_forward": (i32, [c_vp, u32, u32, u32, u32, c_vp, c_vp]),
+    "foc_freq_encode_backward": (i32, [c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp]),
+    "foc_ffmlp_forward": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
+    "foc_ffmlp_inference": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
+    "foc_ffmlp_backward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "foc_ffmlp_backward_workspace_bytes": (u64, [u32, u32, u32]),
+    "foc_allocate_splitk": (i32, [u64]),
+    "foc_free_splitk": (i32, []),
+    "foc_combine_select": (i32, [c_vp, c_vp, c_vp, c_vp, u64, c_vp]),
+    "foc_combine_pack_keys": (i32, [c_vp, u32, c_vp, u64, c_vp]),
+    "foc_combine_unpack": (i32, [c_vp, u32, c_vp, c_vp, c_vp, u64, c_vp]),
+    "foc_composite_fixed_steps": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"focnerf_amd: {LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C focnerf_amd/csrc`. There is no CPU or PyTorch fallback for these ops.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError(f"focnerf_amd: failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.foc_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"focnerf_amd {what}: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t=None):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    dev = t.device if t is not None else None
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("focnerf_amd: expected a CUDA(HIP) tensor; these ops have no CPU implementation")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return FOC_F32
+    if t.dtype == torch.float16:
+        return FOC_F16
+    raise RuntimeError(f"focnerf_amd: unsupported dtype {t.dtype} (float32 or float16 expected)")

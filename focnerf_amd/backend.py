@@ -1,0 +1,216 @@
+"""Tensor-level shims with the exact names and positional orders of the reference's four
+pybind11 extension modules:
+
+    _raymarching   raymarching/src/bindings.cpp:5-19
+    _gridencoder   gridencoder/src/bindings.cpp
+    _freqencoder   freqencoder/src/bindings.cpp
+    _ffmlp         ffmlp/src/bindings.cpp
+
+Each function converts torch tensors to raw device pointers, picks torch's current HIP
+stream and calls the C ABI of libfocnerf_hip.so (include/focnerf.h); a non-zero return
+becomes a RuntimeError, like TORCH_CHECK in the reference. Outputs are written in place
+into caller-allocated tensors, exactly as in the reference.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, stream_of, check, require_cuda, dtype_code
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"focnerf_amd: expected float32 tensor, got {t.dtype}")
+
+
+def _contig(*ts):
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("focnerf_amd: tensor must be contiguous")   # CHECK_CONTIGUOUS in the reference
+
+
+class _Scratch:
+    """Per-device grow-only scratch buffers (int32 counters / fp32 workspaces)."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, key, nbytes, device):
+        k = (key, device.index if device.index is not None else torch.cuda.current_device())
+        buf = self._bufs.get(k)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[k] = buf
+        return buf
+
+
+_scratch = _Scratch()
+
+
+class _raymarching:
+    @staticmethod
+    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        require_cuda(rays_o, rays_d, aabb, nears, fars); _f32(rays_o, rays_d, aabb, nears, fars); _contig(rays_o, rays_d, aabb, nears, fars)
+        check(lib.foc_near_far_from_aabb(ptr(rays_o), ptr(rays_d), ptr(aabb), N, min_near, ptr(nears), ptr(fars), stream_of(rays_o)),
+              "near_far_from_aabb")
+
+    @staticmethod
+    def sph_from_ray(rays_o, rays_d, radius, N, coords):
+        require_cuda(rays_o, rays_d, coords); _f32(rays_o, rays_d, coords); _contig(rays_o, rays_d, coords)
+        check(lib.foc_sph_from_ray(ptr(rays_o), ptr(rays_d), radius, N, ptr(coords), stream_of(rays_o)), "sph_from_ray")
+
+    @staticmethod
+    def morton3D(coords, N, indices):
+        require_cuda(coords, indices); _contig(coords, indices)
+        assert coords.dtype == torch.int32 and indices.dtype == torch.int32
+        check(lib.foc_morton3D(ptr(coords), N, ptr(indices), stream_of(coords)), "morton3D")
+
+    @staticmethod
+    def morton3D_invert(indices, N, coords):
+        require_cuda(coords, indices); _contig(coords, indices)
+        assert coords.dtype == torch.int32 and indices.dtype == torch.int32
+        check(lib.foc_morton3D_invert(ptr(indices), N, ptr(coords), stream_of(coords)), "morton3D_invert")
+
+    @staticmethod
+    def packbits(grid, N, density_thresh, bitfield):
+        require_cuda(grid, bitfield); _f32(grid); _contig(grid, bitfield)
+        assert bitfield.dtype == torch.uint8
+        check(lib.foc_packbits(ptr(grid), N, density_thresh, ptr(bitfield), stream_of(grid)), "packbits")
+
+    @staticmethod
+    def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):
+        require_cuda(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+        _f32(rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises); _contig(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+        assert grid.dtype == torch.uint8 and rays.dtype == torch.int32 and counter.dtype == torch.int32
+        scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(N), rays_o.device)
+        check(lib.foc_march_rays_train(ptr(rays_o), ptr(rays_d), ptr(grid), bound, dt_gamma, max_steps, N, C, H, M, ptr(nears), ptr(fars),
+                                       ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(counter), ptr(noises), ptr(scratch),
+                                       stream_of(rays_o)), "march_rays_train")
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+        require_cuda(sigmas, rgbs, deltas, rays, weights_sum, depth, image); _f32(sigmas, rgbs, deltas, weights_sum, depth, image)
+        _contig(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        check(lib.foc_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh, ptr(weights_sum), ptr(depth),
+                                                   ptr(image), stream_of(sigmas)), "composite_rays_train_forward")
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs):
+        ts = (grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, grad_sigmas, grad_rgbs)
+        require_cuda(*ts, rays); _f32(*ts); _contig(*ts, rays)
+        check(lib.foc_composite_rays_train_backward(ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays),
+                                                    ptr(weights_sum), ptr(image), M, N, T_thresh, ptr(grad_sigmas), ptr(grad_rgbs),
+                                                    stream_of(sigmas)), "composite_rays_train_backward")
+
+    @staticmethod
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises):
+        ts = (rays_t, rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises)
+        require_cuda(*ts, rays_alive, grid); _f32(*ts); _contig(*ts, rays_alive, grid)
+        check(lib.foc_march_rays(n_alive, n_step, ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d), bound, dt_gamma, max_steps, C, H,
+                                 ptr(grid), ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), stream_of(rays_o)), "march_rays")
+
+    @staticmethod
+    def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        ts = (rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+        require_cuda(*ts, rays_alive); _f32(*ts); _contig(*ts, rays_alive)
+        check(lib.foc_composite_rays(n_alive, n_step, T_thresh, ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                     ptr(weights_sum), ptr(depth), ptr(image), stream_of(sigmas)), "composite_rays")
+
+    # extension (no reference binding): ordered device-side compaction of rays_alive >= 0
+    @staticmethod
+    def compact_alive(rays_alive, n_alive, out, n_out):
+        require_cuda(rays_alive, out, n_out)
+        scratch = _scratch.get("compact", 4 * (n_alive // 1024 + 2), rays_alive.device)
+        check(lib.foc_compact_alive(ptr(rays_alive), n_alive, ptr(out), ptr(n_out), ptr(scratch), stream_of(rays_alive)), "compact_alive")
+
+
+class _gridencoder:
+    @staticmethod
+    def _common(inputs, embeddings, offsets):
+        require_cuda(inputs, embeddings, offsets)          # CHECK_CUDA, gridencoder.cu:449-452
+        _contig(inputs, embeddings, offsets)               # CHECK_CONTIGUOUS :455-458
+        if inputs.dtype != torch.float32:
+            raise RuntimeError("inputs must be a float32 tensor")
+        if offsets.dtype != torch.int32:
+            raise RuntimeError("offsets must be an int tensor")   # CHECK_IS_INT :463
+
+    @staticmethod
+    def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, out_bl=False):
+        _gridencoder._common(inputs, embeddings, offsets)
+        require_cuda(outputs, dy_dx); _contig(outputs, dy_dx)
+        dt = dtype_code(embeddings)
+        if outputs.dtype != embeddings.dtype or (dy_dx is not None and dy_dx.dtype != embeddings.dtype):
+            raise RuntimeError("grid_encode_forward: outputs/dy_dx must share the embeddings dtype")
+        fn = lib.foc_grid_encode_forward_bl if out_bl else lib.foc_grid_encode_forward
+        check(fn(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype, int(bool(align_corners)),
+                 interp, dt, None, stream_of(inputs)), "grid_encode_forward")
+
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, grad_bl=False):
+        _gridencoder._common(inputs, embeddings, offsets)
+        require_cuda(grad, grad_embeddings, dy_dx, grad_inputs); _contig(grad, grad_embeddings, dy_dx, grad_inputs)
+        dt = dtype_code(grad)                               # the reference dispatches on grad.scalar_type(), :498-499
+        if grad_embeddings.dtype != grad.dtype:
+            raise RuntimeError("grid_encode_backward: grad_embeddings must share grad's dtype")
+        check(lib.foc_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                                           ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),
+                                           None, stream_of(inputs)), "grid_encode_backward")
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+        require_cuda(inputs, embeddings, grad, offsets); _contig(inputs, embeddings, grad, offsets)
+        dt = dtype_code(embeddings)
+        if inputs.dtype != embeddings.dtype or grad.dtype != embeddings.dtype:
+            raise RuntimeError("grad_total_variation: inputs/grad must share the embeddings dtype")
+        check(lib.foc_grad_total_variation(ptr(inputs), ptr(embeddings), ptr(grad), ptr(offsets), weight, B, D, C, L, float(S), H, gridtype,
+                                           int(bool(align_corners)), dt, stream_of(inputs)), "grad_total_variation")
+
+
+class _freqencoder:
+    @staticmethod
+    def freq_encode_forward(inputs, B, D, deg, C, outputs):
+        require_cuda(inputs, outputs); _f32(inputs, outputs); _contig(inputs, outputs)
+        check(lib.foc_freq_encode_forward(ptr(inputs), B, D, deg, C, ptr(outputs), stream_of(inputs)), "freq_encode_forward")
+
+    @staticmethod
+    def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):
+        require_cuda(grad, outputs, grad_inputs); _f32(grad, outputs, grad_inputs); _contig(grad, outputs, grad_inputs)
+        check(lib.foc_freq_encode_backward(ptr(grad), ptr(outputs), B, D, deg, C, ptr(grad_inputs), stream_of(grad)), "freq_encode_backward")
+
+
+def _half(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float16:
+            raise RuntimeError("focnerf_amd: tensor must be a half tensor")   # CHECK_IS_HALF, ffmlp.cu:638
+
+
+class _ffmlp:
+    @staticmethod
+    def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs):
+        require_cuda(inputs, weights, forward_buffer, outputs); _half(inputs, weights, forward_buffer, outputs); _contig(inputs, weights, forward_buffer, outputs)
+        check(lib.foc_ffmlp_forward(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                    ptr(forward_buffer), ptr(outputs), stream_of(inputs)), "ffmlp_forward")
+
+    @staticmethod
+    def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference_buffer, outputs):
+        require_cuda(inputs, weights, outputs); _half(inputs, weights, outputs); _contig(inputs, weights, outputs)
+        check(lib.foc_ffmlp_inference(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                      ptr(inference_buffer), ptr(outputs), stream_of(inputs)), "ffmlp_inference")
+
+    @staticmethod
+    def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                       calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+        ts = (grad, inputs, weights, forward_buffer, backward_buffer, grad_inputs, grad_weights)
+        require_cuda(*ts); _half(*ts); _contig(*ts)
+        ws = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), grad.device)
+        check(lib.foc_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim, output_dim, hidden_dim, num_layers,
+                                     activation, output_activation, int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
+                                     ptr(grad_weights), ptr(ws), stream_of(grad)), "ffmlp_backward")
+
+    @staticmethod
+    def allocate_splitk(size):
+        check(lib.foc_allocate_splitk(int(size)), "allocate_splitk")
+
+    @staticmethod
+    def free_splitk():
+        check(lib.foc_free_splitk(), "free_splitk")

@@ -1,0 +1,148 @@
+// combine.hip — multi-object combine (COMBINED.py:247-251, 141-200) and library bookkeeping.
+//
+// foc_combine_select      : per-sample strict-'>' max-density select (first object wins ties).
+// foc_combine_pack_keys / foc_combine_unpack : the same select expressed as an order-preserving
+//   64-bit key, so K objects living on K GPUs can be merged with ONE RCCL all-reduce(MAX) of the
+//   keys plus one all-reduce(SUM) of rgb masked to the winning rank (exactly one non-zero
+//   contributor per sample -> bit-exact).
+// foc_composite_fixed_steps : the fixed-step alpha composite the reference writes with
+//   torch.cumprod (COMBINED.py:141-200 / nerf/renderer.py:169-221), one wave per ray with a
+//   wave product-scan over 64 samples at a time.
+#include "common.h"
+#include <string.h>
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+
+void foc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ void __launch_bounds__(256) k_combine_select(const float *__restrict__ dens, const float *__restrict__ rgb,
+                                                        float *__restrict__ max_dens, float *__restrict__ best_rgb, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const float d = dens[i], m = max_dens[i];
+        if (d > m) { best_rgb[i * 3] = rgb[i * 3]; best_rgb[i * 3 + 1] = rgb[i * 3 + 1]; best_rgb[i * 3 + 2] = rgb[i * 3 + 2]; }
+        // torch.maximum propagates NaN
+        max_dens[i] = (d != d || m != m) ? __builtin_nanf("") : (d > m ? d : m);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_combine_pack(const float *__restrict__ dens, uint32_t rank, uint64_t *__restrict__ keys, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        float d = dens[i];
+        d = d > 0.0f ? d : 0.0f;                       // sigma >= 0 (trunc_exp): bit pattern is order preserving; -0/NaN -> 0
+        keys[i] = ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)(0xFFFFFFFFu - rank);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_combine_unpack(const uint64_t *__restrict__ keys, uint32_t rank, const float *__restrict__ rgb,
+                                                        float *__restrict__ max_dens, float *__restrict__ masked_rgb, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = keys[i];
+        const bool mine = (uint32_t)(k & 0xFFFFFFFFu) == 0xFFFFFFFFu - rank;
+        max_dens[i] = __uint_as_float((uint32_t)(k >> 32));
+        masked_rgb[i * 3] = mine ? rgb[i * 3] : 0.0f;
+        masked_rgb[i * 3 + 1] = mine ? rgb[i * 3 + 1] : 0.0f;
+        masked_rgb[i * 3 + 2] = mine ? rgb[i * 3 + 2] : 0.0f;
+    }
+}
+
+// One wave per ray. z_i = near + (far-near)*lin_i with lin = torch.linspace(0,1,T) evaluated the way
+// torch fills it (symmetric halves); deltas = diff(z), last = (far-near)/T;
+// w_i = alpha_i * prod_{j<i}(1 - alpha_j + 1e-15).
+__global__ void __launch_bounds__(256) k_composite_fixed(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                                         const float *__restrict__ nears, const float *__restrict__ fars,
+                                                         uint32_t N, uint32_t T, float bg, float *__restrict__ image4, float *__restrict__ depth) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float near = nears[n], far = fars[n];
+    const float span = far - near;
+    const float sample_dist = span / (float)T;
+    const float step = 1.0f / (float)(T - 1);
+    float Tc = 1.0f, r = 0, g = 0, b = 0, a = 0, d = 0, ws = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < T;
+        float alpha = 0, sigma = 0, c0 = 0, c1 = 0, c2 = 0, oz = 0;
+        if (valid) {
+            const float l0 = (i < T / 2) ? (step * (float)i) : (1.0f - step * (float)(T - 1 - i));
+            const float z = near + span * l0;
+            float delta = sample_dist;
+            if (i + 1 < T) {
+                const uint32_t i1 = i + 1;
+                const float l1 = (i1 < T / 2) ? (step * (float)i1) : (1.0f - step * (float)(T - 1 - i1));
+                delta = (near + span * l1) - z;
+            }
+            const uint64_t s = (uint64_t)n * T + i;
+            sigma = sigmas[s];
+            c0 = rgbs[s * 3]; c1 = rgbs[s * 3 + 1]; c2 = rgbs[s * 3 + 2];
+            alpha = 1 - __expf(-delta * sigma);
+            oz = (z - near) / span;
+            oz = oz < 0 ? 0 : (oz > 1 ? 1 : oz);
+        }
+        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float w = alpha * (Tc * Pex);
+        r = fmaf(w, c0, r); g = fmaf(w, c1, g); b = fmaf(w, c2, b);
+        a = fmaf(w, sigma, a); d = fmaf(w, oz, d); ws += w;
+        Tc *= __shfl(P, 63, 64);
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); a = wave_sum(a); d = wave_sum(d); ws = wave_sum(ws);
+    if (lane == 0) {
+        const float rest = (1 - ws) * bg;
+        float o[4] = {r + rest, g + rest, b + rest, a + rest};
+#pragma unroll
+        for (int k = 0; k < 4; k++) image4[(uint64_t)n * 4 + k] = fminf(1.0f, fmaxf(0.0f, o[k]));
+        depth[n] = d;
+    }
+}
+
+extern "C" {
+
+int foc_abi_version(void) { return FOC_ABI_VERSION; }
+const char *foc_last_error(void) { return g_err; }
+const char *foc_arch(void) { return "gfx950"; }
+
+int foc_combine_select(const float *dens, const float *rgb, float *max_dens, float *best_rgb, uint64_t n, void *stream) {
+    FOC_REQUIRE(n == 0 || (dens && rgb && max_dens && best_rgb), FOC_E_INVALID, "combine_select: null pointer");
+    if (n == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_combine_select, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rgb, max_dens, best_rgb, n);
+    FOC_CHECK_LAUNCH("combine_select");
+    return FOC_OK;
+}
+
+int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint64_t n, void *stream) {
+    FOC_REQUIRE(n == 0 || (dens && keys), FOC_E_INVALID, "combine_pack_keys: null pointer");
+    if (n == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_combine_pack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rank, keys, n);
+    FOC_CHECK_LAUNCH("combine_pack_keys");
+    return FOC_OK;
+}
+
+int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb, float *max_dens, float *masked_rgb, uint64_t n, void *stream) {
+    FOC_REQUIRE(n == 0 || (keys && rgb && max_dens && masked_rgb), FOC_E_INVALID, "combine_unpack: null pointer");
+    if (n == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_combine_unpack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, rank, rgb, max_dens, masked_rgb, n);
+    FOC_CHECK_LAUNCH("combine_unpack");
+    return FOC_OK;
+}
+
+int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const float *nears, const float *fars, uint32_t N, uint32_t T,
+                              float bg, float *image4, float *depth, void *stream) {
+    FOC_REQUIRE(N == 0 || (sigmas && rgbs && nears && fars && image4 && depth), FOC_E_INVALID, "composite_fixed_steps: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "composite_fixed_steps: T must be >= 2");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_composite_fixed, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigmas, rgbs, nears, fars, N, T, bg, image4, depth);
+    FOC_CHECK_LAUNCH("composite_fixed_steps");
+    return FOC_OK;
+}
+
+} // extern "C"

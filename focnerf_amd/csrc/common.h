@@ -1,0 +1,80 @@
+// common.h — shared helpers for the gfx950 kernels of libfocnerf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/focnerf.h"
+
+#define FOC_WAVE 64
+
+// thread-local error message (foc_last_error)
+void foc_set_error(const char *fmt, ...);
+
+#define FOC_REQUIRE(cond, code, ...)                    \
+    do {                                                \
+        if (!(cond)) {                                  \
+            foc_set_error(__VA_ARGS__);                 \
+            return (code);                              \
+        }                                               \
+    } while (0)
+
+// Call after every launch: hipGetLastError catches bad launch configurations without
+// synchronising (so the entry points stay graph-capturable).
+#define FOC_CHECK_LAUNCH(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            foc_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return FOC_E_LAUNCH;                                                   \
+        }                                                                          \
+    } while (0)
+
+static inline uint32_t foc_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// Grid for a grid-stride elementwise kernel: enough workgroups to fill 256 CUs x 8,
+// capped so tiny problems do not launch empty blocks.
+static inline uint32_t foc_grid_1d(uint64_t n, uint32_t block, uint32_t max_blocks = 256 * 8) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (uint32_t)g;
+}
+
+// wave64 reductions / scans via DPP-backed shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive product scan across the 64 lanes
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_sum_i(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}

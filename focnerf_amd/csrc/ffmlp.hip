@@ -1,0 +1,600 @@
+// ffmlp.hip — fully fused fp16 MLP on gfx950 matrix cores (v_mfma_f32_32x32x16_f16).
+//
+// Semantics: ffmlp/src/ffmlp.cu of the reference — kernel_mlp_fused (:331-407),
+// kernel_mlp_fused_backward (:410-518), weight-gradient GEMMs (:800-876); layouts :631-634,
+// :742-748; ReLU forward/backward ffmlp/src/utils.h:427-432, :540-545.
+//
+// CDNA4 design (not a translation of the WMMA/shared-memory structure):
+//  * The network is evaluated TRANSPOSED: Y^T[neurons x batch] = W[neurons x in] * X^T[in x batch].
+//    With the 32x32x16 MFMA the result tile then has the batch sample on the LANE and the
+//    neuron index in the 16 accumulator REGISTERS, which is exactly the B-operand shape of the
+//    next layer's MFMA (sum over neurons). Activations therefore chain from layer to layer in
+//    registers — ReLU + v_cvt to fp16 on the accumulators, no LDS round trip, no barrier.
+//    The k order of such a chained operand is permuted (element j of lane-half h is neuron
+//    16*kc + 8*(j>>2) + 4*h + (j&3)); the permutation is folded into the WEIGHT fragments
+//    when they are staged into LDS once per workgroup, so it costs nothing per sample.
+//  * Every wave owns its batch tiles end to end (64 samples per iteration = 2 MFMA column
+//    tiles sharing each weight fragment); the 4 waves of a workgroup share only the staged
+//    weight image in LDS (read with conflict-free ds_read_b128, 1 KiB per fragment).
+//  * fp32 accumulation (the reference accumulates in fp16, ffmlp.cu:68,169,256,458); layer
+//    outputs are rounded to fp16 exactly once, like the reference's half fragments.
+//  * Backward: activation gradients chain the same way with transposed weight fragments;
+//    weight gradients are one split-K MFMA kernel over the batch (all layers in one launch,
+//    fp32 atomics of whole 128-B row segments into a 16-KiB-per-layer workspace), replacing
+//    the reference's CUTLASS split-K GEMMs on side streams (ffmlp.cu:800-876).
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define MLP_BLOCK 256
+#define MLP_WAVES 4
+
+// neuron (row) index inside a 32-row accumulator tile held in register `reg` by lane-half `h`
+// (C/D map of v_mfma_f32_32x32x*: row = (reg&3) + 8*(reg>>2) + 4*h)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// k index carried by element j of lane-half h when an accumulator tile is reused as a B operand
+__device__ __forceinline__ int chain_k(int kc, int h, int j) { return 16 * kc + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__device__ __forceinline__ f16v mfma16(const h8 a, const h8 b, const f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ h8 ld_frag(const _Float16 *lds, uint32_t frag, uint32_t lane) {
+    return *reinterpret_cast<const h8 *>(lds + (size_t)frag * 512 + lane * 8);
+}
+
+// Build the B fragment of k-chunk (2*mt_prev + s) from accumulator tile `acc` (optionally ReLU'd).
+template <bool RELU>
+__device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        _Float16 v = (_Float16)acc[8 * s + j];
+        if (RELU) v = v > (_Float16)0 ? v : (_Float16)0;
+        r[j] = v;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- weight staging
+// Forward image. Fragment f holds, for lane (r = lane&31, h = lane>>5), the 8 halfs
+//   layer 0      : W0[32*mt + r][16*kc + 8*h + j]                       (natural k: B comes from global inputs)
+//   hidden l>=1  : Wl[32*mt + r][chain_k(kc, h, j)]
+//   output layer : Wout[r][chain_k(kc, h, j)]  for r < 16, else 0
+// Fragment order: layer0 [mt][kc0] | hidden layers [l][mt][kc] | out [kc].
+template <int HIDDEN>
+__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    const uint32_t KS0 = in_dim / 16;
+    const uint32_t n0 = MT * KS0, nh = (num_layers - 1) * MT * KC, total = n0 + nh + KC;
+    const _Float16 *Wh = W + (size_t)HIDDEN * in_dim;
+    const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
+    for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
+        const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (_Float16)0;
+        if (f < n0) {
+            const uint32_t mt = f / KS0, kc = f % KS0, row = 32 * mt + r;
+            if (row < HIDDEN) v = *reinterpret_cast<const h8 *>(W + (size_t)row * in_dim + 16 * kc + 8 * h);
+        } else if (f < n0 + nh) {
+            const uint32_t g = f - n0, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, row = 32 * mt + r;
+            if (row < HIDDEN) {
+                const _Float16 *p = Wh + (size_t)l * HIDDEN * HIDDEN + (size_t)row * HIDDEN + 16 * kc + 4 * h;
+                const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            }
+        } else {
+            const uint32_t kc = f - n0 - nh;
+            if (r < 16) {
+                const _Float16 *p = Wo + (size_t)r * HIDDEN + 16 * kc + 4 * h;
+                const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            }
+        }
+        *reinterpret_cast<h8 *>(lds + (size_t)f * 512 + lane * 8) = v;
+    }
+}
+
+// Backward image (transposed weights: rows = INPUT neuron i of the layer, k = OUTPUT neuron o).
+//   out layer   [mt]        : Wout[8*h + j][32*mt + r]                (k = o natural, K = 16; B = grad from global)
+//   hidden l    [l][mt][kc] : Wl[chain_k(kc,h,j)][32*mt + r]          (l = 0 .. num_layers-2, matrix l maps fwd[l] -> fwd[l+1])
+//   dX          [mt0][kc]   : W0[chain_k(kc,h,j)][32*mt0 + r]  (i < in_dim, else 0)
+// Fragment order: out [mt] | hidden [l][mt][kc] | dX [mt0][kc].
+template <int HIDDEN>
+__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    const uint32_t MT0 = (in_dim + 31) / 32;
+    const uint32_t no = MT, nh = (num_layers - 1) * MT * KC, nx = with_dx ? MT0 * KC : 0, total = no + nh + nx;
+    const _Float16 *Wh = W + (size_t)HIDDEN * in_dim;
+    const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
+    for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
+        const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (_Float16)0;
+        if (f < no) {
+            const uint32_t i = 32 * f + r;
+            if (i < HIDDEN) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = Wo[(size_t)(8 * h + j) * HIDDEN + i];
+            }
+        } else if (f < no + nh) {
+            const uint32_t g = f - no, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, i = 32 * mt + r;
+            if (i < HIDDEN) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = Wh[(size_t)l * HIDDEN * HIDDEN + (size_t)chain_k(kc, h, j) * HIDDEN + i];
+            }
+        } else {
+            const uint32_t g = f - no - nh, mt0 = g / KC, kc = g % KC, i = 32 * mt0 + r;
+            if (i < in_dim) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * in_dim + i];
+            }
+        }
+        *reinterpret_cast<h8 *>(lds + (size_t)f * 512 + lane * 8) = v;
+    }
+}
+
+// Store one accumulator tile (32 neurons x 32 samples) as fp16 into a row-major [B, ld] buffer:
+// lane (c, h) owns sample `row0 + c` and, per register quad q, the 4 consecutive neurons
+// col0 + 8q + 4h .. +3  -> one 8-byte store per quad.
+template <bool RELU>
+__device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint32_t col0, uint32_t ncols,
+                                           const f16v &acc, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t col = col0 + 8 * q + 4 * h;
+        if (col < ncols) {
+            h4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                _Float16 x = (_Float16)acc[4 * q + e];
+                if (RELU) x = x > (_Float16)0 ? x : (_Float16)0;
+                v[e] = x;
+            }
+            *reinterpret_cast<h4 *>(dst + row * ld + col) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- M1: fused forward / inference
+template <int HIDDEN, int NB, bool TRAIN>
+__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
+                                                       _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
+                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t KS0 = in_dim / 16;
+    const uint32_t f_hidden = MT * KS0, f_out = f_hidden + (num_layers - 1) * MT * KC;
+    const uint32_t tile_rows = 32 * NB;
+    const uint32_t n_tiles = B / tile_rows;
+
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint64_t row0 = (uint64_t)tile * tile_rows;
+        f16v acc[MT][NB];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+
+        // ---- layer 0: B operand straight from global inputs (natural k order)
+        for (uint32_t kc = 0; kc < KS0; kc++) {
+            h8 b[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+                b[nb] = *reinterpret_cast<const h8 *>(inputs + (row0 + nb * 32 + c) * in_dim + 16 * kc + 8 * h);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[nb], acc[mt][nb]);
+            }
+        }
+        // ---- hidden layers, chained in registers
+        for (uint32_t l = 1; l <= num_layers; l++) {
+            // acc holds the pre-activation of layer l-1
+            if (TRAIN) {
+                _Float16 *fb = fwd_buf + (uint64_t)(l - 1) * B * HIDDEN;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        if (relu) store_tile<true>(fb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
+                        else store_tile<false>(fb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
+                    }
+            }
+            h8 bf[KC][NB];
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+                    bf[kc][nb] = relu ? acc_to_frag<true>(acc[kc >> 1][nb], kc & 1) : acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+            if (l < num_layers) {
+                const uint32_t fbase = f_hidden + (l - 1) * MT * KC;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const h8 a = ld_frag(lds, fbase + mt * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                    }
+            } else {
+                // ---- output layer (16 neurons in the low half of one M tile), no activation
+                f16v o[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) o[nb][e] = 0.0f;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) {
+                    const h8 a = ld_frag(lds, f_out + kc, lane);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) store_tile<false>(outputs, 16, row0 + nb * 32 + c, 0, 16, o[nb], h);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- M2: fused activation-gradient backward
+// backward_buffer[k] = gradient w.r.t. the (post-ReLU) output of forward layer num_layers-1-k.
+template <int HIDDEN, int NB>
+__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ weights,
+                                                       const _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ bwd_buf,
+                                                       _Float16 *__restrict__ grad_inputs, uint32_t B, uint32_t in_dim,
+                                                       uint32_t num_layers, int relu) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const bool with_dx = grad_inputs != nullptr;
+    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, num_layers, with_dx);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t MT0 = (in_dim + 31) / 32;
+    const uint32_t f_hidden = MT, f_dx = MT + (num_layers - 1) * MT * KC;
+    const uint32_t tile_rows = 32 * NB;
+    const uint32_t n_tiles = B / tile_rows;
+
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint64_t row0 = (uint64_t)tile * tile_rows;
+        f16v acc[MT][NB];
+        // ---- through the output layer: delta = W_out^T * grad^T   (K = 16, one k-step)
+        {
+            h8 bg[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) bg[nb] = *reinterpret_cast<const h8 *>(grad + (row0 + nb * 32 + c) * 16 + 8 * h);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const h8 a = ld_frag(lds, mt, lane);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    f16v z;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) z[e] = 0.0f;
+                    acc[mt][nb] = mfma16(a, bg[nb], z);
+                }
+            }
+        }
+        for (uint32_t k = 0; k < num_layers; k++) {
+            const uint32_t fl = num_layers - 1 - k;   // forward layer whose output gradient `acc` is
+            // ---- ReLU transfer with the stored forward activations (utils.h:540-545), then store
+            if (relu) {
+                const _Float16 *fb = fwd_buf + (uint64_t)fl * B * HIDDEN;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t col = 32 * mt + 8 * q + 4 * h;
+                            if (col < HIDDEN) {
+                                const h4 f = *reinterpret_cast<const h4 *>(fb + (row0 + nb * 32 + c) * HIDDEN + col);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) if (!(f[e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
+                            }
+                        }
+            }
+            {
+                _Float16 *bb = bwd_buf + (uint64_t)k * B * HIDDEN;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) store_tile<false>(bb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
+            }
+            if (fl == 0 && !with_dx) break;
+            h8 bf[KC][NB];
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) bf[kc][nb] = acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+            if (fl > 0) {
+                // through hidden matrix fl-1 (maps fwd[fl-1] -> fwd[fl])
+                const uint32_t fbase = f_hidden + (fl - 1) * MT * KC;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const h8 a = ld_frag(lds, fbase + mt * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                    }
+            } else {
+                // ---- dL/dinput = delta_0 * W_0  (no activation)
+                for (uint32_t mt0 = 0; mt0 < MT0; mt0++) {
+                    f16v x[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) x[nb][e] = 0.0f;
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const h8 a = ld_frag(lds, f_dx + mt0 * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], x[nb]);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, 32 * mt0, in_dim, x[nb], h);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- M3: weight gradients, split-K over the batch
+// Layer id j: 0 = input layer (dW0 = delta_0^T x), 1..num_layers-1 = hidden matrix j-1, num_layers = output layer.
+//   dW[o][i] = sum_b D[b][o] * A[b][i]   with D = delta (or grad for the output layer), A = layer input.
+// A workgroup streams 64-sample chunks of D and A through LDS (coalesced 16-byte loads), each wave owns
+// 32x32 output tiles and reads its MFMA operands transposed out of LDS; partial sums go to the fp32
+// workspace with float atomics shaped as whole 128-byte row segments.
+#define DW_CHUNK 64
+template <int HIDDEN>
+__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
+                                                      const _Float16 *__restrict__ fwd_buf, const _Float16 *__restrict__ bwd_buf,
+                                                      float *__restrict__ ws, uint32_t B, uint32_t in_dim, uint32_t num_layers) {
+    constexpr int LDP = 8;   // row padding (halfs) to spread the strided 2-byte reads over banks
+    __shared__ __attribute__((aligned(16))) _Float16 sD[DW_CHUNK][HIDDEN + LDP];
+    __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][128 + LDP];
+
+    const uint32_t j = blockIdx.y;
+    const _Float16 *Dp; const _Float16 *Ap; uint32_t OUT, IN; uint64_t ws_off;
+    const uint64_t first = (uint64_t)HIDDEN * in_dim, lsz = (uint64_t)HIDDEN * HIDDEN;
+    if (j == 0) { Dp = bwd_buf + (uint64_t)(num_layers - 1) * B * HIDDEN; Ap = inputs; OUT = HIDDEN; IN = in_dim; ws_off = 0; }
+    else if (j < num_layers) { Dp = bwd_buf + (uint64_t)(num_layers - 1 - j) * B * HIDDEN; Ap = fwd_buf + (uint64_t)(j - 1) * B * HIDDEN; OUT = HIDDEN; IN = HIDDEN; ws_off = first + (j - 1) * lsz; }
+    else { Dp = grad; Ap = fwd_buf + (uint64_t)(num_layers - 1) * B * HIDDEN; OUT = 16; IN = HIDDEN; ws_off = first + (uint64_t)(num_layers - 1) * lsz; }
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t MTo = (OUT + 31) / 32, NTi = (IN + 31) / 32, n_out_tiles = MTo * NTi;
+    // up to 4 tiles per wave covers OUT, IN <= 128 (16 tiles / 4 waves)
+    f16v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[t][e] = 0.0f;
+
+    const uint32_t n_chunks = B / DW_CHUNK;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t row0 = (uint64_t)chunk * DW_CHUNK;
+        __syncthreads();
+        // stage D [64 x OUT] and A [64 x IN], 8 halfs per thread-iteration
+        for (uint32_t idx = threadIdx.x; idx < DW_CHUNK * (OUT / 8); idx += MLP_BLOCK) {
+            const uint32_t rr = idx / (OUT / 8), cc = (idx % (OUT / 8)) * 8;
+            *reinterpret_cast<h8 *>(&sD[rr][cc]) = *reinterpret_cast<const h8 *>(Dp + (row0 + rr) * OUT + cc);
+        }
+        for (uint32_t idx = threadIdx.x; idx < DW_CHUNK * (IN / 8); idx += MLP_BLOCK) {
+            const uint32_t rr = idx / (IN / 8), cc = (idx % (IN / 8)) * 8;
+            *reinterpret_cast<h8 *>(&sA[rr][cc]) = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t tile = wave + t * MLP_WAVES;
+            if (tile < n_out_tiles) {
+                const uint32_t mt = tile / NTi, nt = tile % NTi;
+                const uint32_t o = 32 * mt + r, i = 32 * nt + r;
+#pragma unroll
+                for (int ks = 0; ks < DW_CHUNK / 16; ks++) {
+                    h8 a, b;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int bb = 16 * ks + 8 * h + e;
+                        a[e] = o < OUT ? sD[bb][o] : (_Float16)0;
+                        b[e] = i < IN ? sA[bb][i] : (_Float16)0;
+                    }
+                    acc[t] = mfma16(a, b, acc[t]);
+                }
+            }
+        }
+    }
+    // accumulate partial tiles: lane holds column i = 32*nt + r, rows o = 32*mt + acc_row(reg, h)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t tile = wave + t * MLP_WAVES;
+        if (tile < n_out_tiles) {
+            const uint32_t mt = tile / NTi, nt = tile % NTi;
+            const uint32_t i = 32 * nt + r;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const uint32_t o = 32 * mt + acc_row(reg, h);
+                if (o < OUT && i < IN) (void)__hip_atomic_fetch_add(ws + ws_off + (uint64_t)o * IN + i, acc[t][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// fp32 workspace -> fp16 grad_weights (one rounding, like a full-K fp32 accumulation)
+__global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict__ ws, _Float16 *__restrict__ gw, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) gw[i] = (_Float16)ws[i];
+}
+
+// ================================================================= host side
+static uint32_t g_num_cus = 0;
+static uint32_t mlp_num_cus() {
+    if (!g_num_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cus = (uint32_t)n;
+    }
+    return g_num_cus;
+}
+
+static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                     uint32_t activation, uint32_t output_activation) {
+    FOC_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128, FOC_E_INVALID,
+                "%s: hidden_dim should in [16, 32, 64, 128] (got %u; 256 is not built)", who, hidden_dim);   // ffmlp.cu:658
+    FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 128, FOC_E_INVALID, "%s: input_dim must be 16*m, m in [1,8] (got %u)", who, input_dim);
+    FOC_REQUIRE(output_dim <= 16, FOC_E_INVALID, "%s: output_dim must be <= 16 (got %u)", who, output_dim);
+    FOC_REQUIRE(num_layers >= 2 && num_layers <= 16, FOC_E_INVALID, "%s: num_layers must be in [2,16] (got %u)", who, num_layers);
+    FOC_REQUIRE(B % 128 == 0, FOC_E_INVALID, "%s: B must be a multiple of 128 (got %u)", who, B);
+    FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "%s: hidden activation must be relu(0) or none(6) (got %u)", who, activation);
+    FOC_REQUIRE(output_activation == 6, FOC_E_INVALID, "%s: output activation must be none(6) (got %u)", who, output_activation);
+    return FOC_OK;
+}
+
+template <int HIDDEN>
+static size_t mlp_fwd_lds(uint32_t in_dim, uint32_t num_layers) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    return (size_t)(MT * (in_dim / 16) + (num_layers - 1) * MT * KC + KC) * 1024;
+}
+template <int HIDDEN>
+static size_t mlp_bwd_lds(uint32_t in_dim, uint32_t num_layers, bool dx) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    return (size_t)(MT + (num_layers - 1) * MT * KC + (dx ? ((in_dim + 31) / 32) * KC : 0)) * 1024;
+}
+
+template <int HIDDEN, bool TRAIN>
+static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
+                          void *fwd_buf, void *outputs, hipStream_t st) {
+    constexpr int NB = 2;
+    const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
+    FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
+    auto kern = k_mlp_fwd<HIDDEN, NB, TRAIN>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint32_t n_tiles = B / (32 * NB);
+    uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
+    const uint32_t cap = mlp_num_cus() * 4;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu);
+    FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
+    return FOC_OK;
+}
+
+template <bool TRAIN>
+static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                   uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *buffer, void *outputs, void *stream) {
+    const char *who = TRAIN ? "ffmlp_forward" : "ffmlp_inference";
+    FOC_REQUIRE(inputs && weights && outputs && (!TRAIN || buffer), FOC_E_INVALID, "%s: null pointer", who);
+    int rc = mlp_check(who, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+    if (rc) return rc;
+    if (B == 0) return FOC_OK;
+    const int relu = activation == 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (hidden_dim) {
+        case 16: return mlp_fwd_launch<16, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
+        case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
+        case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
+        case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
+    }
+    return FOC_E_INVALID;
+}
+
+template <int HIDDEN>
+static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim,
+                          uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, hipStream_t st) {
+    constexpr int NB = 2;
+    const bool dx = grad_inputs != nullptr;
+    const size_t lds = mlp_bwd_lds<HIDDEN>(in_dim, num_layers, dx);
+    FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: weights (%zu B) do not fit the 160 KiB LDS", lds);
+    auto kern = k_mlp_bwd<HIDDEN, NB>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint32_t n_tiles = B / (32 * NB);
+    uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
+    const uint32_t cap = mlp_num_cus() * 4;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)weights, (const _Float16 *)fwd_buf,
+                       (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, B, in_dim, num_layers, relu);
+    FOC_CHECK_LAUNCH("ffmlp_backward(activations)");
+    // weight gradients
+    const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
+    if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
+    uint32_t gx = B / DW_CHUNK;
+    const uint32_t capx = foc_div_up(mlp_num_cus() * 2, num_layers + 1);
+    if (gx > capx) gx = capx;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((k_mlp_dw<HIDDEN>), dim3(gx, num_layers + 1), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
+                       (const _Float16 *)fwd_buf, (const _Float16 *)bwd_buf, ws, B, in_dim, num_layers);
+    FOC_CHECK_LAUNCH("ffmlp_backward(weights)");
+    hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
+    FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
+    return FOC_OK;
+}
+
+extern "C" {
+
+int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                      uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *forward_buffer, void *outputs, void *stream) {
+    return mlp_fwd<true>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs, stream);
+}
+
+int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                        uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *inference_buffer, void *outputs, void *stream) {
+    return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference_buffer, outputs, stream);
+}
+
+uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    return (uint64_t)hidden_dim * (input_dim + (uint64_t)hidden_dim * (num_layers - 1) + 16) * sizeof(float);
+}
+
+int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
+                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
+    FOC_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
+    FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
+    int rc = mlp_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
+    if (rc) return rc;
+    if (B == 0) return FOC_OK;
+    const int relu = activation == 0;
+    hipStream_t st = (hipStream_t)stream;
+    void *gi = calc_grad_inputs ? grad_inputs : nullptr;
+    switch (hidden_dim) {
+        case 16: return mlp_bwd_launch<16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
+        case 32: return mlp_bwd_launch<32>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
+        case 64: return mlp_bwd_launch<64>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
+        case 128: return mlp_bwd_launch<128>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
+    }
+    return FOC_E_INVALID;
+}
+
+int foc_allocate_splitk(uint64_t size) { (void)size; return FOC_OK; }
+int foc_free_splitk(void) { return FOC_OK; }
+
+} // extern "C"

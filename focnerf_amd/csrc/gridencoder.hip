@@ -1,0 +1,611 @@
+// gridencoder.hip — multiresolution hash / tiled grid encoding for gfx950.
+//
+// Semantics: gridencoder/src/gridencoder.cu of the reference (kernel_grid :87-245,
+// kernel_grid_backward :248-340, kernel_input_backward :343-369, kernel_grad_tv :506-610).
+//
+// MI355X organisation:
+//  * Level placement is XCD-aware. Workgroups are dealt round-robin over the 8 XCDs
+//    (block b and b+8 share one), each XCD has a private 4 MiB L2, and one hashed level
+//    of the default table is 2^19 rows x 2 ch = 2 MiB (fp16) / 4 MiB (fp32). The 1-D grid
+//    is therefore decoded as  xcd = id % 8, level = xcd + 8 * (j / chunks), so a level's
+//    gathers all come from ONE XCD's L2 and stay resident there, instead of the reference's
+//    blockIdx.y = level (gridencoder.cu:103) which spreads every level over all eight L2s.
+//    This is a speed choice only: any placement gives the same result.
+//  * Per-level scale / resolution are computed on the host (same libm expression as the
+//    oracle) and passed by value: no exp2f per thread, and the integer index math cannot
+//    drift with a device transcendental.
+//  * The [B, L*C] output variant assigns the L levels of one point to adjacent lanes, so a
+//    wave stores 256 contiguous bytes — the reference writes [L,B,C] and pays a permute copy
+//    in Python (grid.py:57).
+//  * Backward: fp16 tables use one packed global_atomic_pk_add_f16 per corner for C=2
+//    (both channels in one dword); fp32 tables use global_atomic_add_f32. Zero gradients
+//    are not issued (adding +-0 is a no-op).
+// Compiled with -ffp-contract=off; explicit fmaf() mirrors oracle/oracle.c.
+#include "common.h"
+#include <math.h>
+
+#define GE_MAX_LEVELS 32
+
+struct GeLevels {
+    float scale[GE_MAX_LEVELS];
+    uint32_t resolution[GE_MAX_LEVELS];
+};
+
+// ---- storage-type helpers -------------------------------------------------------------
+template <typename T> struct GeT;
+template <> struct GeT<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct GeT<__half> {
+    static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
+    static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(v); }
+};
+
+template <typename T, uint32_t C> struct GeVec;
+// loads C consecutive table entries as floats with the widest aligned access
+template <uint32_t C> struct GeVec<float, C> {
+    static __device__ __forceinline__ void ld(const float *p, float (&v)[C]) {
+        if constexpr (C == 1) v[0] = p[0];
+        else if constexpr (C == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 4) { const float4 t = *reinterpret_cast<const float4 *>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
+        }
+    }
+    static __device__ __forceinline__ void st(float *p, const float (&v)[C]) {
+        if constexpr (C == 1) p[0] = v[0];
+        else if constexpr (C == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+        }
+    }
+};
+template <uint32_t C> struct GeVec<__half, C> {
+    static __device__ __forceinline__ void ld(const __half *p, float (&v)[C]) {
+        if constexpr (C == 1) v[0] = __half2float(p[0]);
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 2) { const float2 t = __half22float2(*reinterpret_cast<const __half2 *>(p + i)); v[i] = t.x; v[i + 1] = t.y; }
+        }
+    }
+    static __device__ __forceinline__ void st(__half *p, const float (&v)[C]) {
+        if constexpr (C == 1) p[0] = __float2half_rn(v[0]);
+        else {
+#pragma unroll
+            for (uint32_t i = 0; i < C; i += 2) *reinterpret_cast<__half2 *>(p + i) = __halves2half2(__float2half_rn(v[i]), __float2half_rn(v[i + 1]));
+        }
+    }
+};
+
+// ---- index math (gridencoder.cu:50-84) -------------------------------------------------
+template <uint32_t D>
+__device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                             const uint32_t (&pos_grid)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pos_grid[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) {
+        uint32_t result = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < D; i++) result ^= pos_grid[i] * primes[i];
+        index = result;
+    }
+    return index % hashmap_size;   // row index; caller multiplies by C
+}
+
+// Decode a linear block id into (level, chunk) so that all blocks of a level share
+// blockIdx % 8, i.e. one XCD under the observed round-robin dispatch.
+__device__ __forceinline__ bool ge_decode_block(uint32_t id, uint32_t chunks, uint32_t L, uint32_t &level, uint32_t &chunk) {
+    const uint32_t xcd = id & 7u, j = id >> 3;
+    level = xcd + 8u * (j / chunks);
+    chunk = j % chunks;
+    return level < L;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ bool ge_load_point(const float *__restrict__ inputs, uint32_t b, float (&x)[D]) {
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) { x[d] = inputs[(uint64_t)b * D + d]; oob |= (x[d] < 0 || x[d] > 1); }
+    return oob;
+}
+
+// ---- forward: one (point, level) ---------------------------------------------------------
+// out points at the C outputs of this (point, level); dy points at its [D,C] block or null.
+template <typename T, uint32_t D, uint32_t C>
+__device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, const T *__restrict__ table, uint32_t hashmap_size,
+                                               float scale, uint32_t resolution, T *__restrict__ out, T *__restrict__ dy,
+                                               uint32_t gridtype, bool align_corners, uint32_t interp) {
+    float results[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) results[c] = 0.0f;
+    if (oob) {                                                   // gridencoder.cu:119-135
+        GeVec<T, C>::st(out, results);
+        if (dy) {
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) GeT<T>::st(dy + i, 0.0f);
+        }
+        return;
+    }
+    float pos[D], pos_deriv[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {                           // :147-159
+        pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) {
+            const float v = pos[d];
+            pos_deriv[d] = 6 * v * (1.0f - v);
+            pos[d] = v * v * fmaf(-2.0f, v, 3.0f);
+        } else pos_deriv[d] = 1.0f;
+    }
+    // issue all 2^D gathers before consuming them (latency-bound: keep them in flight)
+    float vals[1u << D][C];
+    float ws[1u << D];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {             // :167-191
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        ws[idx] = w;
+        const uint32_t row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        GeVec<T, C>::ld(table + (uint64_t)row * C, vals[idx]);
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) results[c] = fmaf(ws[idx], vals[idx][c], results[c]);
+    }
+    GeVec<T, C>::st(out, results);
+
+    if (dy) {                                                    // :201-244
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float rg[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) rg[c] = 0.0f;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t pgl[D];
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                pgl[gd] = pos_grid[gd];
+                const uint32_t rl = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+                pgl[gd] = pos_grid[gd] + 1;
+                const uint32_t rr = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+                float vl[C], vr[C];
+                GeVec<T, C>::ld(table + (uint64_t)rl * C, vl);
+                GeVec<T, C>::ld(table + (uint64_t)rr * C, vr);
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) rg[c] = fmaf(w * (vr[c] - vl[c]), pos_deriv[gd], rg[c]);
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) GeT<T>::st(dy + gd * C + c, rg[c]);
+        }
+    }
+}
+
+// Level-major launch, outputs [L,B,C]: thread = point, block decodes (level, chunk) XCD-aware.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ inputs, const T *__restrict__ grid,
+                                                      const int32_t *__restrict__ offsets, T *__restrict__ outputs,
+                                                      uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
+                                                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks) {
+    uint32_t level, chunk;
+    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    const uint32_t b = chunk * 256 + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    float x[D];
+    const bool oob = ge_load_point<D>(inputs, b, x);
+    T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
+    ge_forward_one<T, D, C>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                            outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+}
+
+// Point-major launch, outputs [B, L*C]: consecutive lanes = consecutive levels of one point, so
+// the wave's store is contiguous. Thread id g -> b = g / L, level = g % L.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_fwd_bl(const float *__restrict__ inputs, const T *__restrict__ grid,
+                                                     const int32_t *__restrict__ offsets, T *__restrict__ outputs,
+                                                     uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
+                                                     uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint64_t total = (uint64_t)B * L;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = (uint32_t)(g / L), level = (uint32_t)(g - (uint64_t)b * L);
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+        float x[D];
+        const bool oob = ge_load_point<D>(inputs, b, x);
+        T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
+        ge_forward_one<T, D, C>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                                outputs + g * C, dy, gridtype, align_corners, interp);
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------
+template <typename T> struct GeAtomic;
+template <> struct GeAtomic<float> {
+    template <uint32_t C> static __device__ __forceinline__ void add(float *p, const float (&v)[C]) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++)
+            if (v[c] != 0.0f) (void)__hip_atomic_fetch_add(p + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+template <> struct GeAtomic<__half> {
+    template <uint32_t C> static __device__ __forceinline__ void add(__half *p, const float (&v)[C]) {
+        if constexpr (C == 1) {
+            // C == 1 under fp16 is never produced by the reference wrapper (grid.py:43: half only when C % 2 == 0);
+            // handled with a CAS loop on the containing dword for completeness.
+            const __half hv = __float2half_rn(v[0]);
+            if (__half2float(hv) == 0.0f) return;
+            uint32_t *w = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+            const bool hi = (reinterpret_cast<uintptr_t>(p) & 2) != 0;
+            uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), assumed;
+            do {
+                assumed = old;
+                const uint16_t cur = hi ? (uint16_t)(assumed >> 16) : (uint16_t)(assumed & 0xFFFFu);
+                const __half sum = __float2half_rn(__half2float(__ushort_as_half(cur)) + __half2float(hv));
+                const uint32_t nv = hi ? ((assumed & 0x0000FFFFu) | ((uint32_t)__half_as_ushort(sum) << 16))
+                                       : ((assumed & 0xFFFF0000u) | (uint32_t)__half_as_ushort(sum));
+                old = assumed;
+                __hip_atomic_compare_exchange_strong(w, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (old != assumed);
+        } else {
+            typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c += 2) {
+                // the reference rounds each addend to half before the packed atomic (gridencoder.cu:329)
+                v2h hv;
+                hv[0] = (_Float16)v[c];
+                hv[1] = (_Float16)v[c + 1];
+                if ((float)hv[0] == 0.0f && (float)hv[1] == 0.0f) continue;
+                (void)__builtin_amdgcn_global_atomic_fadd_v2f16(
+                    (__attribute__((address_space(1))) v2h *)(p + c), hv);
+            }
+        }
+    }
+};
+
+template <typename T, uint32_t D, uint32_t C>
+__device__ __forceinline__ void ge_backward_one(const float (&x)[D], const float (&g)[C], T *__restrict__ grad_table,
+                                                uint32_t hashmap_size, float scale, uint32_t resolution,
+                                                uint32_t gridtype, bool align_corners, uint32_t interp) {
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) { const float v = pos[d]; pos[d] = v * v * fmaf(-2.0f, v, 3.0f); }
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        const uint32_t row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        float v[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) v[c] = w * g[c];
+        GeAtomic<T>::template add<C>(grad_table + (uint64_t)row * C, v);
+    }
+}
+
+// grad layout: GRAD_BL ? [B, L*C] : [L, B, C].  Level-major XCD-aware launch, thread = point.
+template <typename T, uint32_t D, uint32_t C, bool GRAD_BL>
+__global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, const float *__restrict__ inputs,
+                                                  const int32_t *__restrict__ offsets, T *__restrict__ grad_grid,
+                                                  uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners,
+                                                  uint32_t interp, uint32_t chunks) {
+    uint32_t level, chunk;
+    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    const uint32_t b = chunk * 256 + threadIdx.x;
+    if (b >= B) return;
+    float x[D];
+    if (ge_load_point<D>(inputs, b, x)) return;                   // :276-281
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    float g[C];
+    const T *gp = GRAD_BL ? grad + ((uint64_t)b * L + level) * C : grad + ((uint64_t)level * B + b) * C;
+    GeVec<T, C>::ld(gp, g);
+    bool any = false;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) any |= (g[c] != 0.0f);
+    if (!any) return;
+    ge_backward_one<T, D, C>(x, g, grad_grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                             gridtype, align_corners, interp);
+}
+
+// gridencoder.cu:343-369: grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (fp32 accumulate)
+template <typename T, uint32_t D, uint32_t C, bool GRAD_BL>
+__global__ void __launch_bounds__(256) k_grid_input_bwd(const T *__restrict__ grad, const T *__restrict__ dy_dx, T *__restrict__ grad_inputs,
+                                                        uint32_t B, uint32_t L) {
+    const uint64_t total = (uint64_t)B * D;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (uint64_t)b * D);
+        float r = 0;
+        for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                const float gv = GeT<T>::ld(GRAD_BL ? grad + ((uint64_t)b * L + l) * C + c : grad + ((uint64_t)l * B + b) * C + c);
+                r = fmaf(gv, GeT<T>::ld(dy_dx + (((uint64_t)b * L + l) * D + d) * C + c), r);
+            }
+        }
+        GeT<T>::st(grad_inputs + t, r);
+    }
+}
+
+// gridencoder.cu:506-610 kernel_grad_tv
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grad_tv(const T *__restrict__ inputs, const T *__restrict__ grid, T *__restrict__ grad,
+                                                 const int32_t *__restrict__ offsets, float weight, uint32_t B, uint32_t L,
+                                                 GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t chunks) {
+    uint32_t level, chunk;
+    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    const uint32_t b = chunk * 256 + threadIdx.x;
+    if (b >= B) return;
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) { x[d] = GeT<T>::ld(inputs + (uint64_t)b * D + d); oob |= (x[d] < 0 || x[d] > 1); }
+    if (oob) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    const uint32_t resolution = lv.resolution[level];
+    const T *tab = grid + (uint64_t)off0 * C;
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) pos_grid[d] = (uint32_t)floorf(fmaf(x[d], scale, align_corners ? 0.0f : 0.5f));
+    float results[C], idelta[C], center[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) { results[c] = 0; idelta[c] = 0; }
+    const uint32_t row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid);
+    GeVec<T, C>::ld(tab + (uint64_t)row * C, center);
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur = pos_grid[d];
+        if (cur < resolution) {
+            pos_grid[d] = cur + 1;
+            float o[C];
+            GeVec<T, C>::ld(tab + (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C, o);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) { const float gv = center[c] - o[c]; results[c] += gv; idelta[c] = fmaf(gv, gv, idelta[c]); }
+        }
+        if (cur > 0) {
+            pos_grid[d] = cur - 1;
+            float o[C];
+            GeVec<T, C>::ld(tab + (uint64_t)ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pos_grid) * C, o);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) { const float gv = center[c] - o[c]; results[c] += gv; idelta[c] = fmaf(gv, gv, idelta[c]); }
+        }
+        pos_grid[d] = cur;
+    }
+    float v[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) v[c] = w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f));
+    GeAtomic<T>::template add<C>(grad + ((uint64_t)off0 + row) * C, v);
+}
+
+// ================================================================= host side
+static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
+    if (L > GE_MAX_LEVELS) return 1;
+    for (uint32_t l = 0; l < L; l++) {
+        // gridencoder.cu:138-139, evaluated with the host libm (identical to oracle/oracle.c)
+        const float sc = exp2f((float)l * S) * (float)H - 1.0f;
+        lv.scale[l] = sc;
+        lv.resolution[l] = (uint32_t)ceil((double)sc) + 1;
+    }
+    for (uint32_t l = L; l < GE_MAX_LEVELS; l++) { lv.scale[l] = 0; lv.resolution[l] = 1; }
+    return 0;
+}
+
+static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * chunks * ((L + 7u) / 8u); }
+
+template <typename T, uint32_t D, uint32_t C>
+static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
+                             const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
+    if (bl) {
+        const uint64_t total = (uint64_t)B * L;
+        const uint32_t grid = (uint32_t)((total + 255) / 256 > 0x7FFFFFFFull ? 0x7FFFFFFFull : (total + 255) / 256);
+        hipLaunchKernelGGL((k_grid_fwd_bl<T, D, C>), dim3(grid), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv,
+                           (T *)dy_dx, gridtype, ac, interp);
+    } else {
+        const uint32_t chunks = foc_div_up(B, 256);
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks);
+    }
+    FOC_CHECK_LAUNCH("grid_encode_forward");
+    return FOC_OK;
+}
+
+template <typename T, uint32_t D>
+static int ge_forward_c(uint32_t C, const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
+                        const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
+    switch (C) {
+        case 1: return ge_forward_launch<T, D, 1>(inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        case 2: return ge_forward_launch<T, D, 2>(inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        case 4: return ge_forward_launch<T, D, 4>(inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        case 8: return ge_forward_launch<T, D, 8>(inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        default: foc_set_error("GridEncoding: C must be 1, 2, 4, or 8."); return FOC_E_INVALID;   // gridencoder.cu:381
+    }
+}
+
+template <typename T>
+static int ge_forward_d(uint32_t D, uint32_t C, const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B,
+                        uint32_t L, const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
+    switch (D) {
+        case 2: return ge_forward_c<T, 2>(C, inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        case 3: return ge_forward_c<T, 3>(C, inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        default: foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D); return FOC_E_INVALID;
+    }
+}
+
+static int ge_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
+                      uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp,
+                      int dtype, bool bl, void *stream) {
+    FOC_REQUIRE(inputs && embeddings && offsets && outputs, FOC_E_INVALID, "grid_encode_forward: null pointer");
+    FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_forward: dtype must be FOC_F32 or FOC_F16");
+    FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grid_encode_forward: L must be in [1,%d]", GE_MAX_LEVELS);
+    FOC_REQUIRE(gridtype <= 1 && interp <= 1, FOC_E_INVALID, "grid_encode_forward: bad gridtype/interp");
+    if (B == 0) return FOC_OK;
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FOC_F32) return ge_forward_d<float>(D, C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, align_corners != 0, interp, bl, st);
+    return ge_forward_d<__half>(D, C, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, align_corners != 0, interp, bl, st);
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static int ge_backward_launch(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L,
+                              const GeLevels &lv, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool ac, uint32_t interp,
+                              bool bl, hipStream_t st) {
+    const uint32_t chunks = foc_div_up(B, 256);
+    if (bl) hipLaunchKernelGGL((k_grid_bwd<T, D, C, true>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, (const T *)grad, inputs, offsets,
+                               (T *)grad_emb, B, L, lv, gridtype, ac, interp, chunks);
+    else hipLaunchKernelGGL((k_grid_bwd<T, D, C, false>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, (const T *)grad, inputs, offsets,
+                            (T *)grad_emb, B, L, lv, gridtype, ac, interp, chunks);
+    FOC_CHECK_LAUNCH("grid_encode_backward");
+    if (dy_dx && grad_inputs) {
+        const uint32_t g = foc_grid_1d((uint64_t)B * D, 256);
+        if (bl) hipLaunchKernelGGL((k_grid_input_bwd<T, D, C, true>), dim3(g), dim3(256), 0, st, (const T *)grad, (const T *)dy_dx, (T *)grad_inputs, B, L);
+        else hipLaunchKernelGGL((k_grid_input_bwd<T, D, C, false>), dim3(g), dim3(256), 0, st, (const T *)grad, (const T *)dy_dx, (T *)grad_inputs, B, L);
+        FOC_CHECK_LAUNCH("grid_encode_backward(inputs)");
+    }
+    return FOC_OK;
+}
+
+template <typename T, uint32_t D>
+static int ge_backward_c(uint32_t C, const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L,
+                         const GeLevels &lv, const void *dy_dx, void *grad_inputs, uint32_t gridtype, bool ac, uint32_t interp, bool bl,
+                         hipStream_t st) {
+    switch (C) {
+        case 1: return ge_backward_launch<T, D, 1>(grad, inputs, offsets, grad_emb, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        case 2: return ge_backward_launch<T, D, 2>(grad, inputs, offsets, grad_emb, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        case 4: return ge_backward_launch<T, D, 4>(grad, inputs, offsets, grad_emb, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        case 8: return ge_backward_launch<T, D, 8>(grad, inputs, offsets, grad_emb, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        default: foc_set_error("GridEncoding: C must be 1, 2, 4, or 8."); return FOC_E_INVALID;
+    }
+}
+
+template <typename T, uint32_t D, uint32_t C>
+static int ge_tv_launch(const void *inputs, const void *emb, void *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t L,
+                        const GeLevels &lv, uint32_t gridtype, bool ac, hipStream_t st) {
+    const uint32_t chunks = foc_div_up(B, 256);
+    hipLaunchKernelGGL((k_grad_tv<T, D, C>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, (const T *)inputs, (const T *)emb, (T *)grad, offsets,
+                       weight, B, L, lv, gridtype, ac, chunks);
+    FOC_CHECK_LAUNCH("grad_total_variation");
+    return FOC_OK;
+}
+
+template <typename T, uint32_t D>
+static int ge_tv_c(uint32_t C, const void *inputs, const void *emb, void *grad, const int32_t *offsets, float weight, uint32_t B, uint32_t L,
+                   const GeLevels &lv, uint32_t gridtype, bool ac, hipStream_t st) {
+    switch (C) {
+        case 1: return ge_tv_launch<T, D, 1>(inputs, emb, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        case 2: return ge_tv_launch<T, D, 2>(inputs, emb, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        case 4: return ge_tv_launch<T, D, 4>(inputs, emb, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        case 8: return ge_tv_launch<T, D, 8>(inputs, emb, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        default: foc_set_error("GridEncoding: C must be 1, 2, 4, or 8."); return FOC_E_INVALID;
+    }
+}
+
+extern "C" {
+
+int foc_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
+                            uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                            uint32_t interp, int dtype, const int32_t *offsets_host, void *stream) {
+    (void)offsets_host;
+    return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, false, stream);
+}
+
+int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
+                               uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
+                               uint32_t interp, int dtype, const int32_t *offsets_host, void *stream) {
+    (void)offsets_host;
+    return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, true, stream);
+}
+
+int foc_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                             const int32_t *offsets_host, void *stream) {
+    (void)offsets_host; (void)embeddings;
+    FOC_REQUIRE(grad && inputs && offsets && grad_embeddings, FOC_E_INVALID, "grid_encode_backward: null pointer");
+    FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_backward: dtype must be FOC_F32 or FOC_F16");
+    FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grid_encode_backward: L must be in [1,%d]", GE_MAX_LEVELS);
+    FOC_REQUIRE(gridtype <= 1 && interp <= 1, FOC_E_INVALID, "grid_encode_backward: bad gridtype/interp");
+    if (B == 0) return FOC_OK;
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ac = align_corners != 0, bl = grad_is_bl != 0;
+    if (dtype == FOC_F32) {
+        switch (D) {
+            case 2: return ge_backward_c<float, 2>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+            case 3: return ge_backward_c<float, 3>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        }
+    } else {
+        switch (D) {
+            case 2: return ge_backward_c<__half, 2>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+            case 3: return ge_backward_c<__half, 3>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+        }
+    }
+    foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D);
+    return FOC_E_INVALID;
+}
+
+int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets, float weight, uint32_t B,
+                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
+                             void *stream) {
+    FOC_REQUIRE(inputs && embeddings && grad && offsets, FOC_E_INVALID, "grad_total_variation: null pointer");
+    FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grad_total_variation: dtype must be FOC_F32 or FOC_F16");
+    FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grad_total_variation: L must be in [1,%d]", GE_MAX_LEVELS);
+    if (B == 0) return FOC_OK;
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ac = align_corners != 0;
+    if (dtype == FOC_F32) {
+        switch (D) {
+            case 2: return ge_tv_c<float, 2>(C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+            case 3: return ge_tv_c<float, 3>(C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        }
+    } else {
+        switch (D) {
+            case 2: return ge_tv_c<__half, 2>(C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+            case 3: return ge_tv_c<__half, 3>(C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);
+        }
+    }
+    foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D);
+    return FOC_E_INVALID;
+}
+
+} // extern "C"

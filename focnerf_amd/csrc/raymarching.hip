@@ -1,0 +1,662 @@
+// raymarching.hip — gfx950 kernels behind the _raymarching entry points of include/focnerf.h.
+//
+// Semantics follow raymarching/src/raymarching.cu of the reference (line cites per kernel);
+// the kernels themselves are organised for CDNA4:
+//   * marching is split into count -> ordered scan -> write, so slot reservation is a
+//     deterministic prefix sum in ray order instead of the reference's atomicAdd race
+//     (raymarching.cu:405-406);
+//   * train-time compositing runs ONE WAVE PER RAY: 64 consecutive samples are loaded
+//     coalesced, transmittance is a wave product-scan (DPP shuffles), early termination
+//     is a ballot, the per-ray sums are wave reductions — instead of the reference's one
+//     thread walking its own ray segment (uncoalesced, 128 rays per block).
+// Floating-point policy: compiled with -ffp-contract=off; fused multiply-adds are written
+// as explicit fmaf() exactly where oracle/oracle.c has them, so the marching control flow
+// (and therefore every sample index and position) is bit-identical to the oracle.
+#include "common.h"
+#include <float.h>
+
+#define RM_SQRT3 1.7320508075688772f
+#define RM_RPI   0.3183098861837907f
+
+__device__ __forceinline__ float rm_sign(float x) { return copysignf(1.0f, x); }
+__device__ __forceinline__ float rm_clamp(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+__device__ __forceinline__ uint32_t rm_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t rm_morton3D(uint32_t x, uint32_t y, uint32_t z) {
+    return rm_expand_bits(x) | (rm_expand_bits(y) << 1) | (rm_expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t rm_morton3D_invert(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// frexpf exponent of a non-negative finite float without the libcall: for x = 0 frexpf
+// returns exponent 0; subnormals never reach a positive exponent, and only max(0, e) is used.
+__device__ __forceinline__ int rm_frexp_exp(float x) {
+    int e;
+    (void)frexpf(x, &e);
+    return e;
+}
+
+// ---------------------------------------------------------------- R1 (raymarching.cu:92-145)
+__global__ void __launch_bounds__(256) k_near_far_from_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                     const float *__restrict__ aabb, uint32_t N, float min_near,
+                                     float *__restrict__ nears, float *__restrict__ fars) {
+    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx, t;
+        if (near > far) { t = near; near = far; far = t; }
+        float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
+        if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
+        bool miss = (near > far_y || near_y > far);
+        if (!miss) {
+            if (near_y > near) near = near_y;
+            if (far_y < far) far = far_y;
+            float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
+            if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
+            miss = (near > far_z || near_z > far);
+            if (!miss) {
+                if (near_z > near) near = near_z;
+                if (far_z < far) far = far_z;
+                if (near < min_near) near = min_near;
+            }
+        }
+        nears[n] = miss ? FLT_MAX : near;
+        fars[n] = miss ? FLT_MAX : far;
+    }
+}
+
+// ---------------------------------------------------------------- R2 (raymarching.cu:163-198)
+__global__ void __launch_bounds__(256) k_sph_from_ray(const float *__restrict__ rays_o, const float *__restrict__ rays_d, float radius,
+                               uint32_t N, float *__restrict__ coords) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+        const float C = fmaf(-radius, radius, fmaf(oz, oz, fmaf(oy, oy, ox * ox)));
+        const float t = (-B + sqrtf(fmaf(B, B, -(A * C)))) / A;
+        const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+        const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+        const float phi = atan2f(z, x);
+        coords[n * 2] = fmaf(2 * theta, RM_RPI, -1.0f);
+        coords[n * 2 + 1] = phi * RM_RPI;
+    }
+}
+
+// ---------------------------------------------------------------- R3/R4 (raymarching.cu:214-254)
+__global__ void __launch_bounds__(256) k_morton3D(const int32_t *__restrict__ coords, uint32_t N, int32_t *__restrict__ indices) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+        indices[n] = (int32_t)rm_morton3D((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void __launch_bounds__(256) k_morton3D_invert(const int32_t *__restrict__ indices, uint32_t N, int32_t *__restrict__ coords) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const int32_t ind = indices[n];
+        coords[n * 3] = (int32_t)rm_morton3D_invert((uint32_t)(ind >> 0));
+        coords[n * 3 + 1] = (int32_t)rm_morton3D_invert((uint32_t)(ind >> 1));
+        coords[n * 3 + 2] = (int32_t)rm_morton3D_invert((uint32_t)(ind >> 2));
+    }
+}
+
+// ---------------------------------------------------------------- R5 (raymarching.cu:267-289)
+// One thread packs 32 cells (8 x float4 loads, 128 B contiguous per lane) into one dword, so a
+// wave streams 8 KiB per iteration and stores 256 contiguous bytes.
+__global__ void __launch_bounds__(256) k_packbits_x4(const float4 *__restrict__ grid4, uint32_t N4, float thresh,
+                              uint32_t *__restrict__ bitfield4) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N4; n += gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float4 v = grid4[(uint64_t)n * 8 + q];
+            bits |= (v.x > thresh ? 1u : 0u) << (q * 4 + 0);
+            bits |= (v.y > thresh ? 1u : 0u) << (q * 4 + 1);
+            bits |= (v.z > thresh ? 1u : 0u) << (q * 4 + 2);
+            bits |= (v.w > thresh ? 1u : 0u) << (q * 4 + 3);
+        }
+        bitfield4[n] = bits;
+    }
+}
+__global__ void __launch_bounds__(256) k_packbits_tail(const float *__restrict__ grid, uint32_t n0, uint32_t N, float thresh,
+                                uint8_t *__restrict__ bitfield) {
+    for (uint32_t n = n0 + blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) bits |= (grid[(uint64_t)n * 8 + i] > thresh ? 1u : 0u) << i;
+        bitfield[n] = (uint8_t)bits;
+    }
+}
+
+// ---------------------------------------------------------------- marching core
+// One cell lookup (raymarching.cu:361-379 == :429-448 == :752-770).
+struct RmCell { float x, y, z, dt, mip_bound; int nx, ny, nz; };
+
+struct RmParams {
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
+    uint32_t H;
+};
+
+__device__ __forceinline__ bool rm_cell(const uint8_t *__restrict__ grid, const RmParams &p, float ox, float oy, float oz,
+                                        float dx, float dy, float dz, float t, RmCell &c) {
+    c.x = rm_clamp(fmaf(t, dx, ox), -p.bound, p.bound);
+    c.y = rm_clamp(fmaf(t, dy, oy), -p.bound, p.bound);
+    c.z = rm_clamp(fmaf(t, dz, oz), -p.bound, p.bound);
+    c.dt = rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max);
+    // mip_from_pos / mip_from_dt (:42-54): float min/max, then truncation
+    const float mx = fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z)));
+    const int l1 = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)rm_frexp_exp(mx)));
+    const float mdt = (float)((double)(c.dt * p.Hf) * 0.5);
+    const int l2 = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)rm_frexp_exp(mdt)));
+    const int level = l1 > l2 ? l1 : l2;
+    c.mip_bound = fminf(scalbnf(1.0f, level), p.bound);
+    const float mip_rbound = 1 / c.mip_bound;
+    // 0.5 * (x * mip_rbound + 1) * H in double, narrowed to float by clamp()'s parameter (:374-376)
+    c.nx = (int)rm_clamp((float)(0.5 * (double)fmaf(c.x, mip_rbound, 1.0f) * (double)p.H), 0.0f, p.Hm1);
+    c.ny = (int)rm_clamp((float)(0.5 * (double)fmaf(c.y, mip_rbound, 1.0f) * (double)p.H), 0.0f, p.Hm1);
+    c.nz = (int)rm_clamp((float)(0.5 * (double)fmaf(c.z, mip_rbound, 1.0f) * (double)p.H), 0.0f, p.Hm1);
+    // level * H3 + morton in float (:339,:378)
+    const uint32_t index = (uint32_t)fmaf((float)level, p.H3, (float)rm_morton3D((uint32_t)c.nx, (uint32_t)c.ny, (uint32_t)c.nz));
+    return (grid[index >> 3] & (1u << (index & 7u))) != 0;
+}
+
+// Empty cell: jump to the voxel exit (:389-398).
+__device__ __forceinline__ float rm_skip(const RmParams &p, const RmCell &c, float t, float dx, float dy, float dz,
+                                         float rdx, float rdy, float rdz) {
+    const float tx = fmaf(fmaf(fmaf(0.5f, rm_sign(dx), (float)c.nx + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.x) * rdx;
+    const float ty = fmaf(fmaf(fmaf(0.5f, rm_sign(dy), (float)c.ny + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.y) * rdy;
+    const float tz = fmaf(fmaf(fmaf(0.5f, rm_sign(dz), (float)c.nz + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.z) * rdz;
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do { t += rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max); } while (t < tt);
+    return t;
+}
+
+static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    RmParams p;
+    p.bound = bound; p.dt_gamma = dt_gamma;
+    // same float expressions as raymarching.cu:345-346 (IEEE division on host == device)
+    p.dt_min = 2 * RM_SQRT3 / (float)max_steps;
+    p.dt_max = 2 * RM_SQRT3 * (float)(1 << (C - 1)) / (float)H;
+    p.rH = 1 / (float)H;
+    p.H3 = (float)(H * H * H);
+    p.Hf = (float)H; p.Cf = (float)C; p.Hm1 = (float)(H - 1);
+    p.H = H;
+    return p;
+}
+
+// ---------------------------------------------------------------- R6 pass 1: count (raymarching.cu:348-400)
+__global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                              const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
+                              const float *__restrict__ nears, const float *__restrict__ fars,
+                              const float *__restrict__ noises, int32_t *__restrict__ counts) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    uint32_t num_steps = 0;
+    RmCell c;
+    while (t < far && num_steps < max_steps) {
+        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) { num_steps++; t += c.dt; }
+        else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+    }
+    counts[n] = (int32_t)num_steps;
+}
+
+// ---------------------------------------------------------------- R6 pass 2: ordered slot reservation
+// One 1024-thread workgroup scans the N counts in ray order (each thread owns a contiguous
+// chunk), writes rays[n] = (n, base + exclusive_prefix, count) and bumps the two counters —
+// the deterministic stand-in for the atomicAdd pair of raymarching.cu:405-413.
+__global__ void __launch_bounds__(1024) k_march_scan(const int32_t *__restrict__ counts, uint32_t N,
+                                                     int32_t *__restrict__ rays, int32_t *__restrict__ counter) {
+    __shared__ int s_wave[16];
+    __shared__ int s_total;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (N + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(N, lo + per);
+    int local = 0;
+    for (uint32_t i = lo; i < hi; i++) local += counts[i];
+    const int incl = wave_incl_sum_i(local, (int)lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int v = lane < 16 ? s_wave[lane] : 0;
+        const int vi = wave_incl_sum_i(v, (int)lane);
+        if (lane < 16) s_wave[lane] = vi - v;   // exclusive base per wave
+        if (lane == 15) s_total = vi;
+    }
+    __syncthreads();
+    const int base0 = counter[0];
+    const int ray0 = counter[1];
+    int run = base0 + s_wave[wave] + (incl - local);
+    for (uint32_t i = lo; i < hi; i++) {
+        const int c = counts[i];
+        const uint32_t r = i;   // rows in ray order; a non-zero counter[1] would index past rays[N,3] in the reference
+        rays[r * 3] = (int32_t)i; rays[r * 3 + 1] = run; rays[r * 3 + 2] = c;
+        run += c;
+    }
+    __syncthreads();
+    if (tid == 0) { counter[0] = base0 + s_total; counter[1] = ray0 + (int32_t)N; }
+}
+
+// ---------------------------------------------------------------- R6 pass 3: write (raymarching.cu:415-479)
+__global__ void __launch_bounds__(64) k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                              const uint8_t *__restrict__ grid, RmParams p, uint32_t N, uint32_t M,
+                              const float *__restrict__ nears, const float *__restrict__ fars,
+                              const float *__restrict__ noises, const int32_t *__restrict__ rays,
+                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0) return;
+    if (point_index + num_steps > M) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    float last_t = t;
+    float *px = xyzs + (uint64_t)point_index * 3, *pd = dirs + (uint64_t)point_index * 3, *pl = deltas + (uint64_t)point_index * 2;
+    uint32_t step = 0;
+    RmCell c;
+    while (t < far && step < num_steps) {
+        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
+            px[0] = c.x; px[1] = c.y; px[2] = c.z;
+            pd[0] = dx; pd[1] = dy; pd[2] = dz;
+            t += c.dt;
+            pl[0] = c.dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+    }
+}
+
+// ---------------------------------------------------------------- R7 (raymarching.cu:500-577), one wave per ray
+__global__ void __launch_bounds__(256) k_composite_train_fwd(const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                      const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                      uint32_t M, uint32_t N, float T_thresh,
+                                      float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) {
+        if (lane == 0) { weights_sum[index] = 0; depth[index] = 0; image[index * 3] = 0; image[index * 3 + 1] = 0; image[index * 3 + 2] = 0; }
+        return;
+    }
+    float T_carry = 1.0f, t_carry = 0.0f;
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < num_steps;
+        float sigma = 0, dt0 = 0, dt1 = 0, c0 = 0, c1 = 0, c2 = 0;
+        if (valid) {
+            const uint64_t s = (uint64_t)offset + i;
+            sigma = sigmas[s];
+            const float2 dl = *reinterpret_cast<const float2 *>(deltas + s * 2);
+            dt0 = dl.x; dt1 = dl.y;
+            c0 = rgbs[s * 3]; c1 = rgbs[s * 3 + 1]; c2 = rgbs[s * 3 + 2];
+        }
+        const float alpha = valid ? 1.0f - __expf(-sigma * dt0) : 0.0f;
+        const float om = 1.0f - alpha;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float T_before = T_carry * Pex;
+        const float T_after = T_carry * P;
+        const float tsum = t_carry + wave_incl_sum(dt1, (int)lane);
+        // the reference breaks AFTER accumulating the sample whose T drops below the threshold
+        const unsigned long long term = __ballot(valid && (T_after < T_thresh));
+        const int first = term ? (int)__ffsll((long long)term) - 1 : 64;
+        const float w = (valid && (int)lane <= first) ? alpha * T_before : 0.0f;
+        r = fmaf(w, c0, r); g = fmaf(w, c1, g); b = fmaf(w, c2, b);
+        d = fmaf(w, tsum, d);
+        ws += w;
+        if (term) break;
+        T_carry = __shfl(T_after, 63, 64);
+        t_carry = __shfl(tsum, 63, 64);
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+    if (lane == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+// ---------------------------------------------------------------- R8 (raymarching.cu:601-682), one wave per ray
+__global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__restrict__ grad_weights_sum, const float *__restrict__ grad_image,
+                                      const float *__restrict__ sigmas, const float *__restrict__ rgbs,
+                                      const float *__restrict__ deltas, const int32_t *__restrict__ rays,
+                                      const float *__restrict__ weights_sum, const float *__restrict__ image,
+                                      uint32_t M, uint32_t N, float T_thresh,
+                                      float *__restrict__ grad_sigmas, float *__restrict__ grad_rgbs) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float g0 = grad_image[index * 3], g1 = grad_image[index * 3 + 1], g2 = grad_image[index * 3 + 2];
+    const float gws = grad_weights_sum[index];
+    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
+    const float ws_term = gws * (1 - weights_sum[index]);
+    float T_carry = 1.0f;
+    float r_carry = 0, g_carry = 0, b_carry = 0;
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < num_steps;
+        const uint64_t s = (uint64_t)offset + (valid ? i : 0);
+        float sigma = 0, dt0 = 0, c0 = 0, c1 = 0, c2 = 0;
+        if (valid) {
+            sigma = sigmas[s];
+            dt0 = deltas[s * 2];
+            c0 = rgbs[s * 3]; c1 = rgbs[s * 3 + 1]; c2 = rgbs[s * 3 + 2];
+        }
+        const float alpha = valid ? 1.0f - __expf(-sigma * dt0) : 0.0f;
+        const float om = 1.0f - alpha;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float T_before = T_carry * Pex;
+        const float T_after = T_carry * P;
+        const unsigned long long term = __ballot(valid && (T_after < T_thresh));
+        const int first = term ? (int)__ffsll((long long)term) - 1 : 64;
+        const bool act = valid && (int)lane <= first;
+        const float w = act ? alpha * T_before : 0.0f;
+        // running colour INCLUDING this sample (:648-650)
+        const float r_acc = r_carry + wave_incl_sum(w * c0, (int)lane);
+        const float g_acc = g_carry + wave_incl_sum(w * c1, (int)lane);
+        const float b_acc = b_carry + wave_incl_sum(w * c2, (int)lane);
+        if (act) {
+            grad_rgbs[s * 3] = g0 * w; grad_rgbs[s * 3 + 1] = g1 * w; grad_rgbs[s * 3 + 2] = g2 * w;
+            float acc = g0 * fmaf(T_after, c0, -(r_final - r_acc));
+            acc = fmaf(g1, fmaf(T_after, c1, -(g_final - g_acc)), acc);
+            acc = fmaf(g2, fmaf(T_after, c2, -(b_final - b_acc)), acc);
+            acc += ws_term;
+            grad_sigmas[s] = dt0 * acc;
+        }
+        if (term) break;
+        T_carry = __shfl(T_after, 63, 64);
+        r_carry = __shfl(r_acc, 63, 64); g_carry = __shfl(g_acc, 63, 64); b_carry = __shfl(b_acc, 63, 64);
+    }
+}
+
+// ---------------------------------------------------------------- R9 (raymarching.cu:700-805)
+__global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float *px = xyzs + (uint64_t)n * n_step * 3, *pd = dirs + (uint64_t)n * n_step * 3, *pl = deltas + (uint64_t)n * n_step * 2;
+    float t = rays_t[index];
+    const float far = fars[index];
+    t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    float last_t = t;
+    uint32_t step = 0;
+    RmCell c;
+    while (t < far && step < n_step) {
+        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
+            px[0] = c.x; px[1] = c.y; px[2] = c.z;
+            pd[0] = dx; pd[1] = dy; pd[2] = dz;
+            t += c.dt;
+            pl[0] = c.dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+    }
+}
+
+// ---------------------------------------------------------------- R10 (raymarching.cu:818-905)
+__global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                 int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                                 const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                 float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float *s = sigmas + (uint64_t)n * n_step, *c = rgbs + (uint64_t)n * n_step * 3, *dl = deltas + (uint64_t)n * n_step * 2;
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        r = fmaf(weight, c[0], r); g = fmaf(weight, c[1], g); b = fmaf(weight, c[2], b);
+        if (T < T_thresh) break;
+        s++; c += 3; dl += 2; step++;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// ---------------------------------------------------------------- ordered compaction of rays_alive >= 0
+__global__ void __launch_bounds__(1024) k_compact_count(const int32_t *__restrict__ in, uint32_t n, int32_t *__restrict__ block_counts) {
+    __shared__ int s_w[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const int keep = (i < n && in[i] >= 0) ? 1 : 0;
+    const int c = wave_sum_i(keep);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; k++) t += s_w[k]; block_counts[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(1024) k_compact_scan(int32_t *__restrict__ block_counts, uint32_t nb, int32_t *__restrict__ n_out) {
+    // single workgroup: exclusive scan of nb block counts in place
+    __shared__ int s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(nb, lo + per);
+    int local = 0;
+    for (uint32_t i = lo; i < hi; i++) local += block_counts[i];
+    const int incl = wave_incl_sum_i(local, (int)lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int v = lane < 16 ? s_wave[lane] : 0;
+        const int vi = wave_incl_sum_i(v, (int)lane);
+        if (lane < 16) s_wave[lane] = vi - v;
+        if (lane == 15) n_out[0] = vi;
+    }
+    __syncthreads();
+    int run = s_wave[wave] + (incl - local);
+    for (uint32_t i = lo; i < hi; i++) { const int c = block_counts[i]; block_counts[i] = run; run += c; }
+}
+__global__ void __launch_bounds__(1024) k_compact_scatter(const int32_t *__restrict__ in, uint32_t n, const int32_t *__restrict__ block_base,
+                                                          int32_t *__restrict__ out) {
+    __shared__ int s_w[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = i < n ? in[i] : -1;
+    const int keep = v >= 0 ? 1 : 0;
+    const int incl = wave_incl_sum_i(keep, (int)lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (uint32_t k = 0; k < wave; k++) wbase += s_w[k];
+    if (keep) out[block_base[blockIdx.x] + wbase + incl - 1] = v;
+}
+
+// ================================================================= host entry points
+extern "C" {
+
+int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
+                           float *nears, float *fars, void *stream) {
+    FOC_REQUIRE(rays_o && rays_d && aabb && nears && fars, FOC_E_INVALID, "near_far_from_aabb: null pointer");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_near_far_from_aabb, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, aabb, N, min_near, nears, fars);
+    FOC_CHECK_LAUNCH("near_far_from_aabb");
+    return FOC_OK;
+}
+
+int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
+    FOC_REQUIRE(rays_o && rays_d && coords, FOC_E_INVALID, "sph_from_ray: null pointer");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
+    FOC_CHECK_LAUNCH("sph_from_ray");
+    return FOC_OK;
+}
+
+int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
+    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D: null pointer");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_morton3D, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
+    FOC_CHECK_LAUNCH("morton3D");
+    return FOC_OK;
+}
+
+int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
+    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D_invert: null pointer");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
+    FOC_CHECK_LAUNCH("morton3D_invert");
+    return FOC_OK;
+}
+
+int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
+    FOC_REQUIRE(grid && bitfield, FOC_E_INVALID, "packbits: null pointer");
+    if (N == 0) return FOC_OK;
+    uint32_t N4 = 0;
+    if ((((uintptr_t)grid) & 15u) == 0 && (((uintptr_t)bitfield) & 3u) == 0) N4 = N / 4;
+    if (N4) {
+        hipLaunchKernelGGL(k_packbits_x4, dim3(foc_grid_1d(N4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4 *>(grid), N4, density_thresh, reinterpret_cast<uint32_t *>(bitfield));
+        FOC_CHECK_LAUNCH("packbits");
+    }
+    if (N4 * 4 < N) {
+        hipLaunchKernelGGL(k_packbits_tail, dim3(foc_grid_1d(N - N4 * 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           grid, N4 * 4, N, density_thresh, bitfield);
+        FOC_CHECK_LAUNCH("packbits(tail)");
+    }
+    return FOC_OK;
+}
+
+uint64_t foc_march_rays_train_scratch_bytes(uint32_t N) { return ((uint64_t)N + 64) * sizeof(int32_t); }
+
+int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                         int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+    FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
+                "march_rays_train: null pointer");
+    FOC_REQUIRE(M == 0 || (xyzs && dirs && deltas), FOC_E_INVALID, "march_rays_train: null output with M > 0");
+    FOC_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 512 && max_steps >= 1, FOC_E_INVALID,
+                "march_rays_train: unsupported C=%u H=%u max_steps=%u", C, H, max_steps);
+    // the float index `level*H^3 + morton` of raymarching.cu:378 is exact only below 2^24
+    FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_train: C*H^3 exceeds 2^24");
+    if (N == 0) return FOC_OK;
+    const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch);
+    FOC_CHECK_LAUNCH("march_rays_train(count)");
+    // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
+    // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, st, scratch, N, rays, counter);
+    FOC_CHECK_LAUNCH("march_rays_train(scan)");
+    hipLaunchKernelGGL(k_march_write, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, N, M, nears, fars, noises,
+                       rays, xyzs, dirs, deltas);
+    FOC_CHECK_LAUNCH("march_rays_train(write)");
+    return FOC_OK;
+}
+
+int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
+                                     uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
+                                     void *stream) {
+    FOC_REQUIRE(rays && weights_sum && depth && image, FOC_E_INVALID, "composite_rays_train_forward: null pointer");
+    FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas), FOC_E_INVALID, "composite_rays_train_forward: null input with M > 0");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream,
+                       sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    FOC_CHECK_LAUNCH("composite_rays_train_forward");
+    return FOC_OK;
+}
+
+int foc_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image, const float *sigmas,
+                                      const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
+                                      const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
+                                      float *grad_rgbs, void *stream) {
+    FOC_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, FOC_E_INVALID,
+                "composite_rays_train_backward: null pointer");
+    FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), FOC_E_INVALID,
+                "composite_rays_train_backward: null buffer with M > 0");
+    if (N == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream,
+                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                       grad_sigmas, grad_rgbs);
+    FOC_CHECK_LAUNCH("composite_rays_train_backward");
+    return FOC_OK;
+}
+
+int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                   const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                   const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                   const float *noises, void *stream) {
+    (void)nears;
+    if (n_alive == 0) return FOC_OK;
+    FOC_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, FOC_E_INVALID,
+                "march_rays: null pointer");
+    FOC_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 512 && max_steps >= 1 && n_step >= 1, FOC_E_INVALID,
+                "march_rays: unsupported C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
+    FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays: C*H^3 exceeds 2^24");
+    const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+                       rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    FOC_CHECK_LAUNCH("march_rays");
+    return FOC_OK;
+}
+
+int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                       const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                       float *image, void *stream) {
+    if (n_alive == 0) return FOC_OK;
+    FOC_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, FOC_E_INVALID,
+                "composite_rays: null pointer");
+    hipLaunchKernelGGL(k_composite_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    FOC_CHECK_LAUNCH("composite_rays");
+    return FOC_OK;
+}
+
+int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out, int32_t *scratch, void *stream) {
+    FOC_REQUIRE(n_out && scratch, FOC_E_INVALID, "compact_alive: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nb = foc_div_up(n_alive, 1024);
+    if (n_alive == 0) { (void)hipMemsetAsync(n_out, 0, sizeof(int32_t), st); return FOC_OK; }
+    FOC_REQUIRE(rays_alive && out, FOC_E_INVALID, "compact_alive: null pointer");
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(1024), 0, st, rays_alive, n_alive, scratch);
+    FOC_CHECK_LAUNCH("compact_alive(count)");
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, scratch, nb, n_out);
+    FOC_CHECK_LAUNCH("compact_alive(scan)");
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(1024), 0, st, rays_alive, n_alive, scratch, out);
+    FOC_CHECK_LAUNCH("compact_alive(scatter)");
+    return FOC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,111 @@
+"""Fully fused fp16 MLP — public surface of the reference's ffmlp/ffmlp.py (`ffmlp_forward`,
+`FFMLP`, :15-168), backed by libfocnerf_hip.so (MFMA kernels, fp32 accumulation).
+
+Notes on behaviour kept from the reference:
+  * the weight blob layout and the seed-42 U(+-sqrt(3/hidden)) init (ffmlp.py:120-144);
+  * FFMLP.forward pads the batch with `128 - B % 128` zero rows, i.e. a full extra block when
+    B is already a multiple of 128 (ffmlp.py:157-159) — results for the first B rows are unaffected.
+The stray `from turtle import ...` of ffmlp.py:2 is not reproduced.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from .backend import _ffmlp as _backend
+
+
+class _ffmlp_forward(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.half)
+    def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                inference=False, calc_grad_inputs=False):
+        B = inputs.shape[0]
+        inputs = inputs.contiguous()
+        weights = weights.contiguous()
+        outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
+        if not inference:
+            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                   forward_buffer, outputs)
+            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
+            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
+        else:
+            # the kernel keeps activations in registers; no [B, hidden] scratch is needed (the reference allocates one, ffmlp.py:41)
+            _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                     None, outputs)
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        B = grad.shape[0]
+        grad = grad.contiguous()
+        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
+        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
+        if calc_grad_inputs:
+            grad_inputs = torch.empty_like(inputs)
+        else:
+            grad_inputs = torch.zeros(1, device=grad.device, dtype=grad.dtype)   # dummy, as in the reference (:70)
+        grad_weights = torch.empty_like(weights)
+        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
+        if calc_grad_inputs:
+            return grad_inputs, grad_weights, None, None, None, None, None, None, None, None
+        return None, grad_weights, None, None, None, None, None, None, None, None
+
+
+ffmlp_forward = _ffmlp_forward.apply
+
+
+def convert_activation(act):
+    return {'relu': 0, 'exponential': 1, 'sine': 2, 'sigmoid': 3, 'squareplus': 4, 'softplus': 5}.get(act, 6)
+
+
+class FFMLP(nn.Module):
+    def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation='relu'):
+        super().__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.hidden_dim = hidden_dim
+        self.num_layers = num_layers
+        self.activation = convert_activation(activation)
+        self.output_activation = convert_activation('none')
+        self.tensorcore_width = 16
+
+        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
+        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
+        assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
+        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
+
+        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
+        self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
+        self.weights = nn.Parameter(torch.zeros(self.num_parameters))
+        self.reset_parameters()
+        _backend.allocate_splitk(self.num_layers + 1)
+
+    def cleanup(self):
+        _backend.free_splitk()
+
+    def __repr__(self):
+        return (f"FFMLP: input_dim={self.input_dim} output_dim={self.output_dim} hidden_dim={self.hidden_dim} "
+                f"num_layers={self.num_layers} activation={self.activation}")
+
+    def reset_parameters(self):
+        torch.manual_seed(42)
+        std = math.sqrt(3 / self.hidden_dim)
+        self.weights.data.uniform_(-std, std)
+
+    def forward(self, inputs):
+        B, C = inputs.shape
+        pad = 128 - (B % 128)
+        if pad > 0:
+            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
+        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                                self.activation, self.output_activation, not self.training, inputs.requires_grad)
+        if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
+            outputs = outputs[:B, :self.output_dim]
+        return outputs

@@ -1,0 +1,296 @@
+"""NeRFRenderer — host-side mirror of the reference's renderer, the CALLER of the hot path.
+
+Follows legacy/nerf/renderer.py (the only renderer in the reference whose occupancy-grid path
+runs) for `run_cuda` / `update_extra_state` (:256-376, :445-536) and
+nerf/renderer.py:126-238 for the fixed-step `run` (FOC's default path: num_steps=512,
+upsample_steps=0, colour queried where weights > 1e-10). It exists so the ops can be driven
+end-to-end on the GPU box, where the reference tree is absent; the reference's own renderer
+works unchanged on top of the same ops.
+
+Additions over the reference caller (both optional, both default to reference behaviour):
+  * `device_compaction=True` in the inference loop keeps the alive-ray list on the device
+    between iterations for the compaction itself (order preserving), instead of the boolean
+    mask of legacy/nerf/renderer.py:363;
+  * `weight_thresh` makes the colour-query mask threshold explicit (1e-10 FOC / 1e-4 legacy).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import raymarching
+
+
+def custom_meshgrid(*args):
+    return torch.meshgrid(*args, indexing='ij')
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
+        super().__init__()
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+
+        aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer('aabb_train', aabb_train)
+        self.register_buffer('aabb_infer', aabb_train.clone())
+
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer('density_grid', torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer('density_bitfield', torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def color(self, x, d, mask=None, **kwargs):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # ------------------------------------------------------------------ fixed-step path
+    def run(self, rays_o, rays_d, num_steps=512, upsample_steps=0, bg_color=None, perturb=False, weight_thresh=1e-10,
+            return_fields=False, **kwargs):
+        """nerf/renderer.py:126-238 (upsample_steps must be 0, FOC's setting main_nerf.py:31-32)."""
+        assert upsample_steps == 0, "only the FOC configuration (upsample_steps=0) is implemented"
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears = nears.unsqueeze(-1)
+        fars = fars.unsqueeze(-1)
+
+        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
+        z_vals = nears + (fars - nears) * z_vals
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
+        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
+
+        density_outputs = self.density(xyzs.reshape(-1, 3))
+        for k, v in density_outputs.items():
+            density_outputs[k] = v.view(N, num_steps, -1)
+
+        deltas = z_vals[..., 1:] - z_vals[..., :-1]
+        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
+        alphas = 1 - torch.exp(-deltas * self.density_scale * density_outputs['sigma'].squeeze(-1))
+        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+        weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        sigma_field = density_outputs['sigma']
+        for k, v in density_outputs.items():
+            density_outputs[k] = v.view(-1, v.shape[-1])
+
+        mask = weights > weight_thresh
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **density_outputs)
+        rgbs = rgbs.view(N, -1, 3)
+
+        weights_sum = weights.sum(dim=-1)
+        ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
+        depth = torch.sum(weights * ori_z_vals, dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(sph, rays_d.reshape(-1, 3))
+        elif bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+
+        results = {
+            'depth': depth.view(*prefix),
+            'image': image.view(*prefix, 3),
+            'weights_sum': weights_sum,
+        }
+        if return_fields:   # what COMBINED.py's run() hands to the combiner (:528-534)
+            results['densities'] = sigma_field
+            results['rgbs'] = rgbs
+        return results
+
+    # ------------------------------------------------------------------ occupancy-grid path
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+                 T_thresh=1e-4, device_compaction=False, **kwargs):
+        """legacy/nerf/renderer.py:256-376."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(sph, rays_d)
+        elif bg_color is None:
+            bg_color = 1
+
+        results = {}
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                    force_all_rays, dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            results['weights_sum'] = weights_sum
+        else:
+            dtype = torch.float32
+            weights_sum = torch.zeros(N, dtype=dtype, device=device)
+            depth = torch.zeros(N, dtype=dtype, device=device)
+            image = torch.zeros(N, 3, dtype=dtype, device=device)
+            n_alive = N
+            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step = 0
+            while step < max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
+                                                            self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
+                                                            perturb if step == 0 else False, dt_gamma, max_steps)
+                sigmas, rgbs = self(xyzs, dirs)
+                sigmas = self.density_scale * sigmas
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+                if device_compaction:
+                    out, n_out = raymarching.compact_alive(rays_alive)
+                    rays_alive = out[:int(n_out.item())]
+                else:
+                    rays_alive = rays_alive[rays_alive >= 0]
+                step += n_step
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+
+        results['depth'] = depth
+        results['image'] = image
+        return results
+
+    # ------------------------------------------------------------------ density grid maintenance
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """legacy/nerf/renderer.py:445-536."""
+        if not self.cuda_ray:
+            return
+        tmp_grid = - torch.ones_like(self.density_grid)
+        dev = self.density_bitfield.device
+        if self.iter_density < 16:
+            X = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            Y = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            Z = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            for xs in X:
+                for ys in Y:
+                    for zs in Z:
+                        xx, yy, zz = custom_meshgrid(xs, ys, zs)
+                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                        indices = raymarching.morton3D(coords).long()
+                        xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+                        for cas in range(self.cascade):
+                            bound = min(2 ** cas, self.bound)
+                            half_grid_size = bound / self.grid_size
+                            cas_xyzs = xyzs * (bound - half_grid_size)
+                            cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+                            sigmas = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
+                            sigmas *= self.density_scale
+                            tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
+        else:
+            N = self.grid_size ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
+                indices = raymarching.morton3D(coords).long()
+                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
+                occ_indices = occ_indices[rand_mask]
+                occ_coords = raymarching.morton3D_invert(occ_indices)
+                indices = torch.cat([indices, occ_indices], dim=0)
+                coords = torch.cat([coords, occ_coords], dim=0)
+                xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+                bound = min(2 ** cas, self.bound)
+                half_grid_size = bound / self.grid_size
+                cas_xyzs = xyzs * (bound - half_grid_size)
+                cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+                sigmas = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
+                sigmas *= self.density_scale
+                tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
+
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    @torch.no_grad()
+    def set_density_grid(self, density_grid, density_thresh=None):
+        """Install a precomputed density grid [cascade, H^3] (Morton order) and pack it — used by the
+        synthetic scenes of bench.py / the tests in place of a trained grid."""
+        assert self.cuda_ray
+        self.density_grid.copy_(density_grid)
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        thresh = min(self.mean_density, self.density_thresh) if density_thresh is None else density_thresh
+        self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
+
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """legacy/nerf/renderer.py:539-573."""
+        _run = self.run_cuda if self.cuda_ray else self.run
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        if staged and not self.cuda_ray:
+            depth = torch.empty((B, N), device=device)
+            image = torch.empty((B, N, 3), device=device)
+            for b in range(B):
+                head = 0
+                while head < N:
+                    tail = min(head + max_ray_batch, N)
+                    results_ = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                    depth[b:b + 1, head:tail] = results_['depth']
+                    image[b:b + 1, head:tail] = results_['image']
+                    head += max_ray_batch
+            results = {'depth': depth, 'image': image}
+        else:
+            results = _run(rays_o, rays_d, **kwargs)
+        return results

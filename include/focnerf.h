@@ -1,0 +1,262 @@
+/*
+ * focnerf.h — C ABI of libfocnerf_hip.so, the MI355X (gfx950) implementation of
+ * FOCNeRF's volume-rendering hot path.
+ *
+ * Every entry point replaces one function of the reference's four pybind11
+ * extension modules (_raymarching, _gridencoder, _freqencoder, _ffmlp); the
+ * reference declaration each one stands in for is cited as file:line into the
+ * reference tree. Argument ORDER and MEANING follow the reference binding; the
+ * differences are mechanical:
+ *   - at::Tensor  -> raw device pointer (caller owns every buffer, as in the
+ *                    reference where the Python wrapper allocates all outputs);
+ *   - an explicit dtype code where the reference dispatches on scalar_type();
+ *   - a trailing hipStream_t passed as void* (the reference launches on the
+ *     legacy default stream; here the caller picks the stream);
+ *   - int return: 0 = ok, non-zero = FOC_E_* with foc_last_error() holding a
+ *     thread-local message (the reference raises through TORCH_CHECK /
+ *     std::runtime_error, or checks nothing at all in _raymarching).
+ * No function allocates, frees or synchronises; all are safe to capture into a
+ * hipGraph. All pointers are DEVICE pointers unless stated otherwise.
+ */
+#ifndef FOCNERF_H
+#define FOCNERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOC_OK            0
+#define FOC_E_INVALID     1   /* bad argument (null pointer, unsupported C/D/hidden_dim, ...) */
+#define FOC_E_DTYPE       2   /* unsupported dtype code for this entry point */
+#define FOC_E_LAUNCH      3   /* hipGetLastError() != hipSuccess after a launch */
+
+#define FOC_F32 0
+#define FOC_F16 1
+
+/* ABI version of this header; bump on any signature change. */
+#define FOC_ABI_VERSION 1
+int         foc_abi_version(void);
+/* Thread-local message of the last non-zero return on this thread ("" if none). */
+const char *foc_last_error(void);
+/* Compiled-for architecture string, e.g. "gfx950". */
+const char *foc_arch(void);
+
+/* ------------------------------------------------------------------------- *
+ * _raymarching  (reference: raymarching/src/raymarching.h:7-18,
+ *                           raymarching/src/bindings.cpp:5-19)
+ * All floating tensors are fp32 (the reference's wrappers force fp32 with
+ * custom_fwd(cast_inputs=torch.float32), raymarching/raymarching.py:21).
+ * ------------------------------------------------------------------------- */
+
+/* raymarching.cu:92-156  near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
+ * rays_o/rays_d [N,3], aabb [6] (device), nears/fars [N]. Miss -> both FLT_MAX. */
+int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                           uint32_t N, float min_near, float *nears, float *fars, void *stream);
+
+/* raymarching.cu:163-209  sph_from_ray(rays_o, rays_d, radius, N, coords)   coords [N,2] */
+int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N,
+                     float *coords, void *stream);
+
+/* raymarching.cu:214-232  morton3D(coords int32 [N,3], N, indices int32 [N]) */
+int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream);
+
+/* raymarching.cu:237-260  morton3D_invert(indices int32 [N], N, coords int32 [N,3]) */
+int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream);
+
+/* raymarching.cu:267-300  packbits(grid fp32 [N*8], N, density_thresh, bitfield u8 [N]) */
+int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream);
+
+/* raymarching.cu:311-490  march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps,
+ *                                          N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+ * grid u8 [C*H^3/8]; xyzs/dirs [M,3], deltas [M,2] (caller pre-zeroed, raymarching.py:205-207);
+ * rays int32 [N,3] = (ray id, point offset, point count); counter int32[2] is ADDED to
+ * (counter[0] += total points, counter[1] += N) exactly like the reference's atomicAdd pair
+ * (raymarching.cu:405-406).
+ * Order: the reference's slot order depends on atomicAdd arrival; this implementation
+ * reserves slots by an exclusive scan in RAY ORDER (one of the reference's legal outcomes),
+ * so the result is deterministic: rays[i] = (i, counter0_before + sum_{j<i} n_j, n_i).
+ * scratch: device int32 [N + 64] (per-ray counts + scan carry), caller-owned.          */
+int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid,
+                         float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars,
+                         float *xyzs, float *dirs, float *deltas,
+                         int32_t *rays, int32_t *counter, const float *noises,
+                         int32_t *scratch, void *stream);
+/* Bytes of `scratch` needed by foc_march_rays_train for N rays. */
+uint64_t foc_march_rays_train_scratch_bytes(uint32_t N);
+
+/* raymarching.cu:500-588  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
+ *                                                      weights_sum, depth, image) */
+int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
+                                     const int32_t *rays, uint32_t M, uint32_t N, float T_thresh,
+                                     float *weights_sum, float *depth, float *image, void *stream);
+
+/* raymarching.cu:601-693  composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs,
+ *       deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs)
+ * grad_sigmas/grad_rgbs must be pre-zeroed by the caller (raymarching.py:283-284). */
+int foc_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                      const float *sigmas, const float *rgbs, const float *deltas,
+                                      const int32_t *rays, const float *weights_sum, const float *image,
+                                      uint32_t M, uint32_t N, float T_thresh,
+                                      float *grad_sigmas, float *grad_rgbs, void *stream);
+
+/* raymarching.cu:700-815  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+ *       dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises)
+ * xyzs/dirs/deltas [n_alive*n_step (+pad), 3|3|2] pre-zeroed (raymarching.py:334-336). */
+int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t,
+                   const float *rays_o, const float *rays_d, float bound, float dt_gamma,
+                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid,
+                   const float *nears, const float *fars,
+                   float *xyzs, float *dirs, float *deltas, const float *noises, void *stream);
+
+/* raymarching.cu:818-914  composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs,
+ *       deltas, weights_sum, depth, image)   — in place; rays_alive[n] = -1 marks a finished ray. */
+int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                       int32_t *rays_alive, float *rays_t,
+                       const float *sigmas, const float *rgbs, const float *deltas,
+                       float *weights_sum, float *depth, float *image, void *stream);
+
+/* Device-side compaction of rays_alive (replaces the reference caller's
+ * `rays_alive = rays_alive[rays_alive >= 0]`, legacy/nerf/renderer.py:363, which costs a
+ * host sync per marching iteration). Writes the surviving ids, in order, to `out` and
+ * their count to n_out[0] (device int32). Extension: no reference binding. */
+int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out,
+                      int32_t *scratch, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * _gridencoder  (reference: gridencoder/src/gridencoder.h:12-15,
+ *                           gridencoder/src/bindings.cpp)
+ * inputs fp32 [B,D] in [0,1]; embeddings/outputs/dy_dx/grad* share `dtype`
+ * (FOC_F32 or FOC_F16 — the reference dispatches on embeddings.scalar_type(),
+ * gridencoder.cu:467-470); offsets int32 [L+1] (device). D in {2,3}, C in {1,2,4,8}.
+ * S = log2(per_level_scale). Per-level scale = exp2f(l*S)*H-1 is evaluated on the
+ * HOST (libm) and handed to the kernel, so the integer index math does not depend on
+ * a device transcendental. offsets_host: the same L+1 ints in HOST memory (needed to
+ * size launches without a D2H copy); may be NULL, in which case dense-level LDS
+ * fast paths are disabled.
+ * ------------------------------------------------------------------------- */
+
+/* gridencoder.cu:448-471  grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H,
+ *                                             dy_dx?, gridtype, align_corners, interp)
+ * outputs [L,B,C] (level-major, as the reference kernel writes it); dy_dx [B,L,D,C] or NULL. */
+int foc_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets,
+                            void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            float S, uint32_t H, void *dy_dx, uint32_t gridtype,
+                            int align_corners, uint32_t interp, int dtype,
+                            const int32_t *offsets_host, void *stream);
+
+/* Same computation, but writes outputs as [B, L*C] (what the reference's Python wrapper
+ * produces with a permute+reshape copy, gridencoder/grid.py:57). Extension used by this
+ * repo's wrapper to skip that copy; results are element-for-element identical. */
+int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, const int32_t *offsets,
+                               void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                               float S, uint32_t H, void *dy_dx, uint32_t gridtype,
+                               int align_corners, uint32_t interp, int dtype,
+                               const int32_t *offsets_host, void *stream);
+
+/* gridencoder.cu:473-503  grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings,
+ *       B, D, C, L, S, H, dy_dx?, grad_inputs?, gridtype, align_corners, interp)
+ * grad [L,B,C]; grad_embeddings pre-zeroed (grid.py:77); grad_inputs [B,D] (dtype) or NULL.
+ * grad_is_bl != 0: grad is laid out [B, L*C] instead (skips the wrapper's permute copy,
+ * gridencoder/grid.py:75). */
+int foc_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings,
+                             const int32_t *offsets, void *grad_embeddings,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const void *dy_dx, void *grad_inputs, uint32_t gridtype,
+                             int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                             const int32_t *offsets_host, void *stream);
+
+/* gridencoder.cu:639-645  grad_total_variation(inputs, embeddings, grad, offsets, weight,
+ *       B, D, C, L, S, H, gridtype, align_corners)   — inputs share `dtype` with embeddings. */
+int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad,
+                             const int32_t *offsets, float weight,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             uint32_t gridtype, int align_corners, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * _freqencoder  (reference: freqencoder/src/freqencoder.h:7,10) — fp32 only.
+ * ------------------------------------------------------------------------- */
+
+/* freqencoder.cu:97-110  freq_encode_forward(inputs [B,D], B, D, deg, C, outputs [B,C]) */
+int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                            float *outputs, void *stream);
+/* freqencoder.cu:113-129 freq_encode_backward(grad [B,C], outputs [B,C], B, D, deg, C, grad_inputs [B,D]) */
+int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D,
+                             uint32_t deg, uint32_t C, float *grad_inputs, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * _ffmlp  (reference: ffmlp/src/ffmlp.h:8-14) — fp16 storage, fp32 MFMA accumulation.
+ * weights: one fp16 blob [hidden*input_dim | (num_layers-1)*hidden*hidden | 16*hidden],
+ * each block row-major with the OUTPUT neuron as the row (ffmlp.cu:631-634).
+ * inputs [B,input_dim], outputs [B,16] (output_dim is the padded 16), row-major.
+ * B must be a multiple of 128 (the reference wrapper pads, ffmlp/ffmlp.py:157-159);
+ * hidden_dim in {16,32,64,128}; input_dim % 16 == 0; output_dim <= 16; num_layers >= 2.
+ * activation codes follow ffmlp.py:86-93 (0 = relu ... 6 = none); hidden activation
+ * relu|none, output activation none (the only combinations FFMLP can construct,
+ * ffmlp.py:107-108).
+ * ------------------------------------------------------------------------- */
+
+/* ffmlp.cu:635-671  ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers,
+ *       activation, output_activation, forward_buffer [num_layers,B,hidden], outputs) */
+int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
+                      uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                      uint32_t activation, uint32_t output_activation,
+                      void *forward_buffer, void *outputs, void *stream);
+
+/* ffmlp.cu:673-709  ffmlp_inference(..., inference_buffer [B,hidden] (unused here), outputs) */
+int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
+                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                        uint32_t activation, uint32_t output_activation,
+                        void *inference_buffer, void *outputs, void *stream);
+
+/* ffmlp.cu:749-895  ffmlp_backward(grad [B,16], inputs, weights, forward_buffer, B, input_dim,
+ *       output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs,
+ *       backward_buffer [num_layers,B,hidden], grad_inputs [B,input_dim], grad_weights (blob))
+ * workspace: device fp32, foc_ffmlp_backward_workspace_bytes() bytes, caller-owned; holds
+ * the fp32 split-K partial sums of the weight gradients (the reference's CUTLASS split-K
+ * workspace, cutlass_matmul.h:335-363, is a process-global map instead). */
+int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights,
+                       const void *forward_buffer, uint32_t B, uint32_t input_dim,
+                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                       void *backward_buffer, void *grad_inputs, void *grad_weights,
+                       void *workspace, void *stream);
+uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
+
+/* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
+ * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the
+ * backward launch sequence on the caller's stream, so both are no-ops kept for API parity. */
+int foc_allocate_splitk(uint64_t size);
+int foc_free_splitk(void);
+
+/* ------------------------------------------------------------------------- *
+ * Multi-object combine (reference: COMBINED.py:247-251 best_densities_and_colors_v3).
+ * Per-sample strict-'>' max-density select; first object wins ties.
+ * ------------------------------------------------------------------------- */
+
+/* In place: where dens[i] > max_dens[i]: best_rgb[i,:] = rgb[i,:]; max_dens[i] = max(dens, max_dens).
+ * n = number of samples. */
+int foc_combine_select(const float *dens, const float *rgb, float *max_dens, float *best_rgb,
+                       uint64_t n, void *stream);
+
+/* Pack (sigma, rank) into the order-preserving 64-bit key used for the RCCL MAX
+ * all-reduce of the one-object-per-GPU combine: key = (float_bits(max(sigma,0)) << 32) |
+ * (0xFFFFFFFF - rank); and the inverse select of the winning rank's rgb. */
+int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint64_t n, void *stream);
+int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb,
+                       float *max_dens, float *masked_rgb, uint64_t n, void *stream);
+
+/* Fixed-step composite of a merged field (COMBINED.py:141-200 image_depth_generation):
+ * sigmas [N,T], rgbs [N,T,3], nears/fars [N]; out image4 [N,4] (rgb + sum w*sigma), depth [N].
+ * bg: background value broadcast over the 4 channels; result clamped to [0,1]. */
+int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const float *nears,
+                              const float *fars, uint32_t N, uint32_t T, float bg,
+                              float *image4, float *depth, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCNERF_H */

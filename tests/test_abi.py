@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads and exports every symbol include/focnerf.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "focnerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(foc_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for n in ["foc_near_far_from_aabb", "foc_march_rays_train", "foc_composite_rays_train_forward",
+              "foc_composite_rays_train_backward", "foc_march_rays", "foc_composite_rays", "foc_grid_encode_forward",
+              "foc_grid_encode_backward", "foc_grad_total_variation", "foc_freq_encode_forward", "foc_freq_encode_backward",
+              "foc_ffmlp_forward", "foc_ffmlp_inference", "foc_ffmlp_backward", "foc_combine_select"]:
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from focnerf_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in _declared():
+        assert hasattr(lib, n), f"{n} declared in include/focnerf.h but not exported"
+    assert set(_lib.SIGNATURES) == set(_declared()), "focnerf_amd/_lib.py binds a different set than the header declares"
+
+
+def test_abi_version_and_arch():
+    from focnerf_amd import _lib
+    assert _lib.lib.foc_abi_version() == 1
+    assert _lib.lib.foc_arch() == b"gfx950"
+    assert _lib.lib.foc_last_error() == b""
+
+
+def test_argument_validation_needs_no_gpu():
+    """Null pointers / bad shapes are rejected on the host before any launch."""
+    from focnerf_amd import _lib
+    lib = _lib.lib
+    assert lib.foc_near_far_from_aabb(None, None, None, 4, 0.2, None, None, None) == 1
+    assert b"null pointer" in lib.foc_last_error()
+    one = ctypes.c_void_p(8)  # never dereferenced: validation fails first
+    rc = lib.foc_grid_encode_forward(one, one, one, one, 4, 3, 3, 16, 1.0, 16, None, 0, 0, 0, 0, None, None)
+    assert rc == 1 and b"C must be 1, 2, 4, or 8" in lib.foc_last_error()
+    rc = lib.foc_ffmlp_forward(one, one, 128, 32, 16, 48, 2, 0, 6, one, one, None)
+    assert rc == 1 and b"hidden_dim" in lib.foc_last_error()
+    rc = lib.foc_ffmlp_forward(one, one, 100, 32, 16, 64, 2, 0, 6, one, one, None)
+    assert rc == 1 and b"multiple of 128" in lib.foc_last_error()
+    rc = lib.foc_freq_encode_forward(one, 4, 3, 4, 26, one, None)
+    assert rc == 1
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from focnerf_amd import raymarching
+    if torch.cuda.is_available():
+        pytest.skip("host-only check")
+    with pytest.raises(Exception):   # .cuda() on a GPU-less host, or the explicit CUDA-tensor check
+        raymarching.near_far_from_aabb(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.2)
