@@ -1,0 +1,197 @@
+"""GPU parity: fully fused MLP (MFMA kernels) vs the CPU oracle.
+
+Tolerance model (SURVEY.md §7 "fp16-accumulate vs fp32-accumulate"): every layer output is rounded to
+fp16 once; the kernel accumulates in fp32 on the matrix cores in MFMA order, the oracle (acc_mode=0)
+accumulates in fp32 in k order, so results agree up to fp32 summation order BEFORE the fp16 rounding:
+at most 1 half-ulp per layer, compounding over layers -> a few half-ulps + a small absolute term.
+With small-integer data every product and sum is exact and the comparison is bit-exact: that is the
+test that pins the MFMA operand / accumulator lane maps and the chained-operand k permutation."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import to_np, assert_half_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _be():
+    from focnerf_amd.backend import _ffmlp
+    return _ffmlp
+
+
+def _n_params(I, Hd, nl):
+    return Hd * (I + Hd * (nl - 1) + 16)
+
+
+def _run_forward(x, W, I, Hd, nl, act, train):
+    be = _be()
+    B = x.shape[0]
+    xt, Wt = torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda()
+    out = torch.empty(B, 16, dtype=torch.float16, device="cuda")
+    if train:
+        fb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+        be.ffmlp_forward(xt, Wt, B, I, 16, Hd, nl, act, 6, fb, out)
+        return to_np(out), to_np(fb)
+    be.ffmlp_inference(xt, Wt, B, I, 16, Hd, nl, act, 6, None, out)
+    return to_np(out)
+
+
+SHAPES = [(32, 64, 2), (32, 64, 3), (16, 16, 2), (48, 32, 4), (64, 128, 2), (128, 128, 3), (16, 64, 5)]
+
+
+@pytest.mark.parametrize("I,Hd,nl", SHAPES)
+@pytest.mark.parametrize("act", [0, 6])
+def test_forward_exact_on_integer_data(I, Hd, nl, act):
+    """Small integers: all partial sums are exact in fp32, so every summation order rounds to the same fp16 -> bit-exact."""
+    rng = np.random.default_rng(I * 1000 + Hd + nl)
+    B = 256
+    # sparse small weights keep |activations| < 2048 so fp16 represents every integer exactly
+    W = np.zeros(_n_params(I, Hd, nl), np.float16)
+    nz = rng.random(W.size) < (4.0 / max(I, Hd))
+    W[nz] = rng.integers(-2, 3, nz.sum()).astype(np.float16)
+    x = rng.integers(-3, 4, (B, I)).astype(np.float16)
+    ref_out, ref_fb = oracle.ffmlp_forward(x, W, I, Hd, nl, act)
+    # integer sums stay far below 2^24 (exact in fp32) and below the fp16 overflow; values above 2048 round to
+    # the same fp16 on both sides because the exact sum is identical
+    assert np.abs(ref_fb.astype(np.float32)).max() < 30000 and np.abs(ref_out.astype(np.float32)).max() < 30000
+    assert np.count_nonzero(ref_out) > 100, "degenerate test data"
+    out, fb = _run_forward(x, W, I, Hd, nl, act, True)
+    assert np.array_equal(fb, ref_fb), "forward_buffer differs: MFMA operand/accumulator map is wrong"
+    assert np.array_equal(out, ref_out)
+    assert np.array_equal(_run_forward(x, W, I, Hd, nl, act, False), ref_out)
+
+
+@pytest.mark.parametrize("I,Hd,nl", SHAPES)
+def test_forward_random(I, Hd, nl):
+    rng = np.random.default_rng(7 + I + Hd + nl)
+    B = 512
+    W = (rng.uniform(-1, 1, _n_params(I, Hd, nl)) * math.sqrt(3 / Hd)).astype(np.float16)
+    x = rng.standard_normal((B, I)).astype(np.float16)
+    ref_out, ref_fb = oracle.ffmlp_forward(x, W, I, Hd, nl, 0)
+    out, fb = _run_forward(x, W, I, Hd, nl, 0, True)
+    assert_half_close(fb[0], ref_fb[0], ulps=1.0, atol=1e-6, what="layer 0")
+    assert_half_close(fb, ref_fb, ulps=2.0 * nl, atol=2e-3, what="forward_buffer")
+    assert_half_close(out, ref_out, ulps=2.0 * (nl + 1), atol=4e-3, what="outputs")
+    # against the WMMA-like half-accumulate model of the reference: same numbers up to fp16 accumulation error
+    ref_h = oracle.ffmlp_forward(x, W, I, Hd, nl, 0, training=False, acc_mode=1)
+    assert np.abs(out.astype(np.float32) - ref_h.astype(np.float32)).max() < 0.05 * max(1.0, np.abs(ref_h.astype(np.float32)).max())
+    assert np.array_equal(_run_forward(x, W, I, Hd, nl, 0, False), out), "inference and training kernels must agree bit for bit"
+
+
+@pytest.mark.parametrize("I,Hd,nl", SHAPES)
+@pytest.mark.parametrize("act", [0, 6])
+def test_backward_exact_on_integer_data(I, Hd, nl, act):
+    be = _be()
+    rng = np.random.default_rng(I * 77 + Hd + nl)
+    B = 256
+    W = np.zeros(_n_params(I, Hd, nl), np.float16)
+    nz = rng.random(W.size) < (3.0 / max(I, Hd))
+    W[nz] = rng.integers(-2, 3, nz.sum()).astype(np.float16)
+    x = rng.integers(-2, 3, (B, I)).astype(np.float16)
+    g = np.zeros((B, 16), np.float16)
+    gz = rng.random(g.shape) < 0.25
+    g[gz] = rng.integers(-2, 3, gz.sum()).astype(np.float16)
+    ref_out, ref_fb = oracle.ffmlp_forward(x, W, I, Hd, nl, act)
+    gw_r, gi_r, bb_r = oracle.ffmlp_backward(g, x, W, ref_fb, I, Hd, nl, act, True)
+    assert np.abs(bb_r.astype(np.float32)).max() < 30000 and np.abs(gw_r.astype(np.float32)).max() < 30000
+    t = lambda a: torch.from_numpy(a).cuda()
+    bb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+    gi = torch.empty(B, I, dtype=torch.float16, device="cuda")
+    gw = torch.empty(W.size, dtype=torch.float16, device="cuda")
+    be.ffmlp_backward(t(g), t(x), t(W), t(ref_fb), B, I, 16, Hd, nl, act, 6, True, bb, gi, gw)
+    assert np.array_equal(to_np(bb), bb_r), "backward_buffer differs"
+    assert np.array_equal(to_np(gi), gi_r), "grad_inputs differs"
+    assert np.array_equal(to_np(gw), gw_r), "grad_weights differs"
+    # without grad_inputs the weight gradients are unchanged
+    gw2 = torch.empty_like(gw)
+    be.ffmlp_backward(t(g), t(x), t(W), t(ref_fb), B, I, 16, Hd, nl, act, 6, False, bb, torch.zeros(1, dtype=torch.float16, device="cuda"), gw2)
+    assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (64, 128, 2)])
+def test_backward_random(I, Hd, nl):
+    be = _be()
+    rng = np.random.default_rng(99 + I + Hd + nl)
+    B = 1024
+    W = (rng.uniform(-1, 1, _n_params(I, Hd, nl)) * math.sqrt(3 / Hd)).astype(np.float16)
+    x = rng.standard_normal((B, I)).astype(np.float16)
+    g = (rng.standard_normal((B, 16)) * 0.05).astype(np.float16)
+    out, fb = _run_forward(x, W, I, Hd, nl, 0, True)
+    gw_r, gi_r, bb_r = oracle.ffmlp_backward(g, x, W, fb, I, Hd, nl, 0, True)
+    t = lambda a: torch.from_numpy(a).cuda()
+    bb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+    gi = torch.empty(B, I, dtype=torch.float16, device="cuda")
+    gw = torch.empty(W.size, dtype=torch.float16, device="cuda")
+    be.ffmlp_backward(t(g), t(x), t(W), t(fb), B, I, 16, Hd, nl, 0, 6, True, bb, gi, gw)
+    assert_half_close(to_np(bb), bb_r, ulps=2.0 * nl, atol=2e-4, what="backward_buffer")
+    assert_half_close(to_np(gi), gi_r, ulps=2.0 * (nl + 1), atol=5e-4, what="grad_inputs")
+    assert_half_close(to_np(gw), gw_r, ulps=4.0, atol=2e-3, what="grad_weights")
+
+
+def test_module_padding_autograd_and_init():
+    """FFMLP module: seed-42 init, batch padding to a multiple of 128 (+128 when already aligned), autocast, autograd."""
+    from focnerf_amd.ffmlp import FFMLP
+    net = FFMLP(32, 3, 64, 3).cuda()
+    assert net.weights.numel() == 64 * (32 + 64 * 2 + 16)
+    torch.manual_seed(42)
+    want = torch.zeros(net.weights.numel()).uniform_(-math.sqrt(3 / 64), math.sqrt(3 / 64))
+    assert torch.equal(net.weights.detach().cpu(), want), "seed-42 init of ffmlp.py:141-144"
+    for B in (1, 127, 128, 300):
+        x = torch.randn(B, 32, device="cuda", requires_grad=True)
+        net.train()
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = net(x)
+        assert y.shape == (B, 3) and y.dtype == torch.float16
+        ref = oracle.ffmlp_forward(to_np(x.detach().half()), to_np(net.weights.detach().half()), 32, 64, 3, 0, training=False)
+        assert_half_close(to_np(y), ref[:, :3], ulps=8, atol=4e-3, what=f"module forward B={B}")
+        net.zero_grad()
+        y.float().pow(2).sum().backward()
+        assert net.weights.grad is not None and net.weights.grad.dtype == torch.float32 and torch.isfinite(net.weights.grad).all()
+        assert x.grad is not None and x.grad.shape == (B, 32)
+        net.eval()
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            y2 = net(x)
+        assert torch.equal(y2, y.detach())
+    # fp32 inputs outside autocast are rejected like CHECK_IS_HALF does
+    with pytest.raises(RuntimeError):
+        net(torch.randn(128, 32, device="cuda"))
+
+
+def test_full_batch_rows_are_independent():
+    """BASELINE size: B = 2 097 152 rows (4096 rays x 512 samples). Rows are independent, so a random subset
+    evaluated by the oracle must equal the same rows of the full launch; the weight gradient of the full
+    batch must equal the sum of the gradients of its two halves (linearity over the batch)."""
+    be = _be()
+    rng = np.random.default_rng(5)
+    I, Hd, nl = 32, 64, 2
+    B = 4096 * 512
+    W = (rng.uniform(-1, 1, _n_params(I, Hd, nl)) * math.sqrt(3 / Hd)).astype(np.float16)
+    Wt = torch.from_numpy(W).cuda()
+    x = torch.randn(B, I, device="cuda").half()
+    out = torch.empty(B, 16, dtype=torch.float16, device="cuda")
+    fb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+    be.ffmlp_forward(x, Wt, B, I, 16, Hd, nl, 0, 6, fb, out)
+    sel = torch.from_numpy(rng.choice(B, 2048, replace=False)).cuda()
+    sel = torch.cat([sel, torch.tensor([0, 63, 64, B - 1], device="cuda")])
+    ref_out, ref_fb = oracle.ffmlp_forward(to_np(x[sel]), W, I, Hd, nl, 0)
+    assert_half_close(to_np(out[sel]), ref_out, ulps=6, atol=4e-3, what="subset rows")
+    assert_half_close(to_np(fb[:, sel]), ref_fb, ulps=4, atol=2e-3, what="subset forward_buffer")
+    g = (torch.randn(B, 16, device="cuda") * 0.01).half()
+
+    def bwd(lo, hi):
+        n = hi - lo
+        bb = torch.empty(nl, n, Hd, dtype=torch.float16, device="cuda")
+        gi = torch.empty(n, I, dtype=torch.float16, device="cuda")
+        gw = torch.empty(W.size, dtype=torch.float16, device="cuda")
+        be.ffmlp_backward(g[lo:hi].contiguous(), x[lo:hi].contiguous(), Wt, fb[:, lo:hi].contiguous(), n, I, 16, Hd, nl, 0, 6, True, bb, gi, gw)
+        return gw.float(), gi
+    gw_full, gi_full = bwd(0, B)
+    gw_a, gi_a = bwd(0, B // 2)
+    gw_b, gi_b = bwd(B // 2, B)
+    assert torch.equal(gi_full[: B // 2], gi_a) and torch.equal(gi_full[B // 2:], gi_b)
+    scale = gw_full.abs().max()
+    assert (gw_full - (gw_a + gw_b)).abs().max() <= 4e-3 * scale + 1e-3

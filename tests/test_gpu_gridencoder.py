@@ -1,0 +1,235 @@
+"""GPU parity: gridencoder / freqencoder (Python operator API -> C ABI -> HIP) vs the CPU oracle.
+Forward: the kernels evaluate the same fp32 fmaf sequence as oracle acc_mode=1, so fp32 AND fp16 outputs
+are bit-exact against it; against the reference-literal half accumulation (acc_mode=0) fp16 outputs are
+within 1 half-ulp. Backward sums are atomics (order dependent, like the reference): tolerance only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import to_np, assert_half_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(D, C, L, H, log2_hash, desired, seed, dtype, gridtype="hash", align_corners=False):
+    from focnerf_amd.gridencoder import level_offsets
+    pls = np.exp2(np.log2(desired / H) / (L - 1))
+    off = level_offsets(D, L, pls, H, log2_hash, align_corners)
+    rng = np.random.default_rng(seed)
+    table = rng.uniform(-1, 1, (int(off[-1]), C)).astype(dtype)
+    return pls, float(np.log2(pls)), off, table
+
+
+def _points(B, D, seed, oob=True):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, D)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 1.0
+    if oob and B > 8:
+        x[2, 0] = -0.01
+        x[3, D - 1] = 1.0001
+        x[4] = np.float32(1.0) - np.float32(1e-7)
+    return x
+
+
+def _be():
+    from focnerf_amd.backend import _gridencoder
+    return _gridencoder
+
+
+CASES = [
+    # D, C, L, H, log2_hash, desired, gridtype, align, interp
+    (3, 2, 16, 16, 19, 2048, 0, False, 0),      # the NeRF default (bound 1)
+    (3, 2, 16, 16, 19, 4096, 0, False, 0),      # bound 2
+    (3, 1, 8, 16, 15, 512, 0, False, 0),
+    (3, 4, 8, 16, 15, 512, 1, False, 0),        # tiled
+    (3, 8, 4, 8, 14, 128, 0, True, 1),          # align_corners + smoothstep
+    (2, 2, 12, 16, 17, 2048, 0, False, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_forward_bit_exact(case, dtype):
+    D, C, L, H, lh, desired, gridtype, ac, interp = case
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 1, dtype, align_corners=ac)
+    B = 5000
+    x = _points(B, D, 2)
+    ref, ref_dy = oracle.grid_encode_forward(x, table, off, D, C, L, S, H, True, gridtype, ac, interp, acc_mode=1)
+    tdt = torch.float32 if dtype == np.float32 else torch.float16
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    be = _be()
+    # reference layout [L,B,C]
+    out = torch.empty(L, B, C, dtype=tdt, device="cuda")
+    dy = torch.empty(B, L * D * C, dtype=tdt, device="cuda")
+    be.grid_encode_forward(xt, tt, ot, out, B, D, C, L, S, H, dy, gridtype, ac, interp)
+    assert np.array_equal(to_np(out), ref), "outputs [L,B,C] not bit-exact"
+    got_dy = to_np(dy).reshape(B, L, D, C)
+    if dtype == np.float32:
+        assert np.array_equal(got_dy, ref_dy)
+    else:
+        assert_half_close(got_dy, ref_dy, ulps=1.0, what="dy_dx")
+    # fused layout [B, L*C]
+    out2 = torch.empty(B, L * C, dtype=tdt, device="cuda")
+    be.grid_encode_forward(xt, tt, ot, out2, B, D, C, L, S, H, None, gridtype, ac, interp, out_bl=True)
+    assert np.array_equal(to_np(out2), np.transpose(ref, (1, 0, 2)).reshape(B, L * C))
+    # out-of-range points encode to exact zeros on every level (gridencoder.cu:119-135)
+    assert np.all(to_np(out)[:, 2] == 0) and np.all(to_np(out)[:, 3] == 0)
+    if dtype == np.float16:
+        lit = oracle.grid_encode_forward(x, table, off, D, C, L, S, H, False, gridtype, ac, interp, acc_mode=0)
+        assert_half_close(to_np(out), lit, ulps=1.0, atol=1e-7, what="vs reference-literal half accumulation")
+
+
+@pytest.mark.parametrize("case", CASES[:5])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_backward(case, dtype):
+    D, C, L, H, lh, desired, gridtype, ac, interp = case
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, dtype, align_corners=ac)
+    B = 4000
+    x = _points(B, D, 4)
+    rng = np.random.default_rng(9)
+    grad = (rng.standard_normal((L, B, C)) * 0.1).astype(dtype)
+    grad[:, 7] = 0                                     # zero-gradient rows are skipped
+    _, dy = oracle.grid_encode_forward(x, table, off, D, C, L, S, H, True, gridtype, ac, interp, acc_mode=1)
+    ge_ref, gi_ref = oracle.grid_encode_backward(grad, x, off, int(off[-1]), D, C, L, S, H, dy, gridtype, ac, interp)
+    tdt = torch.float32 if dtype == np.float32 else torch.float16
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    be = _be()
+    for bl in (False, True):
+        g = torch.from_numpy(grad).cuda()
+        if bl:
+            g = g.permute(1, 0, 2).reshape(B, L * C).contiguous()
+        ge = torch.zeros(int(off[-1]), C, dtype=tdt, device="cuda")
+        gi = torch.zeros(B, D, dtype=tdt, device="cuda")
+        be.grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, torch.from_numpy(dy.reshape(B, -1)).cuda(), gi, gridtype, ac, interp, grad_bl=bl)
+        got, want = to_np(ge).astype(np.float32), ge_ref.astype(np.float32)
+        if dtype == np.float32:
+            np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
+            np.testing.assert_allclose(to_np(gi).astype(np.float32), gi_ref.astype(np.float32), atol=1e-3, rtol=1e-3)
+        else:
+            # half atomics round the running sum at every add (as the reference's __half2 atomicAdd does)
+            scale = np.abs(want).max()
+            assert np.abs(got - want).max() <= 2e-2 * scale + 1e-3
+            np.testing.assert_allclose(to_np(gi).astype(np.float32), gi_ref.astype(np.float32), atol=5e-2, rtol=5e-2)
+        # checksum: interpolation weights sum to 1, so per level sum(grad_embeddings) == sum(grad) over in-range points
+        inb = np.all((x >= 0) & (x <= 1), axis=1)
+        if interp == 0:
+            for l in range(L):
+                want_sum = grad[l][inb].astype(np.float64).sum(0)
+                got_sum = got[off[l]:off[l + 1]].astype(np.float64).sum(0)
+                tol = 1e-3 if dtype == np.float32 else 0.5
+                np.testing.assert_allclose(got_sum, want_sum, atol=tol)
+
+
+def test_grid_encode_autograd_and_module():
+    """GridEncoder module: fp32 and autocast(fp16) paths, both kernel layouts, gradients w.r.t. table and inputs."""
+    import os
+    from focnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(0)
+    enc = GridEncoder(desired_resolution=2048).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = (torch.rand(3000, 3, device="cuda") * 2 - 1).requires_grad_(True)
+    outs = {}
+    for lbc in ("0", "1"):
+        os.environ["FOCNERF_GRID_LBC"] = lbc
+        enc.zero_grad(); x.grad = None
+        y = enc(x, bound=1)
+        assert y.shape == (3000, 32) and y.dtype == torch.float32
+        w = torch.linspace(-1, 1, 32, device="cuda")
+        (y * w).sum().backward()
+        outs[lbc] = (y.detach().clone(), enc.embeddings.grad.clone(), x.grad.clone())
+    os.environ["FOCNERF_GRID_LBC"] = "0"
+    assert torch.equal(outs["0"][0], outs["1"][0])
+    assert torch.allclose(outs["0"][1], outs["1"][1], atol=1e-5)
+    assert torch.allclose(outs["0"][2], outs["1"][2], atol=1e-3, rtol=1e-3)
+    # oracle on the same data
+    S = float(np.log2(enc.per_level_scale))
+    xin = ((x.detach() + 1) / 2).cpu().numpy()
+    ref = oracle.grid_encode_forward(xin, to_np(enc.embeddings), to_np(enc.offsets), 3, 2, 16, S, 16)
+    assert np.array_equal(to_np(outs["0"][0]), np.transpose(ref, (1, 0, 2)).reshape(3000, 32))
+    # finite-difference check of d/dx through dy_dx (linear interpolation is piecewise linear in x)
+    with torch.no_grad():
+        e = 1e-4
+        xp = x.detach().clone(); xp[:, 0] += e
+        xm = x.detach().clone(); xm[:, 0] -= e
+        fd = ((enc(xp) - enc(xm)) * w).sum(-1) / (2 * e)
+    good = (x.detach().abs() < 0.999).all(-1)
+    rel = (fd[good] - outs["0"][2][good, 0]).abs() / (fd[good].abs() + 1.0)
+    assert rel.median() < 2e-2
+    # autocast: half table, half outputs, fp32 parameter gradient
+    enc.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        yh = enc(x.detach(), bound=1)
+    assert yh.dtype == torch.float16
+    yh.float().sum().backward()
+    assert enc.embeddings.grad.dtype == torch.float32
+    refh = oracle.grid_encode_forward(xin, to_np(enc.embeddings).astype(np.float16), to_np(enc.offsets), 3, 2, 16, S, 16)
+    assert np.array_equal(to_np(yh), np.transpose(refh, (1, 0, 2)).reshape(3000, 32))
+
+
+def test_grad_total_variation():
+    from focnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(1)
+    enc = GridEncoder(num_levels=8, desired_resolution=256, log2_hashmap_size=15).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    x = torch.rand(5000, 3, device="cuda") * 2 - 1
+    with pytest.raises(ValueError):
+        GridEncoder(num_levels=2, desired_resolution=32, log2_hashmap_size=10).cuda().grad_total_variation()
+    enc.grad_total_variation(weight=1e-2, inputs=x, bound=1)
+    S = float(np.log2(enc.per_level_scale))
+    ref = oracle.grad_total_variation(((x + 1) / 2).cpu().numpy(), to_np(enc.embeddings), np.zeros_like(to_np(enc.embeddings)),
+                                      to_np(enc.offsets), 1e-2, 3, 2, 8, S, 16)
+    np.testing.assert_allclose(to_np(enc.embeddings.grad), ref, atol=1e-6, rtol=1e-4)
+
+
+def test_full_batch_properties():
+    """BASELINE size: B = 4096 rays x 512 samples = 2 097 152 points, default 16-level table (fp16)."""
+    from focnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(2)
+    enc = GridEncoder(desired_resolution=2048).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    B = 4096 * 512
+    x = torch.rand(B, 3, device="cuda") * 2 - 1
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = enc(x)
+        # a random subset against the oracle: rows are independent, so this is exact
+        sel = torch.randperm(B, device="cuda")[:4096]
+        S = float(np.log2(enc.per_level_scale))
+        ref = oracle.grid_encode_forward(((x[sel] + 1) / 2).cpu().numpy(), to_np(enc.embeddings).astype(np.float16), to_np(enc.offsets), 3, 2, 16, S, 16)
+        assert np.array_equal(to_np(y[sel]), np.transpose(ref, (1, 0, 2)).reshape(4096, 32))
+    # linearity in the table (fp32 path): T -> 2T doubles every output exactly (power-of-two scaling)
+    y1 = enc(x)
+    enc.embeddings.data.mul_(2)
+    y2 = enc(x)
+    enc.embeddings.data.mul_(0.5)
+    assert torch.equal(y2, y1 * 2)
+    del y1, y2
+    # backward checksum at full size, fp32: per level, sum(grad_embeddings) == sum(grad)
+    enc.zero_grad()
+    yf = enc(x)
+    g = torch.randn(B, 32, device="cuda") * 1e-3
+    yf.backward(g)
+    ge = enc.embeddings.grad
+    off = to_np(enc.offsets)
+    for l in range(16):
+        got = ge[off[l]:off[l + 1]].double().sum(0)
+        want = g[:, 2 * l:2 * l + 2].double().sum(0)
+        assert torch.allclose(got, want, atol=2e-3), f"level {l}"
+
+
+def test_freq_encoder():
+    from focnerf_amd.freqencoder import FreqEncoder
+    torch.manual_seed(0)
+    for deg, B in [(4, 10007), (10, 513), (6, 1)]:
+        enc = FreqEncoder(3, deg)
+        x = (torch.randn(B, 3, device="cuda")).requires_grad_(True)
+        y = enc(x)
+        ref = oracle.freq_encode_forward(to_np(x), deg)
+        # sin(2^f x) at large arguments: ocml vs libm differ by a few ulp of the ARGUMENT reduction
+        np.testing.assert_allclose(to_np(y), ref, atol=2e-5 if deg > 6 else 2e-6)
+        g = torch.randn_like(y)
+        y.backward(g)
+        gref = oracle.freq_encode_backward(to_np(g), to_np(y), 3, deg)
+        np.testing.assert_allclose(to_np(x.grad), gref, atol=1e-3, rtol=1e-4)

@@ -1,0 +1,115 @@
+"""GPU: the ops driven end-to-end through the renderer / network (the callers of SURVEY.md §3a-3c)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(bound, cuda_ray, seed=0):
+    from focnerf_amd import synthetic
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(seed)
+    m = NeRFNetwork(bound=bound, cuda_ray=cuda_ray).cuda()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    if cuda_ray:
+        m.set_density_grid(synthetic.analytic_density_grid(bound, device="cuda"))
+    return m
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
+
+
+def test_network_matches_oracle_pipeline():
+    """encoder -> sigma MLP -> trunc_exp / colour MLP -> sigmoid, against the oracle ops chained on the CPU."""
+    from focnerf_amd.shencoder import sh_encode_deg4
+    m = _model(1, False).eval()
+    B = 1000
+    x = torch.rand(B, 3, device="cuda") * 2 - 1
+    d = torch.randn(B, 3, device="cuda")
+    d = d / d.norm(dim=-1, keepdim=True)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        sigma, rgb = m(x, d)
+    S = float(np.log2(m.encoder.per_level_scale))
+    enc = oracle.grid_encode_forward(to_np((x + 1) / 2), to_np(m.encoder.embeddings).astype(np.float16), to_np(m.encoder.offsets), 3, 2, 16, S, 16)
+    enc = np.transpose(enc, (1, 0, 2)).reshape(B, 32)
+    pad = 128 - B % 128
+    encp = np.concatenate([enc, np.zeros((pad, 32), np.float16)])
+    h = oracle.ffmlp_forward(encp, to_np(m.sigma_net.weights).astype(np.float16), 32, 64, 2, 0, training=False)[:B]
+    sig_ref = np.exp(h[:, 0].astype(np.float32))
+    np.testing.assert_allclose(to_np(sigma), sig_ref, rtol=3e-2, atol=1e-3)     # exp amplifies the few-half-ulp MLP difference
+    sh = to_np(sh_encode_deg4(d)).astype(np.float16)
+    cin = np.concatenate([sh, h[:, 1:], np.zeros((B, 1), np.float16)], 1)
+    cin = np.concatenate([cin, np.zeros((pad, 32), np.float16)])
+    c = oracle.ffmlp_forward(cin, to_np(m.color_net.weights).astype(np.float16), 32, 64, 3, 0, training=False)[:B, :3]
+    rgb_ref = 1 / (1 + np.exp(-c.astype(np.float32)))
+    np.testing.assert_allclose(to_np(rgb).astype(np.float32), rgb_ref, atol=1e-2)
+
+
+def test_cuda_ray_training_reduces_loss():
+    """A few Adam steps on the occupancy-grid path (march -> encode -> MLPs -> composite -> backward)."""
+    from focnerf_amd import synthetic
+    bound = 2
+    m = _model(bound, True).train()
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda")
+    o, d = synthetic.make_view_rays(64, 64, bound, 1, seed=1, device="cuda")
+    target = torch.zeros(1, o.shape[1], 3, device="cuda")
+    target[..., 0] = 0.8
+    losses = []
+    for it in range(30):
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = m.render(o, d, staged=False, perturb=True, force_all_rays=False, dt_gamma=1 / 128, max_steps=1024, bg_color=0.0)
+            loss = torch.nn.functional.mse_loss(out["image"], target)
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+        if it % 16 == 15:
+            m.update_extra_state()
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), f"loss did not go down: {losses[:5]} -> {losses[-5:]}"
+    assert m.mean_count > 0
+
+
+def test_inference_loop_matches_training_composite():
+    """The incremental inference path (march_rays / composite_rays) and the one-shot training path
+    (march_rays_train / composite_rays_train) render the same image for the same network."""
+    from focnerf_amd import synthetic
+    bound = 2
+    m = _model(bound, True, seed=3)
+    o, d = synthetic.make_view_rays(48, 48, bound, 1, seed=2, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        m.train()
+        a = m.render(o, d, staged=False, perturb=False, force_all_rays=True, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0)
+        m.eval()
+        b = m.render(o, d, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
+        c = m.render(o, d, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4, device_compaction=True)
+    assert torch.allclose(a["image"], b["image"], atol=2e-3)
+    assert torch.equal(b["image"], c["image"])
+    assert (a["image"] < 0.99).any(), "the view should hit the object"
+
+
+def test_fixed_step_run_matches_oracle_composite():
+    """FOC default path: run() with num_steps=512; image/depth against the oracle's fixed-step composite of the same fields."""
+    m = _model(1, False, seed=5).eval()
+    from focnerf_amd import synthetic, raymarching
+    o, d = synthetic.make_view_rays(32, 32, 1, 1, seed=3, device="cuda", radius=2.0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        res = m.run(o, d, num_steps=512, upsample_steps=0, bg_color=1.0, perturb=False, return_fields=True)
+    nears, fars = raymarching.near_far_from_aabb(o[0], d[0], m.aabb_infer, m.min_near)
+    img4, depth = oracle.composite_fixed_steps(to_np(res["densities"].squeeze(-1).float()), to_np(res["rgbs"].float()), to_np(nears), to_np(fars), 1.0, clamp01=False)
+    hit = to_np(nears) < 1e30
+    np.testing.assert_allclose(to_np(res["image"][0])[hit], img4[hit, :3], atol=1e-4)
+    np.testing.assert_allclose(to_np(res["depth"][0])[hit], depth[hit], atol=1e-4)
+    # the HIP fixed-step composite used by the combiner gives the same numbers (clamped)
+    from focnerf_amd.combine import composite_fixed_steps
+    im4, dp = composite_fixed_steps(res["densities"].squeeze(-1).float().contiguous(), res["rgbs"].float().contiguous(), nears, fars, 1.0)
+    np.testing.assert_allclose(to_np(im4)[hit], np.clip(img4[hit], 0, 1), atol=1e-4)
+    np.testing.assert_allclose(to_np(dp)[hit], depth[hit], atol=1e-4)

@@ -1,0 +1,42 @@
+"""Shared helpers for the GPU parity tests."""
+import math
+
+import numpy as np
+import torch
+
+from focnerf_amd import synthetic
+
+
+def scene(bound, N, seed=0, H=64, W=64, dev="cuda", sigma0=50.0, radius=2.0):
+    """Rays of a small synthetic view + the packed analytic occupancy grid (host copies included)."""
+    cascade = 1 + math.ceil(math.log2(bound))
+    grid = synthetic.analytic_density_grid(bound, sigma0=sigma0, device="cpu")
+    thresh = min(float(grid.clamp(min=0).mean()), 10.0)
+    bits = synthetic.packbits_host(grid, thresh)
+    rays_o, rays_d = synthetic.make_view_rays(H, W, bound, 1, seed=seed, device="cpu", radius=radius)
+    rays_o, rays_d = rays_o[0], rays_d[0]
+    if N < rays_o.shape[0]:
+        g = torch.Generator().manual_seed(seed + 100)
+        sel = torch.randperm(rays_o.shape[0], generator=g)[:N]
+        rays_o, rays_d = rays_o[sel].contiguous(), rays_d[sel].contiguous()
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+    return dict(bound=float(bound), cascade=cascade, grid=grid, thresh=thresh, bits=bits, rays_o=rays_o, rays_d=rays_d, aabb=aabb)
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def half_ulp(x):
+    """Spacing of fp16 at |x| (elementwise, numpy float32 in)."""
+    ax = np.maximum(np.abs(x.astype(np.float32)), 2.0 ** -14)
+    return (2.0 ** (np.floor(np.log2(ax)) - 10)).astype(np.float32)
+
+
+def assert_half_close(got, want, ulps=2.0, atol=0.0, what=""):
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    tol = ulps * half_ulp(want) + atol
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off by more than {ulps} half-ulp (+{atol}); " \
+                          f"worst |diff|={np.abs(got - want).max()}"
