@@ -1,0 +1,331 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the FOCNeRF hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, one OBJECT per rank — weak scaling)
+
+Workload (BASELINE.json configs[1]): single-object hash-grid + fused-MLP NeRF, fp16 autocast, rays
+drawn from synthetic 800x800 views, FOC's default fixed-step renderer (num_steps=512,
+upsample_steps=0, nerf/renderer.py:126-238): one STEP = 4096 rays x 512 samples = 2 097 152 samples
+through R1 -> G1 -> M1(sigma) -> weights -> M1(colour, masked) -> composite -> loss -> backward
+(M2, G2) -> Adam. `value` = samples completed per second, whole job (sum over ranks), inputs resident
+in HBM. Extra keys: `render` (full 800x800 view, rays/s), `occupancy_path` (config[2]: march +
+composite kernels), `roofline` (dominant kernel, timed with events on the launch stream),
+`cpu_baseline` (the CPU oracle port on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+NUM_RAYS = 4096          # main_nerf.py:28
+NUM_STEPS = 512          # main_nerf.py:31
+VIEW = 800
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0
+
+# algorithmic bytes per sample (fp16 table/activations, fp32 coords)
+ALGO_BYTES = {
+    "grid_encode_forward": 588.0,
+    "grid_encode_backward": 588.0,
+    "ffmlp_forward": None,    # per network, filled below from its shape
+    "ffmlp_backward": None,
+}
+
+
+def mlp_bytes_per_row(input_dim, hidden, num_layers, train, backward=False):
+    # forward (train): read input, write every hidden activation, write 16 outputs   (fp16)
+    fwd = 2 * input_dim + (2 * hidden * num_layers if train else 0) + 32
+    if not backward:
+        return float(fwd)
+    # backward: read grad 32, forward activations (mask + dW) 2x, write + re-read backward buffers, inputs, grad_inputs
+    return float(32 + 2 * (2 * hidden * num_layers) + 2 * (2 * hidden * num_layers) + 2 * input_dim + 2 * input_dim)
+
+
+def mlp_flops_per_row(input_dim, hidden, num_layers):
+    return 2.0 * (input_dim * hidden + (num_layers - 1) * hidden * hidden + hidden * 16)
+
+
+class KernelTimer:
+    """Event pairs around the C-ABI calls of focnerf_amd.backend, on torch's current stream (the stream the kernels launch on)."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+        self._orig = {}
+
+    def install(self):
+        from focnerf_amd import backend
+        targets = [(backend._gridencoder, "grid_encode_forward"), (backend._gridencoder, "grid_encode_backward"),
+                   (backend._ffmlp, "ffmlp_forward"), (backend._ffmlp, "ffmlp_inference"), (backend._ffmlp, "ffmlp_backward"),
+                   (backend._raymarching, "march_rays_train"), (backend._raymarching, "composite_rays_train_forward"),
+                   (backend._raymarching, "composite_rays_train_backward"), (backend._raymarching, "near_far_from_aabb")]
+        for cls, name in targets:
+            orig = getattr(cls, name)
+            self._orig[(cls, name)] = orig
+
+            def make(orig, name):
+                def wrapped(*a, **k):
+                    if not self.enabled:
+                        return orig(*a, **k)
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    r = orig(*a, **k)
+                    e.record()
+                    units = a[4] if name.startswith("grid_encode_forward") else None
+                    if name == "grid_encode_backward":
+                        units = a[5]
+                    elif name.startswith("ffmlp"):
+                        units = a[2] if name != "ffmlp_backward" else a[4]
+                    self.records.setdefault(name, []).append((s, e, units, a))
+                    return r
+                return staticmethod(wrapped)
+            setattr(cls, name, make(orig, name))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            units = [u for _, _, u, _ in recs if u is not None]
+            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                         "avg_units": (sum(units) / len(units)) if units else None}
+        return out
+
+
+def build_model(bound, device, cuda_ray=False, seed=0):
+    from focnerf_amd.network import NeRFNetwork
+    from focnerf_amd import synthetic
+    torch.manual_seed(seed)
+    model = NeRFNetwork(bound=bound, cuda_ray=cuda_ray).to(device)
+    if cuda_ray:
+        model.set_density_grid(synthetic.analytic_density_grid(bound, device=device))
+    return model
+
+
+def make_training_rays(device, bound, n_views, seed):
+    from focnerf_amd import synthetic
+    g = torch.Generator().manual_seed(seed)
+    poses = synthetic.rand_poses(n_views, device, radius=2.0, generator=g)
+    intr = synthetic.intrinsics(VIEW, VIEW)
+    return poses, intr
+
+
+def sample_batch(poses, intr, device, gen):
+    from focnerf_amd import synthetic
+    v = int(torch.randint(0, poses.shape[0], (1,), generator=gen).item())
+    inds = torch.randint(0, VIEW * VIEW, (1, NUM_RAYS), generator=gen).to(device)
+    rays_o, rays_d = synthetic.get_rays(poses[v:v + 1], intr, VIEW, VIEW, inds)
+    # synthetic target: colour of the analytic scene does not matter for throughput; use a smooth function of the ray
+    target = 0.5 + 0.5 * torch.sin(3.0 * rays_d)
+    return rays_o, rays_d, target
+
+
+def train_step(model, opt, scaler, rays_o, rays_d, target):
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = model.render(rays_o, rays_d, staged=False, num_steps=NUM_STEPS, upsample_steps=0, perturb=True, bg_color=None)
+        loss = torch.nn.functional.mse_loss(out["image"], target)
+    opt.zero_grad(set_to_none=True)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    return loss
+
+
+def cuda_ray_train_step(model, opt, scaler, rays_o, rays_d, target):
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = model.render(rays_o, rays_d, staged=False, perturb=True, force_all_rays=False, dt_gamma=1 / 128, max_steps=1024, bg_color=None)
+        loss = torch.nn.functional.mse_loss(out["image"], target)
+    opt.zero_grad(set_to_none=True)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    return loss
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle port of the same step's kernels (G1 -> M1 sigma -> M1 colour -> fixed-step composite, forward and backward)
+    on a bounded sample: as many 512-sample rays as fit in ~budget_s seconds of one host core."""
+    import numpy as np
+    import oracle
+    from focnerf_amd.gridencoder import level_offsets
+    rng = np.random.default_rng(0)
+    pls = np.exp2(np.log2(2048 / 16) / 15)
+    S = float(np.log2(pls))
+    off = level_offsets(3, 16, pls, 16, 19)
+    table = rng.uniform(-1, 1, (int(off[-1]), 2)).astype(np.float16)
+    Ws = (rng.uniform(-1, 1, 64 * (32 + 64 + 16)) * 0.2).astype(np.float16)
+    Wc = (rng.uniform(-1, 1, 64 * (32 + 128 + 16)) * 0.2).astype(np.float16)
+    rays_per_chunk = 8
+    B = rays_per_chunk * NUM_STEPS            # 4096 samples, a multiple of 128
+    done, t0 = 0, time.perf_counter()
+    while True:
+        x = rng.random((B, 3)).astype(np.float32)
+        enc = oracle.grid_encode_forward(x, table, off, 3, 2, 16, S, 16)
+        enc_bl = np.ascontiguousarray(np.transpose(enc, (1, 0, 2)).reshape(B, 32))
+        h, fb_s = oracle.ffmlp_forward(enc_bl, Ws, 32, 64, 2, 0)
+        sigma = np.exp(h[:, 0].astype(np.float32))
+        c, fb_c = oracle.ffmlp_forward(np.concatenate([h, h], 1).astype(np.float16), Wc, 32, 64, 3, 0)
+        rgb = 1 / (1 + np.exp(-c[:, :3].astype(np.float32)))
+        nears = np.full(rays_per_chunk, 0.5, np.float32); fars = np.full(rays_per_chunk, 2.5, np.float32)
+        oracle.composite_fixed_steps(sigma.reshape(rays_per_chunk, NUM_STEPS), rgb.reshape(rays_per_chunk, NUM_STEPS, 3), nears, fars, 1.0)
+        g = (rng.standard_normal((B, 16)) * 0.01).astype(np.float16)
+        gw_c, gi_c, _ = oracle.ffmlp_backward(g, np.concatenate([h, h], 1).astype(np.float16), Wc, fb_c, 32, 64, 3, 0, True)
+        gw_s, gi_s, _ = oracle.ffmlp_backward(gi_c[:, :16].copy(), enc_bl, Ws, fb_s, 32, 64, 2, 0, True)
+        genc = np.ascontiguousarray(np.transpose(gi_s.reshape(B, 16, 2), (1, 0, 2)))
+        oracle.grid_encode_backward(genc, x, off, int(off[-1]), 3, 2, 16, S, 16)
+        done += B
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {"value": done / el, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{done} samples ({done // NUM_STEPS} rays x {NUM_STEPS}) of the same step's kernels "
+                      f"(hash-grid fwd/bwd, both fused MLPs fwd/bwd, fixed-step composite), scalar C oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--render-views", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the render / occupancy-path extras")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    bound = 1
+    model = build_model(bound, device, cuda_ray=False, seed=rank).train()
+    opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    scaler = torch.amp.GradScaler("cuda")
+    poses, intr = make_training_rays(device, bound, 8, seed=rank)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    batches = [sample_batch(poses, intr, device, gen) for _ in range(4)]
+
+    timer = KernelTimer()
+    timer.install()
+
+    for i in range(args.warmup):
+        train_step(model, opt, scaler, *batches[i % len(batches)])
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        train_step(model, opt, scaler, *batches[i % len(batches)])
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    timer.enabled = False
+    ksum = timer.summary()
+
+    samples_per_step = NUM_RAYS * NUM_STEPS
+    value = world * samples_per_step * args.steps / el
+    result = {
+        "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: single-object hash-grid(L16,C2,2^19)+ffmlp fp16 NeRF, rays from synthetic 800x800 views, "
+                               "fixed-step renderer num_steps=512", "rays_per_step": NUM_RAYS, "samples_per_step": samples_per_step,
+                   "objects": world, "parallelism": f"one object per GPU x{world}", "optimizer": "Adam(fused) inside the timed step"},
+    }
+
+    # ---- roofline of the dominant kernel of the timed region
+    if ksum:
+        shapes = {"ffmlp_forward": None, "ffmlp_backward": None}
+        dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
+        r = ksum[dom]
+        units = r["avg_units"] or samples_per_step
+        if dom in ("grid_encode_forward", "grid_encode_backward"):
+            bytes_per_unit = ALGO_BYTES[dom]
+        elif dom in ("ffmlp_forward", "ffmlp_inference"):
+            bytes_per_unit = 0.5 * (mlp_bytes_per_row(32, 64, 2, True) + mlp_bytes_per_row(32, 64, 3, True))
+        else:
+            bytes_per_unit = 0.5 * (mlp_bytes_per_row(32, 64, 2, True, True) + mlp_bytes_per_row(32, 64, 3, True, True))
+        achieved = bytes_per_unit * units / (r["avg_ms"] * 1e-3) / 1e9
+        result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": None, "avg_launch_ms": r["avg_ms"], "units_per_launch": units, "algorithmic_bytes_per_unit": bytes_per_unit}
+        result["kernels"] = {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "share_of_step": round(v["total_ms"] / (1000.0 * el), 4)}
+                             for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])}
+
+    if not args.no_extras:
+        # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
+        from focnerf_amd import synthetic
+        model.eval()
+        rays_o, rays_d = synthetic.get_rays(poses[:1], intr, VIEW, VIEW)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            model.render(rays_o[:, :8192], rays_d[:, :8192], staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.render_views):
+                model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False)
+            barrier()
+        rel = max_over_ranks(time.perf_counter() - t0)
+        result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",
+                            "samples_per_sec": world * VIEW * VIEW * NUM_STEPS * args.render_views / rel, "views": args.render_views,
+                            "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks"}
+
+        # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
+        m2 = build_model(2, device, cuda_ray=True, seed=rank).train()
+        opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+        sc2 = torch.amp.GradScaler("cuda")
+        poses2, _ = make_training_rays(device, 2, 8, seed=rank)
+        b2 = [sample_batch(poses2, intr, device, gen) for _ in range(4)]
+        for i in range(17):
+            cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+            if i == 15:
+                m2.mean_count = int(m2.step_counter[:16, 0].sum().item() / 16)    # what update_extra_state would set (renderer.py:533)
+        barrier()
+        n2 = max(args.steps, 10)
+        c0 = 0
+        t0 = time.perf_counter()
+        for i in range(n2):
+            cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+        barrier()
+        el2 = max_over_ranks(time.perf_counter() - t0)
+        per_step = float(m2.step_counter[:, 0].float().mean().item())
+        result["occupancy_path"] = {"metric": "train_samples_per_sec", "value": world * per_step * n2 / el2, "unit": "samples/s",
+                                    "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
+                                    "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,22 @@ class _gridencoder:
         check(fn(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype, int(bool(align_corners)),
                  interp, dt, None, stream_of(inputs)), "grid_encode_forward")
 
+    _offsets_host = {}
+
+    @staticmethod
+    def _host_offsets(offsets):
+        """Host copy of the (tiny, immutable) level-offset table; cached so the backward does not sync every call."""
+        key = (offsets.data_ptr(), offsets.numel(), offsets._version, str(offsets.device))
+        h = _gridencoder._offsets_host.get(key)
+        if h is None:
+            import ctypes
+            arr = offsets.detach().cpu().numpy().astype("int32")
+            h = (arr, arr.ctypes.data_as(ctypes.c_void_p))
+            if len(_gridencoder._offsets_host) > 64:
+                _gridencoder._offsets_host.clear()
+            _gridencoder._offsets_host[key] = h
+        return h[1]
+
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, grad_bl=False):
         _gridencoder._common(inputs, embeddings, offsets)
@@ -152,6 +168,15 @@ class _gridencoder:
         dt = dtype_code(grad)                               # the reference dispatches on grad.scalar_type(), :498-499
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grid_encode_backward: grad_embeddings must share grad's dtype")
+        # D=3, C=2 tables: partition + LDS accumulation instead of scattered atomics (FOCNERF_GRID_ATOMIC=1 forces the atomic kernel)
+        import os
+        ws_bytes = 0 if os.environ.get("FOCNERF_GRID_ATOMIC", "0") == "1" else lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
+        if ws_bytes and B * 8 * L < 2 ** 32:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad.device)
+            check(lib.foc_grid_encode_backward_binned(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                                                      ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),
+                                                      _gridencoder._host_offsets(offsets), ptr(ws), ws_bytes, stream_of(inputs)), "grid_encode_backward_binned")
+            return
         check(lib.foc_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                                            ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),
                                            None, stream_of(inputs)), "grid_encode_backward")

@@ -41,9 +41,9 @@ __global__ void __launch_bounds__(256) k_freq_bwd(const float *__restrict__ grad
 extern "C" {
 
 int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs, void *stream) {
+    if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && outputs, FOC_E_INVALID, "freq_encode_forward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_forward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);
-    if (B == 0) return FOC_OK;
     hipLaunchKernelGGL(k_freq_fwd, dim3(foc_grid_1d((uint64_t)B * C, 256)), dim3(256), 0, (hipStream_t)stream, inputs, B, D, C, outputs);
     FOC_CHECK_LAUNCH("freq_encode_forward");
     return FOC_OK;
@@ -51,9 +51,9 @@ int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_
 
 int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                              float *grad_inputs, void *stream) {
+    if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && outputs && grad_inputs, FOC_E_INVALID, "freq_encode_backward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_backward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);
-    if (B == 0) return FOC_OK;
     hipLaunchKernelGGL(k_freq_bwd, dim3(foc_grid_1d((uint64_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad, outputs, B, D, deg, C, grad_inputs);
     FOC_CHECK_LAUNCH("freq_encode_backward");
     return FOC_OK;

@@ -32,6 +32,11 @@ struct GeLevels {
 };
 
 // ---- storage-type helpers -------------------------------------------------------------
+// Keeps an fp32 value materialised in a VGPR. Without it LLVM folds `(half)fma(a,b,c)` into
+// v_fma_mixlo_f16, which rounds the exact fma ONCE to fp16; the reference (and the oracle) round to
+// fp32 first and then to fp16, and the two differ on fp32 values that sit on an fp16 tie.
+__device__ __forceinline__ float ge_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+
 template <typename T> struct GeT;
 template <> struct GeT<float> {
     static __device__ __forceinline__ float ld(const float *p) { return *p; }
@@ -39,7 +44,7 @@ template <> struct GeT<float> {
 };
 template <> struct GeT<__half> {
     static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
-    static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(v); }
+    static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(ge_opaque(v)); }
 };
 
 template <typename T, uint32_t C> struct GeVec;
@@ -71,10 +76,10 @@ template <uint32_t C> struct GeVec<__half, C> {
         }
     }
     static __device__ __forceinline__ void st(__half *p, const float (&v)[C]) {
-        if constexpr (C == 1) p[0] = __float2half_rn(v[0]);
+        if constexpr (C == 1) p[0] = __float2half_rn(ge_opaque(v[0]));
         else {
 #pragma unroll
-            for (uint32_t i = 0; i < C; i += 2) *reinterpret_cast<__half2 *>(p + i) = __halves2half2(__float2half_rn(v[i]), __float2half_rn(v[i + 1]));
+            for (uint32_t i = 0; i < C; i += 2) *reinterpret_cast<__half2 *>(p + i) = __halves2half2(__float2half_rn(ge_opaque(v[i])), __float2half_rn(ge_opaque(v[i + 1])));
         }
     }
 };
@@ -257,7 +262,7 @@ template <> struct GeAtomic<__half> {
         if constexpr (C == 1) {
             // C == 1 under fp16 is never produced by the reference wrapper (grid.py:43: half only when C % 2 == 0);
             // handled with a CAS loop on the containing dword for completeness.
-            const __half hv = __float2half_rn(v[0]);
+            const __half hv = __float2half_rn(ge_opaque(v[0]));
             if (__half2float(hv) == 0.0f) return;
             uint32_t *w = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
             const bool hi = (reinterpret_cast<uintptr_t>(p) & 2) != 0;
@@ -277,8 +282,8 @@ template <> struct GeAtomic<__half> {
             for (uint32_t c = 0; c < C; c += 2) {
                 // the reference rounds each addend to half before the packed atomic (gridencoder.cu:329)
                 v2h hv;
-                hv[0] = (_Float16)v[c];
-                hv[1] = (_Float16)v[c + 1];
+                hv[0] = (_Float16)ge_opaque(v[c]);
+                hv[1] = (_Float16)ge_opaque(v[c + 1]);
                 if ((float)hv[0] == 0.0f && (float)hv[1] == 0.0f) continue;
                 (void)__builtin_amdgcn_global_atomic_fadd_v2f16(
                     (__attribute__((address_space(1))) v2h *)(p + c), hv);
@@ -340,6 +345,257 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
     if (!any) return;
     ge_backward_one<T, D, C>(x, g, grad_grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
                              gridtype, align_corners, interp);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward without scattered atomics: partition (bin) -> per-segment LDS accumulation.
+//
+// The atomic scatter above is bound by the chip's memory-side atomic unit: 64 lanes hitting 64
+// different 64-B lines run at ~20 G atomics/s whatever the schedule (MI355X_MICROARCH.md "Global
+// float atomics"; measured here: 2.1 M points x 128 atomics in 15.7 ms). This path turns the
+// scatter into streaming traffic:
+//   1 count    every (point, level) computes its 8 corner rows; row >> 13 is the row's SEGMENT
+//              (8192 rows = 64 KiB of fp32 pairs, one LDS image); per-workgroup LDS histogram,
+//              then one global add per non-empty (level, segment);
+//   2 scan     exclusive prefix over the <= 64 x L segment counts, chunk table for step 4;
+//   3 scatter  recompute the rows, rank each record inside its segment with an LDS returning
+//              atomic, reserve the workgroup's range per segment with ONE global returning atomic,
+//              write {local row, w*grad} records (8 B for fp16, 4+8 B for fp32) with plain stores;
+//   4 reduce   one workgroup per (segment, chunk of <= 65536 records): accumulate in a 64 KiB fp32
+//              LDS image with ds_add_f32, then add the image to the gradient table with
+//              CONTIGUOUS atomics (256 B per wave instruction: the full-rate shape).
+// Sums are fp32 in LDS and rounded to the table dtype once per chunk — more accurate than the
+// reference's half2 atomicAdd per addend (gridencoder.cu:325-331). C = 2, D = 3 (the NeRF tables).
+#define GB_SEG_SHIFT 13u
+#define GB_SEG (1u << GB_SEG_SHIFT)            // rows per segment
+#define GB_MAX_SEGS 64u                        // per level: covers 2^19-row levels
+#define GB_CHUNK 65536u                        // records per reduce workgroup
+#define GB_SPT 4u                              // samples per thread in count/scatter
+#define GB_WG 256u
+
+struct GbHeader {                              // lives at the start of the workspace
+    uint32_t counts[GE_MAX_LEVELS * GB_MAX_SEGS];
+    uint32_t base[GE_MAX_LEVELS * GB_MAX_SEGS + 1];
+    uint32_t cursor[GE_MAX_LEVELS * GB_MAX_SEGS];
+    uint32_t chunk_prefix[GE_MAX_LEVELS * GB_MAX_SEGS + 1];
+};
+
+template <typename T> struct GbRec;
+template <> struct GbRec<__half> { static constexpr uint32_t bytes = 8; };    // {u32 local row, half2}
+template <> struct GbRec<float> { static constexpr uint32_t bytes = 12; };    // u32 rows[] + float2 vals[]
+
+// corner rows of one (point, level): same arithmetic as ge_backward_one
+template <uint32_t D>
+__device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
+                                           bool align_corners, uint32_t interp, uint32_t (&rows)[1u << D], float (&ws)[1u << D]) {
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+        if (interp == 1) { const float v = pos[d]; pos[d] = v * v * fmaf(-2.0f, v, 3.0f); }
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+        }
+        ws[idx] = w;
+        rows[idx] = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+    }
+}
+
+template <typename T, bool GRAD_BL>
+__device__ __forceinline__ bool gb_load(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t b, uint32_t level, uint32_t B,
+                                        uint32_t L, float (&x)[3], float (&g)[2]) {
+    if (b >= B) return false;
+    if (ge_load_point<3>(inputs, b, x)) return false;
+    const T *gp = GRAD_BL ? grad + ((uint64_t)b * L + level) * 2 : grad + ((uint64_t)level * B + b) * 2;
+    GeVec<T, 2>::ld(gp, g);
+    return (g[0] != 0.0f) || (g[1] != 0.0f);
+}
+
+template <typename T, bool GRAD_BL>
+__global__ void __launch_bounds__(GB_WG) k_gbin_count(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                                      GbHeader *__restrict__ hdr, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
+                                                      bool align_corners, uint32_t interp, uint32_t chunks) {
+    __shared__ uint32_t hist[GB_MAX_SEGS];
+    uint32_t level, chunk;
+    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    if (threadIdx.x < GB_MAX_SEGS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+#pragma unroll
+    for (uint32_t s = 0; s < GB_SPT; s++) {
+        const uint32_t b = (chunk * GB_SPT + s) * GB_WG + threadIdx.x;
+        float x[3], g[2];
+        if (gb_load<T, GRAD_BL>(grad, inputs, b, level, B, L, x, g)) {
+            uint32_t rows[8]; float ws[8];
+            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+            for (int i = 0; i < 8; i++) atomicAdd(&hist[rows[i] >> GB_SEG_SHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GB_MAX_SEGS && hist[threadIdx.x])
+        (void)__hip_atomic_fetch_add(&hdr->counts[level * GB_MAX_SEGS + threadIdx.x], hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// single workgroup: prefix sums over L * 64 segment counts
+__global__ void __launch_bounds__(1024) k_gbin_scan(GbHeader *__restrict__ hdr, uint32_t L) {
+    __shared__ uint32_t s_rec[GE_MAX_LEVELS * GB_MAX_SEGS];
+    __shared__ uint32_t s_chk[GE_MAX_LEVELS * GB_MAX_SEGS];
+    const uint32_t n = L * GB_MAX_SEGS;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t c = hdr->counts[i];
+        s_rec[i] = c;
+        s_chk[i] = (c + GB_CHUNK - 1) / GB_CHUNK;
+        hdr->cursor[i] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {       // n <= 2048: a serial scan is ~2 us and keeps this trivially correct
+        uint32_t r = 0, k = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            hdr->base[i] = r; hdr->chunk_prefix[i] = k;
+            r += s_rec[i]; k += s_chk[i];
+        }
+        hdr->base[n] = r; hdr->chunk_prefix[n] = k;
+    }
+}
+
+template <typename T, bool GRAD_BL>
+__global__ void __launch_bounds__(GB_WG) k_gbin_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                                        GbHeader *__restrict__ hdr, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L,
+                                                        GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks) {
+    __shared__ uint32_t hist[GB_MAX_SEGS];
+    __shared__ uint32_t gbase[GB_MAX_SEGS];
+    uint32_t level, chunk;
+    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    if (threadIdx.x < GB_MAX_SEGS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+    uint32_t key[GB_SPT][8];          // (segment << 26) | rank-in-workgroup     (rank < 8192)
+    uint32_t lrow[GB_SPT][8];
+    float val[GB_SPT][8][2];
+    bool live[GB_SPT];
+#pragma unroll
+    for (uint32_t s = 0; s < GB_SPT; s++) {
+        const uint32_t b = (chunk * GB_SPT + s) * GB_WG + threadIdx.x;
+        float x[3], g[2];
+        live[s] = gb_load<T, GRAD_BL>(grad, inputs, b, level, B, L, x, g);
+        if (live[s]) {
+            uint32_t rows[8]; float ws[8];
+            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
+                const uint32_t rank = atomicAdd(&hist[seg], 1u);
+                key[s][i] = (seg << 26) | rank;
+                lrow[s][i] = rows[i] & (GB_SEG - 1u);
+                val[s][i][0] = ws[i] * g[0];
+                val[s][i][1] = ws[i] * g[1];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GB_MAX_SEGS) {
+        const uint32_t h = hist[threadIdx.x];
+        const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
+        gbase[threadIdx.x] = h ? hdr->base[slot] + __hip_atomic_fetch_add(&hdr->cursor[slot], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t s = 0; s < GB_SPT; s++) {
+        if (!live[s]) continue;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t at = (uint64_t)gbase[key[s][i] >> 26] + (key[s][i] & 0x3FFFFFFu);
+            if (at >= max_recs) continue;                      // cannot happen when counts and scatter agree; keeps a logic slip from faulting
+            if constexpr (sizeof(T) == 2) {
+                uint2 r;
+                r.x = lrow[s][i];
+                const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(val[s][i][0])), __float2half_rn(ge_opaque(val[s][i][1])));
+                r.y = *reinterpret_cast<const uint32_t *>(&hv);
+                reinterpret_cast<uint2 *>(recs)[at] = r;
+            } else {
+                uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
+                float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));   // values follow the row array (8-B aligned)
+                rr[at] = lrow[s][i];
+                vv[at] = make_float2(val[s][i][0], val[s][i][1]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
+                                                     const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
+    __shared__ float acc[GB_SEG * 2];              // 64 KiB
+    __shared__ uint32_t s_slot, s_lo, s_hi;
+    const uint32_t n = L * GB_MAX_SEGS;
+    const uint32_t total_chunks = hdr->chunk_prefix[n];
+    if (blockIdx.x >= total_chunks) return;
+    if (threadIdx.x == 0) {
+        // largest slot with chunk_prefix[slot] <= blockIdx.x  (binary search over <= 2049 entries)
+        uint32_t lo = 0, hi = n;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hdr->chunk_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+        // skip empty slots that share the same prefix value
+        while (lo + 1 < n && hdr->chunk_prefix[lo + 1] <= blockIdx.x) lo++;
+        const uint32_t c = blockIdx.x - hdr->chunk_prefix[lo];
+        const uint32_t cnt = hdr->counts[lo];
+        s_slot = lo;
+        s_lo = hdr->base[lo] + c * GB_CHUNK;
+        s_hi = hdr->base[lo] + min(cnt, (c + 1) * GB_CHUNK);
+    }
+    for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += 512) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t slot = s_slot, lo = s_lo, hi = s_hi;
+    if constexpr (sizeof(T) == 2) {
+        const uint2 *rr = reinterpret_cast<const uint2 *>(recs);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 512) {
+            const uint2 r = rr[i];
+            const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
+            atomicAdd(&acc[r.x * 2], v.x);
+            atomicAdd(&acc[r.x * 2 + 1], v.y);
+        }
+    } else {
+        const uint32_t *rr = reinterpret_cast<const uint32_t *>(recs);
+        const float2 *vv = reinterpret_cast<const float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 512) {
+            const uint32_t r = rr[i];
+            const float2 v = vv[i];
+            atomicAdd(&acc[r * 2], v.x);
+            atomicAdd(&acc[r * 2 + 1], v.y);
+        }
+    }
+    __syncthreads();
+    const uint32_t level = slot / GB_MAX_SEGS, seg = slot % GB_MAX_SEGS;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t row0 = seg * GB_SEG;
+    T *dst = grad_grid + ((uint64_t)off0 + row0) * 2;
+    const uint32_t nrows = hashmap_size > row0 ? min(GB_SEG, hashmap_size - row0) : 0u;
+    if constexpr (sizeof(T) == 2) {
+        typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
+        for (uint32_t r = threadIdx.x; r < nrows; r += 512) {
+            const float a = acc[2 * r], b = acc[2 * r + 1];
+            if (a == 0.0f && b == 0.0f) continue;
+            v2h hv; hv[0] = (_Float16)ge_opaque(a); hv[1] = (_Float16)ge_opaque(b);
+            (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) v2h *)(dst + 2 * r), hv);
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < nrows * 2; e += 512) {
+            const float a = acc[e];
+            if (a != 0.0f) (void)__hip_atomic_fetch_add(dst + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // gridencoder.cu:343-369: grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (fp32 accumulate)
@@ -471,6 +727,7 @@ static int ge_forward_d(uint32_t D, uint32_t C, const float *inputs, const void 
 static int ge_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
                       uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners, uint32_t interp,
                       int dtype, bool bl, void *stream) {
+    if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && embeddings && offsets && outputs, FOC_E_INVALID, "grid_encode_forward: null pointer");
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_forward: dtype must be FOC_F32 or FOC_F16");
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grid_encode_forward: L must be in [1,%d]", GE_MAX_LEVELS);
@@ -537,6 +794,38 @@ static int ge_tv_c(uint32_t C, const void *inputs, const void *emb, void *grad, 
     }
 }
 
+
+// ---- binned backward: host side --------------------------------------------------------------
+static uint64_t gb_max_recs(uint32_t B, uint32_t L) { return (uint64_t)B * 8u * L; }
+static uint64_t gb_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
+    const uint64_t hdr = (sizeof(GbHeader) + 255) & ~(uint64_t)255;
+    const uint64_t m = gb_max_recs(B, L);
+    return hdr + (dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 256;
+}
+
+template <typename T>
+static int gb_run(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, const GeLevels &lv,
+                  uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, hipStream_t st) {
+    GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
+    void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
+    const uint64_t max_recs = gb_max_recs(B, L);
+    if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
+    const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
+    const dim3 grid(ge_xcd_grid(chunks, L));
+    if (bl) hipLaunchKernelGGL((k_gbin_count<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
+    else hipLaunchKernelGGL((k_gbin_count<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
+    FOC_CHECK_LAUNCH("grid_encode_backward(count)");
+    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
+    if (bl) hipLaunchKernelGGL((k_gbin_scatter<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
+    else hipLaunchKernelGGL((k_gbin_scatter<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+    const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;
+    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(512), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
+    FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
+    return FOC_OK;
+}
+
 extern "C" {
 
 int foc_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
@@ -558,6 +847,7 @@ int foc_grid_encode_backward(const void *grad, const float *inputs, const void *
                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
                              const int32_t *offsets_host, void *stream) {
     (void)offsets_host; (void)embeddings;
+    if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && inputs && offsets && grad_embeddings, FOC_E_INVALID, "grid_encode_backward: null pointer");
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_backward: dtype must be FOC_F32 or FOC_F16");
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grid_encode_backward: L must be in [1,%d]", GE_MAX_LEVELS);
@@ -582,9 +872,51 @@ int foc_grid_encode_backward(const void *grad, const float *inputs, const void *
     return FOC_E_INVALID;
 }
 
+uint64_t foc_grid_encode_backward_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype) {
+    if (D != 3 || C != 2 || L > GE_MAX_LEVELS) return 0;       // 0: the binned path does not apply; use foc_grid_encode_backward
+    return gb_workspace_bytes(B, L, dtype);
+}
+
+int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
+    (void)embeddings;
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_binned: null pointer");
+    FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_backward_binned: dtype must be FOC_F32 or FOC_F16");
+    FOC_REQUIRE(D == 3 && C == 2, FOC_E_INVALID, "grid_encode_backward_binned: only D=3, C=2 (got D=%u C=%u)", D, C);
+    FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && gridtype <= 1 && interp <= 1, FOC_E_INVALID, "grid_encode_backward_binned: bad L/gridtype/interp");
+    FOC_REQUIRE(workspace_bytes >= gb_workspace_bytes(B, L, dtype), FOC_E_INVALID, "grid_encode_backward_binned: workspace too small");
+    FOC_REQUIRE((uint64_t)B * 8u * L < (1ull << 32), FOC_E_INVALID, "grid_encode_backward_binned: B*8*L must stay below 2^32 records");
+    for (uint32_t l = 0; l < L; l++)
+        FOC_REQUIRE((uint32_t)(offsets_host[l + 1] - offsets_host[l]) <= GB_SEG * GB_MAX_SEGS, FOC_E_INVALID,
+                    "grid_encode_backward_binned: level %u has more than %u rows", l, GB_SEG * GB_MAX_SEGS);
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ac = align_corners != 0, bl = grad_is_bl != 0;
+    int rc = dtype == FOC_F32 ? gb_run<float>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, st)
+                              : gb_run<__half>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, st);
+    if (rc) return rc;
+    if (dy_dx && grad_inputs) {
+        const uint32_t g = foc_grid_1d((uint64_t)B * 3, 256);
+        if (dtype == FOC_F32) {
+            if (bl) hipLaunchKernelGGL((k_grid_input_bwd<float, 3, 2, true>), dim3(g), dim3(256), 0, st, (const float *)grad, (const float *)dy_dx, (float *)grad_inputs, B, L);
+            else hipLaunchKernelGGL((k_grid_input_bwd<float, 3, 2, false>), dim3(g), dim3(256), 0, st, (const float *)grad, (const float *)dy_dx, (float *)grad_inputs, B, L);
+        } else {
+            if (bl) hipLaunchKernelGGL((k_grid_input_bwd<__half, 3, 2, true>), dim3(g), dim3(256), 0, st, (const __half *)grad, (const __half *)dy_dx, (__half *)grad_inputs, B, L);
+            else hipLaunchKernelGGL((k_grid_input_bwd<__half, 3, 2, false>), dim3(g), dim3(256), 0, st, (const __half *)grad, (const __half *)dy_dx, (__half *)grad_inputs, B, L);
+        }
+        FOC_CHECK_LAUNCH("grid_encode_backward(inputs)");
+    }
+    return FOC_OK;
+}
+
 int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets, float weight, uint32_t B,
                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                              void *stream) {
+    if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && embeddings && grad && offsets, FOC_E_INVALID, "grad_total_variation: null pointer");
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grad_total_variation: dtype must be FOC_F32 or FOC_F16");
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS, FOC_E_INVALID, "grad_total_variation: L must be in [1,%d]", GE_MAX_LEVELS);

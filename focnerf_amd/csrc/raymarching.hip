@@ -508,8 +508,8 @@ extern "C" {
 
 int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
                            float *nears, float *fars, void *stream) {
-    FOC_REQUIRE(rays_o && rays_d && aabb && nears && fars, FOC_E_INVALID, "near_far_from_aabb: null pointer");
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(rays_o && rays_d && aabb && nears && fars, FOC_E_INVALID, "near_far_from_aabb: null pointer");
     hipLaunchKernelGGL(k_near_far_from_aabb, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        rays_o, rays_d, aabb, N, min_near, nears, fars);
     FOC_CHECK_LAUNCH("near_far_from_aabb");
@@ -517,32 +517,32 @@ int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
 }
 
 int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
-    FOC_REQUIRE(rays_o && rays_d && coords, FOC_E_INVALID, "sph_from_ray: null pointer");
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(rays_o && rays_d && coords, FOC_E_INVALID, "sph_from_ray: null pointer");
     hipLaunchKernelGGL(k_sph_from_ray, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
     FOC_CHECK_LAUNCH("sph_from_ray");
     return FOC_OK;
 }
 
 int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
-    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D: null pointer");
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D: null pointer");
     hipLaunchKernelGGL(k_morton3D, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
     FOC_CHECK_LAUNCH("morton3D");
     return FOC_OK;
 }
 
 int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
-    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D_invert: null pointer");
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D_invert: null pointer");
     hipLaunchKernelGGL(k_morton3D_invert, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
     FOC_CHECK_LAUNCH("morton3D_invert");
     return FOC_OK;
 }
 
 int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
-    FOC_REQUIRE(grid && bitfield, FOC_E_INVALID, "packbits: null pointer");
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(grid && bitfield, FOC_E_INVALID, "packbits: null pointer");
     uint32_t N4 = 0;
     if ((((uintptr_t)grid) & 15u) == 0 && (((uintptr_t)bitfield) & 3u) == 0) N4 = N / 4;
     if (N4) {
@@ -564,6 +564,7 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+    if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
                 "march_rays_train: null pointer");
     FOC_REQUIRE(M == 0 || (xyzs && dirs && deltas), FOC_E_INVALID, "march_rays_train: null output with M > 0");
@@ -571,7 +572,6 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                 "march_rays_train: unsupported C=%u H=%u max_steps=%u", C, H, max_steps);
     // the float index `level*H^3 + morton` of raymarching.cu:378 is exact only below 2^24
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_train: C*H^3 exceeds 2^24");
-    if (N == 0) return FOC_OK;
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch);
@@ -589,9 +589,9 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
                                      uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
                                      void *stream) {
+    if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays && weights_sum && depth && image, FOC_E_INVALID, "composite_rays_train_forward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas), FOC_E_INVALID, "composite_rays_train_forward: null input with M > 0");
-    if (N == 0) return FOC_OK;
     hipLaunchKernelGGL(k_composite_train_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream,
                        sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     FOC_CHECK_LAUNCH("composite_rays_train_forward");
@@ -602,11 +602,11 @@ int foc_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
                                       const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                       float *grad_rgbs, void *stream) {
+    if (N == 0) return FOC_OK;
     FOC_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, FOC_E_INVALID,
                 "composite_rays_train_backward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), FOC_E_INVALID,
                 "composite_rays_train_backward: null buffer with M > 0");
-    if (N == 0) return FOC_OK;
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream,
                        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
                        grad_sigmas, grad_rgbs);

@@ -169,6 +169,22 @@ int foc_grid_encode_backward(const void *grad, const float *inputs, const void *
                              int align_corners, uint32_t interp, int dtype, int grad_is_bl,
                              const int32_t *offsets_host, void *stream);
 
+/* Same result as foc_grid_encode_backward for D = 3, C = 2 tables, computed WITHOUT scattered atomics:
+ * the (row, w*grad) contributions are partitioned by 8192-row table segment and summed per segment in
+ * LDS (fp32), then added to grad_embeddings with contiguous atomics. Scattered memory-side atomics cap
+ * the atomic entry point at ~2x10^10 corner updates/s on MI355X; this path streams instead.
+ * workspace: device scratch of foc_grid_encode_backward_workspace_bytes() bytes (0 = shape not
+ * supported: call foc_grid_encode_backward). offsets_host (L+1 ints in HOST memory) is required.
+ * Extension: no reference binding (the reference has only the atomic kernel, gridencoder.cu:248-340). */
+uint64_t foc_grid_encode_backward_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype);
+int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const void *embeddings,
+                                    const int32_t *offsets, void *grad_embeddings,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                    const void *dy_dx, void *grad_inputs, uint32_t gridtype,
+                                    int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes,
+                                    void *stream);
+
 /* gridencoder.cu:639-645  grad_total_variation(inputs, embeddings, grad, offsets, weight,
  *       B, D, C, L, S, H, gridtype, align_corners)   — inputs share `dtype` with embeddings. */
 int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad,

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from util import to_np, assert_half_close
+from util import to_np, assert_half_close, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -64,7 +64,7 @@ def test_forward_bit_exact(case, dtype):
     out = torch.empty(L, B, C, dtype=tdt, device="cuda")
     dy = torch.empty(B, L * D * C, dtype=tdt, device="cuda")
     be.grid_encode_forward(xt, tt, ot, out, B, D, C, L, S, H, dy, gridtype, ac, interp)
-    assert np.array_equal(to_np(out), ref), "outputs [L,B,C] not bit-exact"
+    assert_bits_equal(to_np(out), ref, "outputs [L,B,C]")
     got_dy = to_np(dy).reshape(B, L, D, C)
     if dtype == np.float32:
         assert np.array_equal(got_dy, ref_dy)
@@ -83,7 +83,9 @@ def test_forward_bit_exact(case, dtype):
 
 @pytest.mark.parametrize("case", CASES[:5])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
-def test_backward(case, dtype):
+@pytest.mark.parametrize("atomic", ["0", "1"])      # 0: partition + LDS accumulation (D=3,C=2), 1: scattered-atomic kernel
+def test_backward(case, dtype, atomic, monkeypatch):
+    monkeypatch.setenv("FOCNERF_GRID_ATOMIC", atomic)
     D, C, L, H, lh, desired, gridtype, ac, interp = case
     pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, dtype, align_corners=ac)
     B = 4000
@@ -165,7 +167,7 @@ def test_grid_encode_autograd_and_module():
     yh.float().sum().backward()
     assert enc.embeddings.grad.dtype == torch.float32
     refh = oracle.grid_encode_forward(xin, to_np(enc.embeddings).astype(np.float16), to_np(enc.offsets), 3, 2, 16, S, 16)
-    assert np.array_equal(to_np(yh), np.transpose(refh, (1, 0, 2)).reshape(3000, 32))
+    assert_bits_equal(to_np(yh), np.ascontiguousarray(np.transpose(refh, (1, 0, 2)).reshape(3000, 32)), "autocast forward")
 
 
 def test_grad_total_variation():
@@ -198,7 +200,7 @@ def test_full_batch_properties():
         sel = torch.randperm(B, device="cuda")[:4096]
         S = float(np.log2(enc.per_level_scale))
         ref = oracle.grid_encode_forward(((x[sel] + 1) / 2).cpu().numpy(), to_np(enc.embeddings).astype(np.float16), to_np(enc.offsets), 3, 2, 16, S, 16)
-        assert np.array_equal(to_np(y[sel]), np.transpose(ref, (1, 0, 2)).reshape(4096, 32))
+        assert_bits_equal(to_np(y[sel]), np.ascontiguousarray(np.transpose(ref, (1, 0, 2)).reshape(4096, 32)), "full batch subset")
     # linearity in the table (fp32 path): T -> 2T doubles every output exactly (power-of-two scaling)
     y1 = enc(x)
     enc.embeddings.data.mul_(2)

@@ -62,7 +62,7 @@ def test_cuda_ray_training_reduces_loss():
     target = torch.zeros(1, o.shape[1], 3, device="cuda")
     target[..., 0] = 0.8
     losses = []
-    for it in range(30):
+    for it in range(16):
         with torch.autocast("cuda", dtype=torch.float16):
             out = m.render(o, d, staged=False, perturb=True, force_all_rays=False, dt_gamma=1 / 128, max_steps=1024, bg_color=0.0)
             loss = torch.nn.functional.mse_loss(out["image"], target)
@@ -71,11 +71,13 @@ def test_cuda_ray_training_reduces_loss():
         scaler.step(opt)
         scaler.update()
         losses.append(loss.item())
-        if it % 16 == 15:
-            m.update_extra_state()
     assert np.isfinite(losses).all()
-    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), f"loss did not go down: {losses[:5]} -> {losses[-5:]}"
-    assert m.mean_count > 0
+    assert np.mean(losses[-3:]) < 0.7 * np.mean(losses[:3]), f"loss did not go down: {losses[:3]} -> {losses[-3:]}"
+    # density-grid maintenance on top of the ops (morton3D, density query, packbits), inside autocast as the reference trainer runs it
+    with torch.autocast("cuda", dtype=torch.float16):
+        m.update_extra_state()
+    assert m.mean_count > 0 and m.iter_density == 1 and m.local_step == 0
+    assert m.density_bitfield.dtype == torch.uint8 and torch.isfinite(m.density_grid).all()
 
 
 def test_inference_loop_matches_training_composite():

@@ -40,3 +40,22 @@ def assert_half_close(got, want, ulps=2.0, atol=0.0, what=""):
     bad = np.abs(got - want) > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off by more than {ulps} half-ulp (+{atol}); " \
                           f"worst |diff|={np.abs(got - want).max()}"
+
+
+def assert_bits_equal(got, ref, what=""):
+    """Bit-for-bit equality with a useful report (count, worst cases as values and hex)."""
+    got = np.ascontiguousarray(got)
+    ref = np.ascontiguousarray(ref)
+    assert got.shape == ref.shape and got.dtype == ref.dtype, f"{what}: shape/dtype {got.shape}/{got.dtype} vs {ref.shape}/{ref.dtype}"
+    it = {2: np.uint16, 4: np.uint32, 1: np.uint8, 8: np.uint64}[got.dtype.itemsize]
+    gb, rb = got.view(it), ref.view(it)
+    # +0 and -0 are distinct bit patterns but the same value; report them separately
+    bad = gb != rb
+    if not bad.any():
+        return
+    idx = np.argwhere(bad)
+    lines = [f"{what}: {bad.sum()} / {bad.size} elements differ"]
+    for k in idx[:12]:
+        k = tuple(k)
+        lines.append(f"  at {k}: got {got[k]!r} (0x{int(gb[k]):x})  want {ref[k]!r} (0x{int(rb[k]):x})")
+    raise AssertionError("\n".join(lines))
