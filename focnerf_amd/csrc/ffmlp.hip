@@ -27,6 +27,8 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef short s4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s4 lds_s4;
 
 #define MLP_BLOCK 256
 #define MLP_WAVES 4
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
                                                       const _Float16 *__restrict__ fwd_buf, const _Float16 *__restrict__ bwd_buf,
                                                       float *__restrict__ ws, uint32_t B, uint32_t in_dim, uint32_t num_layers) {
     constexpr int LDP = 8;   // row padding (halfs) to spread the strided 2-byte reads over banks
-    __shared__ __attribute__((aligned(16))) _Float16 sD[DW_CHUNK][HIDDEN + LDP];
+    __shared__ __attribute__((aligned(16))) _Float16 sD[DW_CHUNK][(HIDDEN < 32 ? 32 : HIDDEN) + LDP];   // >= 32 columns: transposed reads span a whole 32-row tile
     __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][128 + LDP];
 
     const uint32_t j = blockIdx.y;
@@ -420,14 +422,26 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
             if (tile < n_out_tiles) {
                 const uint32_t mt = tile / NTi, nt = tile % NTi;
                 const uint32_t o = 32 * mt + r, i = 32 * nt + r;
+                // Both operands need 8 consecutive BATCH rows of one neuron column: a transposed read of the
+                // row-major LDS tiles. ds_read_b64_tr_b16 hands lane i of each 16-lane group column i of a
+                // 4-row x 16-column block (lane 4q+p supplies the address of row q, columns 4p..4p+3), so one
+                // fragment is two such reads. All 64 lanes take part (the tile test above is wave-uniform);
+                // lanes whose neuron is past OUT / IN read in-bounds garbage and are zeroed afterwards.
+                const int q = (lane & 15) >> 2, p = lane & 3, cg = 16 * ((lane >> 4) & 1);
 #pragma unroll
                 for (int ks = 0; ks < DW_CHUNK / 16; ks++) {
+                    const int k0 = 16 * ks + 8 * h + q;
+                    const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0][32 * mt + cg + 4 * p]);
+                    const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0 + 4][32 * mt + cg + 4 * p]);
+                    const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0][32 * nt + cg + 4 * p]);
+                    const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0 + 4][32 * nt + cg + 4 * p]);
                     h8 a, b;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int bb = 16 * ks + 8 * h + e;
-                        a[e] = o < OUT ? sD[bb][o] : (_Float16)0;
-                        b[e] = i < IN ? sA[bb][i] : (_Float16)0;
+                    for (int e = 0; e < 4; e++) {
+                        a[e] = o < OUT ? __builtin_bit_cast(_Float16, a0[e]) : (_Float16)0;
+                        a[4 + e] = o < OUT ? __builtin_bit_cast(_Float16, a1[e]) : (_Float16)0;
+                        b[e] = i < IN ? __builtin_bit_cast(_Float16, b0[e]) : (_Float16)0;
+                        b[4 + e] = i < IN ? __builtin_bit_cast(_Float16, b1[e]) : (_Float16)0;
                     }
                     acc[t] = mfma16(a, b, acc[t]);
                 }

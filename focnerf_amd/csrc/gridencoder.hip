@@ -557,22 +557,37 @@ __global__ void __launch_bounds__(512) k_gbin_reduce(const GbHeader *__restrict_
     for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += 512) acc[i] = 0.0f;
     __syncthreads();
     const uint32_t slot = s_slot, lo = s_lo, hi = s_hi;
+    // 8 record loads in flight per lane before the LDS adds (one load per iteration leaves the loop latency-bound)
+    constexpr uint32_t UNR = 8;
     if constexpr (sizeof(T) == 2) {
         const uint2 *rr = reinterpret_cast<const uint2 *>(recs);
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 512) {
-            const uint2 r = rr[i];
-            const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r.y));
-            atomicAdd(&acc[r.x * 2], v.x);
-            atomicAdd(&acc[r.x * 2 + 1], v.y);
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 512 * UNR) {
+            uint2 r[UNR];
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * 512; r[u] = i < hi ? rr[i] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++) {
+                if (i0 + u * 512 < hi) {
+                    const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r[u].y));
+                    atomicAdd(&acc[r[u].x * 2], v.x);
+                    atomicAdd(&acc[r[u].x * 2 + 1], v.y);
+                }
+            }
         }
     } else {
         const uint32_t *rr = reinterpret_cast<const uint32_t *>(recs);
         const float2 *vv = reinterpret_cast<const float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 512) {
-            const uint32_t r = rr[i];
-            const float2 v = vv[i];
-            atomicAdd(&acc[r * 2], v.x);
-            atomicAdd(&acc[r * 2 + 1], v.y);
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 512 * UNR) {
+            uint32_t r[UNR]; float2 v[UNR];
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * 512; const bool ok = i < hi; r[u] = ok ? rr[i] : 0u; v[u] = ok ? vv[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++) {
+                if (i0 + u * 512 < hi) {
+                    atomicAdd(&acc[r[u] * 2], v[u].x);
+                    atomicAdd(&acc[r[u] * 2 + 1], v[u].y);
+                }
+            }
         }
     }
     __syncthreads();
