@@ -29,6 +29,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef short s4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s4 lds_s4;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define MLP_BLOCK 256
 #define MLP_WAVES 4
@@ -435,15 +437,14 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
                     const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0 + 4][32 * mt + cg + 4 * p]);
                     const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0][32 * nt + cg + 4 * p]);
                     const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0 + 4][32 * nt + cg + 4 * p]);
-                    h8 a, b;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        a[e] = o < OUT ? __builtin_bit_cast(_Float16, a0[e]) : (_Float16)0;
-                        a[4 + e] = o < OUT ? __builtin_bit_cast(_Float16, a1[e]) : (_Float16)0;
-                        b[e] = i < IN ? __builtin_bit_cast(_Float16, b0[e]) : (_Float16)0;
-                        b[4 + e] = i < IN ? __builtin_bit_cast(_Float16, b1[e]) : (_Float16)0;
-                    }
-                    acc[t] = mfma16(a, b, acc[t]);
+                    // assemble the fragments at dword granularity (hipcc 7.2 mis-folds per-element extracts of the
+                    // builtin's v4i16 result: it reuses element 0 for every lane element)
+                    const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
+                    const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
+                    u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
+                    if (!(o < OUT)) av = u32x4{0u, 0u, 0u, 0u};
+                    if (!(i < IN)) bv = u32x4{0u, 0u, 0u, 0u};
+                    acc[t] = mfma16(__builtin_bit_cast(h8, av), __builtin_bit_cast(h8, bv), acc[t]);
                 }
             }
         }

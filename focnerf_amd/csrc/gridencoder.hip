@@ -362,10 +362,10 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
 //   3 scatter  recompute the rows, rank each record inside its segment with an LDS returning
 //              atomic, reserve the workgroup's range per segment with ONE global returning atomic,
 //              write {local row, w*grad} records (8 B for fp16, 4+8 B for fp32) with plain stores;
-//   4 reduce   one workgroup per (segment, chunk of <= 65536 records): accumulate in a 64 KiB fp32
-//              LDS image with ds_add_f32, then add the image to the gradient table with
+//   4 reduce   one workgroup per (segment, chunk of <= 65536 records): accumulate in a 128 KiB f64
+//              LDS image with ds_add_f64, then add the image to the gradient table with
 //              CONTIGUOUS atomics (256 B per wave instruction: the full-rate shape).
-// Sums are fp32 in LDS and rounded to the table dtype once per chunk — more accurate than the
+// Sums are f64 in LDS and rounded to the table dtype once per chunk — more accurate than the
 // reference's half2 atomicAdd per addend (gridencoder.cu:325-331). C = 2, D = 3 (the NeRF tables).
 #define GB_SEG_SHIFT 13u
 #define GB_SEG (1u << GB_SEG_SHIFT)            // rows per segment
@@ -534,58 +534,60 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter(const T *__restrict__ gr
     }
 }
 
+// LDS accumulation is done in DOUBLE: on gfx950 ds_add_f32 on random addresses runs ~23x slower than
+// ds_add_u32 (measured 101 vs 2349 G records/s, tools/bench_lds_atomic.hip) while ds_add_f64 runs at
+// 1823 G/s — so the fp32-quality sum is kept in a 128 KiB f64 image (one workgroup per CU).
+#define GB_RTHREADS 1024u
 template <typename T>
-__global__ void __launch_bounds__(512) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
-                                                     const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
-    __shared__ float acc[GB_SEG * 2];              // 64 KiB
+__global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
+                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
+    __shared__ double acc[GB_SEG * 2];             // 128 KiB
     __shared__ uint32_t s_slot, s_lo, s_hi;
     const uint32_t n = L * GB_MAX_SEGS;
     const uint32_t total_chunks = hdr->chunk_prefix[n];
     if (blockIdx.x >= total_chunks) return;
     if (threadIdx.x == 0) {
-        // largest slot with chunk_prefix[slot] <= blockIdx.x  (binary search over <= 2049 entries)
+        // largest slot with chunk_prefix[slot] <= blockIdx.x  (binary search over <= 2049 entries; empty slots share a prefix value
+        // with the next non-empty one, and the largest index wins, which is the non-empty slot)
         uint32_t lo = 0, hi = n;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hdr->chunk_prefix[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-        // skip empty slots that share the same prefix value
-        while (lo + 1 < n && hdr->chunk_prefix[lo + 1] <= blockIdx.x) lo++;
         const uint32_t c = blockIdx.x - hdr->chunk_prefix[lo];
         const uint32_t cnt = hdr->counts[lo];
         s_slot = lo;
         s_lo = hdr->base[lo] + c * GB_CHUNK;
         s_hi = hdr->base[lo] + min(cnt, (c + 1) * GB_CHUNK);
     }
-    for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += 512) acc[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += GB_RTHREADS) acc[i] = 0.0;
     __syncthreads();
     const uint32_t slot = s_slot, lo = s_lo, hi = s_hi;
-    // 8 record loads in flight per lane before the LDS adds (one load per iteration leaves the loop latency-bound)
-    constexpr uint32_t UNR = 8;
+    constexpr uint32_t UNR = 4;                     // record loads in flight per lane before the LDS adds
     if constexpr (sizeof(T) == 2) {
         const uint2 *rr = reinterpret_cast<const uint2 *>(recs);
-        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 512 * UNR) {
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += GB_RTHREADS * UNR) {
             uint2 r[UNR];
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * 512; r[u] = i < hi ? rr[i] : make_uint2(0u, 0u); }
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; r[u] = i < hi ? rr[i] : make_uint2(0u, 0u); }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
-                if (i0 + u * 512 < hi) {
+                if (i0 + u * GB_RTHREADS < hi) {
                     const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&r[u].y));
-                    atomicAdd(&acc[r[u].x * 2], v.x);
-                    atomicAdd(&acc[r[u].x * 2 + 1], v.y);
+                    atomicAdd(&acc[r[u].x * 2], (double)v.x);
+                    atomicAdd(&acc[r[u].x * 2 + 1], (double)v.y);
                 }
             }
         }
     } else {
         const uint32_t *rr = reinterpret_cast<const uint32_t *>(recs);
         const float2 *vv = reinterpret_cast<const float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 512 * UNR) {
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += GB_RTHREADS * UNR) {
             uint32_t r[UNR]; float2 v[UNR];
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * 512; const bool ok = i < hi; r[u] = ok ? rr[i] : 0u; v[u] = ok ? vv[i] : make_float2(0.f, 0.f); }
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; r[u] = ok ? rr[i] : 0u; v[u] = ok ? vv[i] : make_float2(0.f, 0.f); }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
-                if (i0 + u * 512 < hi) {
-                    atomicAdd(&acc[r[u] * 2], v[u].x);
-                    atomicAdd(&acc[r[u] * 2 + 1], v[u].y);
+                if (i0 + u * GB_RTHREADS < hi) {
+                    atomicAdd(&acc[r[u] * 2], (double)v[u].x);
+                    atomicAdd(&acc[r[u] * 2 + 1], (double)v[u].y);
                 }
             }
         }
@@ -599,15 +601,15 @@ __global__ void __launch_bounds__(512) k_gbin_reduce(const GbHeader *__restrict_
     const uint32_t nrows = hashmap_size > row0 ? min(GB_SEG, hashmap_size - row0) : 0u;
     if constexpr (sizeof(T) == 2) {
         typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
-        for (uint32_t r = threadIdx.x; r < nrows; r += 512) {
-            const float a = acc[2 * r], b = acc[2 * r + 1];
+        for (uint32_t r = threadIdx.x; r < nrows; r += GB_RTHREADS) {
+            const float a = (float)acc[2 * r], b = (float)acc[2 * r + 1];
             if (a == 0.0f && b == 0.0f) continue;
             v2h hv; hv[0] = (_Float16)ge_opaque(a); hv[1] = (_Float16)ge_opaque(b);
             (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) v2h *)(dst + 2 * r), hv);
         }
     } else {
-        for (uint32_t e = threadIdx.x; e < nrows * 2; e += 512) {
-            const float a = acc[e];
+        for (uint32_t e = threadIdx.x; e < nrows * 2; e += GB_RTHREADS) {
+            const float a = (float)acc[e];
             if (a != 0.0f) (void)__hip_atomic_fetch_add(dst + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -836,7 +838,7 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     else hipLaunchKernelGGL((k_gbin_scatter<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
     FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;
-    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(512), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
+    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
     FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return FOC_OK;
 }
