@@ -148,8 +148,9 @@ __device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds,
 // lane (c, h) owns sample `row0 + c` and, per register quad q, the 4 consecutive neurons
 // col0 + 8q + 4h .. +3  -> one 8-byte store per quad.
 template <bool RELU>
-__device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint32_t col0, uint32_t ncols,
+__device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint64_t nrows, uint32_t col0, uint32_t ncols,
                                            const f16v &acc, int h) {
+    if (row >= nrows) return;          // ragged last tile: rows past B are computed on clamped inputs and dropped
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t col = col0 + 8 * q + 4 * h;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restric
     const uint32_t KS0 = in_dim / 16;
     const uint32_t f_hidden = MT * KS0, f_out = f_hidden + (num_layers - 1) * MT * KC;
     const uint32_t tile_rows = 32 * NB;
-    const uint32_t n_tiles = B / tile_rows;
+    const uint32_t n_tiles = (B + tile_rows - 1) / tile_rows;
 
     for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
         const uint64_t row0 = (uint64_t)tile * tile_rows;
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restric
             h8 b[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
-                b[nb] = *reinterpret_cast<const h8 *>(inputs + (row0 + nb * 32 + c) * in_dim + 16 * kc + 8 * h);
+                b[nb] = *reinterpret_cast<const h8 *>(inputs + min(row0 + nb * 32 + c, (uint64_t)B - 1) * in_dim + 16 * kc + 8 * h);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
@@ -215,8 +216,8 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restric
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        if (relu) store_tile<true>(fb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
-                        else store_tile<false>(fb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
+                        if (relu) store_tile<true>(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
+                        else store_tile<false>(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
                     }
             }
             h8 bf[KC][NB];
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restric
                     for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
                 }
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) store_tile<false>(outputs, 16, row0 + nb * 32 + c, 0, 16, o[nb], h);
+                for (int nb = 0; nb < NB; nb++) store_tile<false>(outputs, 16, row0 + nb * 32 + c, B, 0, 16, o[nb], h);
             }
         }
     }
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (num_layers - 1) * MT * KC;
     const uint32_t tile_rows = 32 * NB;
-    const uint32_t n_tiles = B / tile_rows;
+    const uint32_t n_tiles = (B + tile_rows - 1) / tile_rows;
 
     for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
         const uint64_t row0 = (uint64_t)tile * tile_rows;
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
         {
             h8 bg[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) bg[nb] = *reinterpret_cast<const h8 *>(grad + (row0 + nb * 32 + c) * 16 + 8 * h);
+            for (int nb = 0; nb < NB; nb++) bg[nb] = *reinterpret_cast<const h8 *>(grad + min(row0 + nb * 32 + c, (uint64_t)B - 1) * 16 + 8 * h);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const h8 a = ld_frag(lds, mt, lane);
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
                         for (int q = 0; q < 4; q++) {
                             const uint32_t col = 32 * mt + 8 * q + 4 * h;
                             if (col < HIDDEN) {
-                                const h4 f = *reinterpret_cast<const h4 *>(fb + (row0 + nb * 32 + c) * HIDDEN + col);
+                                const h4 f = *reinterpret_cast<const h4 *>(fb + min(row0 + nb * 32 + c, (uint64_t)B - 1) * HIDDEN + col);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) if (!(f[e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
                             }
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) store_tile<false>(bb, HIDDEN, row0 + nb * 32 + c, 32 * mt, HIDDEN, acc[mt][nb], h);
+                    for (int nb = 0; nb < NB; nb++) store_tile<false>(bb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
             }
             if (fl == 0 && !with_dx) break;
             h8 bf[KC][NB];
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
                         for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], x[nb]);
                     }
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, 32 * mt0, in_dim, x[nb], h);
+                    for (int nb = 0; nb < NB; nb++) store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
                 }
             }
         }
@@ -404,18 +405,22 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[t][e] = 0.0f;
 
-    const uint32_t n_chunks = B / DW_CHUNK;
+    const uint32_t n_chunks = (B + DW_CHUNK - 1) / DW_CHUNK;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint64_t row0 = (uint64_t)chunk * DW_CHUNK;
         __syncthreads();
         // stage D [64 x OUT] and A [64 x IN], 8 halfs per thread-iteration
         for (uint32_t idx = threadIdx.x; idx < DW_CHUNK * (OUT / 8); idx += MLP_BLOCK) {
             const uint32_t rr = idx / (OUT / 8), cc = (idx % (OUT / 8)) * 8;
-            *reinterpret_cast<h8 *>(&sD[rr][cc]) = *reinterpret_cast<const h8 *>(Dp + (row0 + rr) * OUT + cc);
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};                       // rows past B contribute nothing
+            if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(Dp + (row0 + rr) * OUT + cc);
+            *reinterpret_cast<h8 *>(&sD[rr][cc]) = v;
         }
         for (uint32_t idx = threadIdx.x; idx < DW_CHUNK * (IN / 8); idx += MLP_BLOCK) {
             const uint32_t rr = idx / (IN / 8), cc = (idx % (IN / 8)) * 8;
-            *reinterpret_cast<h8 *>(&sA[rr][cc]) = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
+            *reinterpret_cast<h8 *>(&sA[rr][cc]) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -488,7 +493,6 @@ static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t o
     FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 128, FOC_E_INVALID, "%s: input_dim must be 16*m, m in [1,8] (got %u)", who, input_dim);
     FOC_REQUIRE(output_dim <= 16, FOC_E_INVALID, "%s: output_dim must be <= 16 (got %u)", who, output_dim);
     FOC_REQUIRE(num_layers >= 2 && num_layers <= 16, FOC_E_INVALID, "%s: num_layers must be in [2,16] (got %u)", who, num_layers);
-    FOC_REQUIRE(B % 128 == 0, FOC_E_INVALID, "%s: B must be a multiple of 128 (got %u)", who, B);
     FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "%s: hidden activation must be relu(0) or none(6) (got %u)", who, activation);
     FOC_REQUIRE(output_activation == 6, FOC_E_INVALID, "%s: output activation must be none(6) (got %u)", who, output_activation);
     return FOC_OK;
@@ -513,7 +517,7 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     auto kern = k_mlp_fwd<HIDDEN, NB, TRAIN>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const uint32_t n_tiles = B / (32 * NB);
+    const uint32_t n_tiles = foc_div_up(B, 32 * NB);
     uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
@@ -551,7 +555,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     auto kern = k_mlp_bwd<HIDDEN, NB>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const uint32_t n_tiles = B / (32 * NB);
+    const uint32_t n_tiles = foc_div_up(B, 32 * NB);
     uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
@@ -561,7 +565,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     // weight gradients
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
     if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
-    uint32_t gx = B / DW_CHUNK;
+    uint32_t gx = foc_div_up(B, DW_CHUNK);
     const uint32_t capx = foc_div_up(mlp_num_cus() * 2, num_layers + 1);
     if (gx > capx) gx = capx;
     if (gx < 1) gx = 1;

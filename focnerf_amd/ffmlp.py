@@ -3,8 +3,8 @@
 
 Notes on behaviour kept from the reference:
   * the weight blob layout and the seed-42 U(+-sqrt(3/hidden)) init (ffmlp.py:120-144);
-  * FFMLP.forward pads the batch with `128 - B % 128` zero rows, i.e. a full extra block when
-    B is already a multiple of 128 (ffmlp.py:157-159) — results for the first B rows are unaffected.
+  * the reference's FFMLP.forward pads the batch with `128 - B % 128` zero rows (ffmlp.py:157-159); results
+    for the first B rows do not depend on that padding, and the kernels here accept any B, so no pad copy is made.
 The stray `from turtle import ...` of ffmlp.py:2 is not reproduced.
 """
 import math
@@ -101,9 +101,9 @@ class FFMLP(nn.Module):
 
     def forward(self, inputs):
         B, C = inputs.shape
-        pad = 128 - (B % 128)
-        if pad > 0:
-            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
+        # The reference pads the batch to a multiple of 128 with a full copy (ffmlp.py:157-159, and a whole extra block
+        # when B is already aligned); the kernels here handle the ragged last tile themselves, so the rows the caller
+        # sees are identical and the 2 x B x C bytes of copy traffic per call are gone.
         outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
                                 self.activation, self.output_activation, not self.training, inputs.requires_grad)
         if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:

@@ -208,7 +208,8 @@ int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B
  * weights: one fp16 blob [hidden*input_dim | (num_layers-1)*hidden*hidden | 16*hidden],
  * each block row-major with the OUTPUT neuron as the row (ffmlp.cu:631-634).
  * inputs [B,input_dim], outputs [B,16] (output_dim is the padded 16), row-major.
- * B must be a multiple of 128 (the reference wrapper pads, ffmlp/ffmlp.py:157-159);
+ * Any B >= 1 is accepted (the reference kernels need a multiple of 128 and its wrapper pads with a copy,
+ * ffmlp/ffmlp.py:157-159; here the ragged last tile is handled in the kernels, so no padded copy is needed);
  * hidden_dim in {16,32,64,128}; input_dim % 16 == 0; output_dim <= 16; num_layers >= 2.
  * activation codes follow ffmlp.py:86-93 (0 = relu ... 6 = none); hidden activation
  * relu|none, output activation none (the only combinations FFMLP can construct,

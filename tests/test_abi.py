@@ -47,8 +47,8 @@ def test_argument_validation_needs_no_gpu():
     assert rc == 1 and b"C must be 1, 2, 4, or 8" in lib.foc_last_error()
     rc = lib.foc_ffmlp_forward(one, one, 128, 32, 16, 48, 2, 0, 6, one, one, None)
     assert rc == 1 and b"hidden_dim" in lib.foc_last_error()
-    rc = lib.foc_ffmlp_forward(one, one, 100, 32, 16, 64, 2, 0, 6, one, one, None)
-    assert rc == 1 and b"multiple of 128" in lib.foc_last_error()
+    rc = lib.foc_ffmlp_forward(one, one, 128, 24, 16, 64, 2, 0, 6, one, one, None)
+    assert rc == 1 and b"input_dim" in lib.foc_last_error()
     rc = lib.foc_freq_encode_forward(one, 4, 3, 4, 26, one, None)
     assert rc == 1
 

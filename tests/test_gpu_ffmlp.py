@@ -195,3 +195,31 @@ def test_full_batch_rows_are_independent():
     assert torch.equal(gi_full[: B // 2], gi_a) and torch.equal(gi_full[B // 2:], gi_b)
     scale = gw_full.abs().max()
     assert (gw_full - (gw_a + gw_b)).abs().max() <= 4e-3 * scale + 1e-3
+
+
+@pytest.mark.parametrize("B", [1, 63, 65, 333])
+def test_ragged_batch_matches_oracle(B):
+    """Batches that are not a multiple of the 64-row tile: the last tile is computed on clamped rows and never stored;
+    weight gradients must not see the phantom rows."""
+    be = _be()
+    rng = np.random.default_rng(B)
+    I, Hd, nl = 32, 64, 3
+    W = (rng.uniform(-1, 1, _n_params(I, Hd, nl)) * math.sqrt(3 / Hd)).astype(np.float16)
+    x = rng.standard_normal((B, I)).astype(np.float16)
+    g = (rng.standard_normal((B, 16)) * 0.05).astype(np.float16)
+    out, fb = _run_forward(x, W, I, Hd, nl, 0, True)
+    ref_out, ref_fb = oracle.ffmlp_forward(x, W, I, Hd, nl, 0)
+    assert_half_close(out, ref_out, ulps=8, atol=4e-3, what="outputs")
+    assert_half_close(fb, ref_fb, ulps=6, atol=2e-3, what="forward_buffer")
+    gw_r, gi_r, bb_r = oracle.ffmlp_backward(g, x, W, fb, I, Hd, nl, 0, True)
+    t = lambda a: torch.from_numpy(a).cuda()
+    # guard regions after every buffer: nothing may be written past row B
+    bb = torch.full((nl, B + 64, Hd), 7.0, dtype=torch.float16, device="cuda")
+    gi = torch.full((B + 64, I), 7.0, dtype=torch.float16, device="cuda")
+    gw = torch.empty(W.size, dtype=torch.float16, device="cuda")
+    bbv = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+    be.ffmlp_backward(t(g), t(x), t(W), t(fb), B, I, 16, Hd, nl, 0, 6, True, bbv, gi[:B], gw)
+    assert torch.all(gi[B:] == 7.0), "grad_inputs written past row B"
+    assert_half_close(to_np(bbv), bb_r, ulps=6, atol=2e-4, what="backward_buffer")
+    assert_half_close(to_np(gi[:B]), gi_r, ulps=8, atol=5e-4, what="grad_inputs")
+    assert_half_close(to_np(gw), gw_r, ulps=4.0, atol=2e-3, what="grad_weights")
