@@ -40,6 +40,31 @@ ALGO_BYTES = {
 }
 
 
+# C-ABI op -> the HIP kernels it launches (names as rocprofv3 prints them)
+OP_KERNELS = {
+    "grid_encode_backward": ["k_gbin_count", "k_gbin_scan", "k_gbin_scatter", "k_gbin_reduce"],
+    "grid_encode_forward": ["k_grid_fwd_bl"],
+    "ffmlp_forward": ["k_mlp_fwd"],
+    "ffmlp_inference": ["k_mlp_fwd"],
+    "ffmlp_backward": ["k_mlp_bwd", "k_mlp_dw", "k_mlp_dw_finalize"],
+}
+
+
+def pmc_traffic_bytes(op):
+    """HBM bytes per launch of `op` from the newest committed PMC summary (collected in separate rocprofv3 --pmc passes), or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_hbm.csv")))
+    if not files:
+        return None
+    total, found = 0.0, False
+    for row in csv.DictReader(open(files[-1])):
+        if any(k in row["kernel"] for k in OP_KERNELS.get(op, [])):
+            total += float(row["hbm_bytes_per_launch"])
+            found = True
+    return total if found else None
+
+
 def mlp_bytes_per_row(input_dim, hidden, num_layers, train, backward=False):
     # forward (train): read input, write every hidden activation, write 16 outputs   (fp16)
     fwd = 2 * input_dim + (2 * hidden * num_layers if train else 0) + 32
@@ -272,8 +297,11 @@ def main():
         else:
             bytes_per_unit = 0.5 * (mlp_bytes_per_row(32, 64, 2, True, True) + mlp_bytes_per_row(32, 64, 3, True, True))
         achieved = bytes_per_unit * units / (r["avg_ms"] * 1e-3) / 1e9
-        result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": None, "avg_launch_ms": r["avg_ms"], "units_per_launch": units, "algorithmic_bytes_per_unit": bytes_per_unit}
+        result["roofline"] = {"kernel": f"{dom} = {'+'.join(OP_KERNELS.get(dom, [dom]))}", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom), "avg_launch_ms": r["avg_ms"],
+                              "units_per_launch": units, "algorithmic_bytes_per_unit": bytes_per_unit,
+                              "note": "timed with events on the launch stream around the C-ABI call (all kernels of the op); traffic = HBM bytes per "
+                                      "launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/*_pmc_hbm.csv"}
         result["kernels"] = {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "share_of_step": round(v["total_ms"] / (1000.0 * el), 4)}
                              for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])}
 
