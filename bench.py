@@ -153,9 +153,9 @@ def sample_batch(poses, intr, device, gen):
     return rays_o, rays_d, target
 
 
-def train_step(model, opt, scaler, rays_o, rays_d, target):
+def train_step(model, opt, scaler, rays_o, rays_d, target, fused=True):
     with torch.autocast("cuda", dtype=torch.float16):
-        out = model.render(rays_o, rays_d, staged=False, num_steps=NUM_STEPS, upsample_steps=0, perturb=True, bg_color=None)
+        out = model.render(rays_o, rays_d, staged=False, num_steps=NUM_STEPS, upsample_steps=0, perturb=True, bg_color=None, fused=fused)
         loss = torch.nn.functional.mse_loss(out["image"], target)
     opt.zero_grad(set_to_none=True)
     scaler.scale(loss).backward()
@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--render-views", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the render / occupancy-path extras")
+    ap.add_argument("--no-fused", action="store_true", help="headline step through the torch glue of NeRFRenderer.run instead of csrc/fixedstep.hip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,13 +262,14 @@ def main():
     timer = KernelTimer()
     timer.install()
 
+    fused = not args.no_fused
     for i in range(args.warmup):
-        train_step(model, opt, scaler, *batches[i % len(batches)])
+        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused)
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        train_step(model, opt, scaler, *batches[i % len(batches)])
+        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused)
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
     timer.enabled = False
@@ -281,7 +283,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: single-object hash-grid(L16,C2,2^19)+ffmlp fp16 NeRF, rays from synthetic 800x800 views, "
                                "fixed-step renderer num_steps=512", "rays_per_step": NUM_RAYS, "samples_per_step": samples_per_step,
-                   "objects": world, "parallelism": f"one object per GPU x{world}", "optimizer": "Adam(fused) inside the timed step"},
+                   "objects": world, "parallelism": f"one object per GPU x{world}", "optimizer": "Adam(fused) inside the timed step",
+                   "render_glue": "csrc/fixedstep.hip (fused density head + composite)" if fused else "torch ops of NeRFRenderer.run"},
     }
 
     # ---- roofline of the dominant kernel of the timed region
@@ -306,16 +309,29 @@ def main():
                              for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])}
 
     if not args.no_extras:
+        # ---- the same step through the reference caller's torch glue (NeRFRenderer.run) instead of the fused kernels
+        if fused:
+            for i in range(3):
+                train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+            barrier()
+            t0 = time.perf_counter()
+            nu = max(5, args.steps // 2)
+            for i in range(nu):
+                train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+            barrier()
+            elu = max_over_ranks(time.perf_counter() - t0)
+            result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
+                                         "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
         # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
         from focnerf_amd import synthetic
         model.eval()
         rays_o, rays_d = synthetic.get_rays(poses[:1], intr, VIEW, VIEW)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            model.render(rays_o[:, :8192], rays_d[:, :8192], staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False)
+            model.render(rays_o[:, :8192], rays_d[:, :8192], staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.render_views):
-                model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False)
+                model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
             barrier()
         rel = max_over_ranks(time.perf_counter() - t0)
         result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",

@@ -1,0 +1,314 @@
+// fixedstep.hip — FOC's default render path (fixed num_steps per ray, no occupancy grid) as fused ops.
+//
+// Reference: the torch code of nerf/renderer.py:145-221 (identical in COMBINED.py:451-534), plus the
+// glue of nerf/network_ff.py:51-134 that sits between the encoder and the two MLPs:
+//     z = near + (far-near)*linspace(0,1,T) [+ (rand-0.5)*(far-near)/T]; xyz = clip(o + d z, aabb)
+//     sigma = trunc_exp(h[:,0]); alpha = 1 - exp(-delta*density_scale*sigma)
+//     weights = alpha * cumprod([1, 1-alpha+1e-15])[:-1]
+//     colour input = [SH16(dir) | h[:,1:16] | 0]; rgb = sigmoid(colour_net(.)) where weights > thresh, else 0
+//     image = sum w rgb + (1 - sum w) bg ; depth = sum w clamp((z-near)/(far-near),0,1)
+// In the reference these are ~60 small torch kernels per step (≈35 % of the measured step once the
+// encoder and MLP kernels are native). Here: one sample-generation kernel, and ONE WAVE PER RAY kernels for
+// the density head (sigma, weights by a DPP product-scan, colour-net input rows) and for the composite,
+// forward and backward. The colour network is evaluated densely and masked (same values as the reference's
+// gather -> MLP -> scatter, without the nonzero/index round trips).
+// SURVEY.md §8(f)-3; these entry points have no reference binding.
+#include "common.h"
+#include <float.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct FsGeom { float near, far, span, sample_dist, step; };
+
+__device__ __forceinline__ FsGeom fs_geom(const float *__restrict__ nears, const float *__restrict__ fars, uint32_t n, uint32_t T) {
+    FsGeom g;
+    g.near = nears[n]; g.far = fars[n];
+    g.span = g.far - g.near;
+    g.sample_dist = g.span / (float)T;
+    g.step = 1.0f / (float)(T - 1);
+    return g;
+}
+// torch.linspace(0, 1, T) as torch fills it (symmetric halves), then z = near + span * lin [+ (u - 0.5) * sample_dist]
+__device__ __forceinline__ float fs_z(const FsGeom &g, uint32_t i, uint32_t T, const float *__restrict__ noise, uint64_t s) {
+    const float lin = (i < T / 2) ? (g.step * (float)i) : (1.0f - g.step * (float)(T - 1 - i));
+    float z = g.near + g.span * lin;
+    if (noise) z = z + (noise[s] - 0.5f) * g.sample_dist;
+    return z;
+}
+
+// degree-4 real spherical harmonics (focnerf_amd/shencoder.py), same expressions in fp32
+__device__ __forceinline__ void fs_sh16(float x, float y, float z, float (&o)[16]) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// ---------------------------------------------------------------- sample generation
+__global__ void __launch_bounds__(256) k_fs_sample(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
+                                                   const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
+                                                   uint32_t N, uint32_t T, float bound, float *__restrict__ xyzs, float *__restrict__ enc_in) {
+    const uint64_t total = (uint64_t)N * T;
+    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    const float two_b = 2 * bound;
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (uint64_t)gridDim.x * 256) {
+        const uint32_t n = (uint32_t)(s / T), i = (uint32_t)(s - (uint64_t)n * T);
+        const FsGeom g = fs_geom(nears, fars, n, T);
+        const float z = fs_z(g, i, T, noise, s);
+        // torch: rays_o + rays_d * z (two kernels, two roundings), then min(max(., aabb_lo), aabb_hi)
+        float x = rays_o[n * 3] + rays_d[n * 3] * z, y = rays_o[n * 3 + 1] + rays_d[n * 3 + 1] * z, w = rays_o[n * 3 + 2] + rays_d[n * 3 + 2] * z;
+        x = fminf(fmaxf(x, a0), a3); y = fminf(fmaxf(y, a1), a4); w = fminf(fmaxf(w, a2), a5);
+        if (xyzs) { xyzs[s * 3] = x; xyzs[s * 3 + 1] = y; xyzs[s * 3 + 2] = w; }
+        if (enc_in) { enc_in[s * 3] = (x + bound) / two_b; enc_in[s * 3 + 1] = (y + bound) / two_b; enc_in[s * 3 + 2] = (w + bound) / two_b; }
+    }
+}
+
+// ---------------------------------------------------------------- density head, forward (one wave per ray)
+// h [M,16] fp16 (sigma-net output); outputs sigma [M], trans [M] (transmittance BEFORE each sample), weights [M],
+// weights_sum [N], depth [N], colour-net input rows cin [M,32] fp16 (may be null).
+__global__ void __launch_bounds__(256) k_fs_head_fwd(const _Float16 *__restrict__ h, const float *__restrict__ rays_d, const float *__restrict__ nears,
+                                                     const float *__restrict__ fars, const float *__restrict__ noise, uint32_t N, uint32_t T,
+                                                     float density_scale, float *__restrict__ sigma_out, float *__restrict__ trans_out,
+                                                     float *__restrict__ weights_out, float *__restrict__ weights_sum, float *__restrict__ depth,
+                                                     _Float16 *__restrict__ cin) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const FsGeom g = fs_geom(nears, fars, n, T);
+    h8 shlo, shhi;
+    if (cin) {
+        float sh[16];
+        fs_sh16(rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], sh);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { shlo[k] = (_Float16)sh[k]; shhi[k] = (_Float16)sh[8 + k]; }
+    }
+    float Tc = 1.0f, ws = 0, dp = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < T;
+        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const h8 r0 = *reinterpret_cast<const h8 *>(h + s * 16), r1 = *reinterpret_cast<const h8 *>(h + s * 16 + 8);
+        const float sigma = expf((float)r0[0]);                                  // trunc_exp forward (activation.py:9)
+        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float delta = g.sample_dist;
+        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
+        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float Tb = Tc * Pex;
+        const float w = alpha * Tb;
+        if (valid) {
+            sigma_out[s] = sigma; trans_out[s] = Tb; weights_out[s] = w;
+            float oz = (z - g.near) / g.span;
+            oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);                       // keeps NaN (0/0 on rays that miss the box), like torch.clamp
+            ws += w; dp += w * oz;
+            if (cin) {
+                h8 c2, c3;
+#pragma unroll
+                for (int k = 0; k < 7; k++) { c2[k] = r0[k + 1]; c3[k] = r1[k + 1]; }
+                c2[7] = r1[0]; c3[7] = (_Float16)0;
+                h8 *dst = reinterpret_cast<h8 *>(cin + s * 32);
+                dst[0] = shlo; dst[1] = shhi; dst[2] = c2; dst[3] = c3;
+            }
+        }
+        Tc *= __shfl(P, 63, 64);
+    }
+    ws = wave_sum(ws); dp = wave_sum(dp);
+    if (lane == 0) { weights_sum[n] = ws; depth[n] = dp; }
+}
+
+// reverse (suffix) inclusive sum across the wave
+__device__ __forceinline__ float wave_suffix_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += u;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- density head, backward
+// grad_w [M] (from the composite), grad_ws [N], grad_depth [N] (either may be null), grad_cin [M,32] fp16 (may be null)
+// -> grad_h [M,16] fp16: column 0 through weights -> alpha -> sigma -> trunc_exp, columns 1..15 = grad_cin[:,16:31].
+__global__ void __launch_bounds__(256) k_fs_head_bwd(const _Float16 *__restrict__ h, const float *__restrict__ sigma_in, const float *__restrict__ trans_in,
+                                                     const float *__restrict__ nears, const float *__restrict__ fars, const float *__restrict__ noise,
+                                                     const float *__restrict__ grad_w, const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
+                                                     const _Float16 *__restrict__ grad_cin, uint32_t N, uint32_t T, float density_scale,
+                                                     _Float16 *__restrict__ grad_h) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const FsGeom g = fs_geom(nears, fars, n, T);
+    const float gws = grad_ws ? grad_ws[n] : 0.0f, gdp = grad_depth ? grad_depth[n] : 0.0f;
+    float S_carry = 0.0f;                      // sum over samples AFTER the current chunk of g_j * w_j
+    const uint32_t n_chunks = (T + 63) / 64;
+    for (uint32_t cidx = n_chunks; cidx-- > 0;) {
+        const uint32_t i = cidx * 64 + lane;
+        const bool valid = i < T;
+        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const float sigma = sigma_in[s], Tb = trans_in[s];
+        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float delta = g.sample_dist;
+        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        const float ex = expf((-delta * density_scale) * sigma);            // 1 - alpha
+        const float alpha = 1 - ex;
+        const float om = 1 - alpha + 1e-15f;
+        float oz = (z - g.near) / g.span;
+        oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
+        float gi = (grad_w ? grad_w[s] : 0.0f) + gws;
+        if (gdp != 0.0f) gi += gdp * oz;
+        const float gw_i = valid ? gi * (alpha * Tb) : 0.0f;                // g_i * w_i
+        const float incl = wave_suffix_incl_sum(gw_i, (int)lane);
+        const float S_i = S_carry + (incl - gw_i);                          // strictly after i
+        const float dalpha = gi * Tb - S_i / om;
+        const float dsigma = dalpha * (delta * density_scale) * ex;
+        const _Float16 h0 = h[s * 16];
+        const float dh0 = dsigma * expf(fminf(fmaxf((float)h0, -15.0f), 15.0f));   // trunc_exp backward (activation.py:15)
+        if (valid) {
+            h8 o0, o1;
+            if (grad_cin) {
+                const h8 c2 = *reinterpret_cast<const h8 *>(grad_cin + s * 32 + 16), c3 = *reinterpret_cast<const h8 *>(grad_cin + s * 32 + 24);
+#pragma unroll
+                for (int k = 0; k < 7; k++) { o0[k + 1] = c2[k]; o1[k + 1] = c3[k]; }
+                o1[0] = c2[7];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
+            }
+            o0[0] = (_Float16)dh0;
+            h8 *dst = reinterpret_cast<h8 *>(grad_h + s * 16);
+            dst[0] = o0; dst[1] = o1;
+        }
+        S_carry += __shfl(incl, 0, 64);
+    }
+}
+
+// ---------------------------------------------------------------- composite, forward / backward
+// c [M,16] fp16 (colour-net output, rgb logits in columns 0..2), weights [M]; bg: per-ray [N,3] or scalar.
+__device__ __forceinline__ float fs_sigmoid_h(float x) {
+    // the reference applies torch.sigmoid to the HALF tensor (network_ff.py:117): fp32 math, one rounding to fp16
+    return (float)(_Float16)(1.0f / (1.0f + expf(-x)));
+}
+
+__global__ void __launch_bounds__(256) k_fs_composite_fwd(const _Float16 *__restrict__ c, const float *__restrict__ weights, const float *__restrict__ bg_ray,
+                                                          float bg_scalar, uint32_t N, uint32_t T, float thresh, float *__restrict__ image) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float r = 0, g = 0, b = 0, ws = 0;
+    for (uint32_t i = lane; i < T; i += 64) {
+        const uint64_t s = (uint64_t)n * T + i;
+        const float w = weights[s];
+        ws += w;
+        if (w > thresh) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+            const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
+            r += w * fs_sigmoid_h((float)cc[0]); g += w * fs_sigmoid_h((float)cc[1]); b += w * fs_sigmoid_h((float)cc[2]);
+        }
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws);
+    if (lane == 0) {
+        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+        image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = g + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fs_composite_bwd(const float *__restrict__ grad_image, const _Float16 *__restrict__ c, const float *__restrict__ weights,
+                                                          const float *__restrict__ bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
+                                                          _Float16 *__restrict__ grad_c, float *__restrict__ grad_w) {
+    const uint64_t total = (uint64_t)N * T;
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (uint64_t)gridDim.x * 256) {
+        const uint32_t n = (uint32_t)(s / T);
+        const float g0 = grad_image[n * 3], g1 = grad_image[n * 3 + 1], g2 = grad_image[n * 3 + 2];
+        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+        const float w = weights[s];
+        float gw = -(g0 * b0 + g1 * b1 + g2 * b2);
+        h8 o0, o1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
+        if (w > thresh) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+            const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
+            const float y0 = fs_sigmoid_h((float)cc[0]), y1 = fs_sigmoid_h((float)cc[1]), y2 = fs_sigmoid_h((float)cc[2]);
+            gw += g0 * y0 + g1 * y1 + g2 * y2;
+            o0[0] = (_Float16)(g0 * w * y0 * (1 - y0)); o0[1] = (_Float16)(g1 * w * y1 * (1 - y1)); o0[2] = (_Float16)(g2 * w * y2 * (1 - y2));
+        }
+        grad_w[s] = gw;
+        h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16);
+        dst[0] = o0; dst[1] = o1;
+    }
+}
+
+// ================================================================= host entry points
+extern "C" {
+
+int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
+                     uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(rays_o && rays_d && nears && fars && aabb && (xyzs || enc_in), FOC_E_INVALID, "fixed_sample: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_sample: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_sample, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars, aabb,
+                       noise, N, T, bound, xyzs, enc_in);
+    FOC_CHECK_LAUNCH("fixed_sample");
+    return FOC_OK;
+}
+
+int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars, const float *noise, uint32_t N, uint32_t T,
+                           float density_scale, float *sigma, float *trans, float *weights, float *weights_sum, float *depth, void *cin, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(h && rays_d && nears && fars && sigma && trans && weights && weights_sum && depth, FOC_E_INVALID, "fixed_head_forward: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_forward: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_head_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, rays_d, nears, fars, noise, N, T,
+                       density_scale, sigma, trans, weights, weights_sum, depth, (_Float16 *)cin);
+    FOC_CHECK_LAUNCH("fixed_head_forward");
+    return FOC_OK;
+}
+
+int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears, const float *fars, const float *noise,
+                            const float *grad_w, const float *grad_ws, const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
+                            float density_scale, void *grad_h, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(h && sigma && trans && nears && fars && grad_h, FOC_E_INVALID, "fixed_head_backward: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_backward: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_head_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, sigma, trans, nears, fars, noise,
+                       grad_w, grad_ws, grad_depth, (const _Float16 *)grad_cin, N, T, density_scale, (_Float16 *)grad_h);
+    FOC_CHECK_LAUNCH("fixed_head_backward");
+    return FOC_OK;
+}
+
+int foc_fixed_composite_forward(const void *c, const float *weights, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
+                                float *image, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(c && weights && image, FOC_E_INVALID, "fixed_composite_forward: null pointer");
+    hipLaunchKernelGGL(k_fs_composite_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)c, weights, bg_ray, bg_scalar, N, T,
+                       thresh, image);
+    FOC_CHECK_LAUNCH("fixed_composite_forward");
+    return FOC_OK;
+}
+
+int foc_fixed_composite_backward(const float *grad_image, const void *c, const float *weights, const float *bg_ray, float bg_scalar, uint32_t N,
+                                 uint32_t T, float thresh, void *grad_c, float *grad_w, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(grad_image && c && weights && grad_c && grad_w, FOC_E_INVALID, "fixed_composite_backward: null pointer");
+    hipLaunchKernelGGL(k_fs_composite_bwd, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, grad_image,
+                       (const _Float16 *)c, weights, bg_ray, bg_scalar, N, T, thresh, (_Float16 *)grad_c, grad_w);
+    FOC_CHECK_LAUNCH("fixed_composite_backward");
+    return FOC_OK;
+}
+
+} // extern "C"

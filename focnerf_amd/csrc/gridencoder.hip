@@ -534,6 +534,113 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter(const T *__restrict__ gr
     }
 }
 
+// ---- point-major count / scatter for the [B, L*C] gradient layout -----------------------------
+// With grad laid out [B, L*C] a level-major kernel reads 4 bytes per 64-byte line and every level runs on a
+// different XCD, so each line is fetched 16 times (PMC: 2.5 GB per pass for 134 MB of gradient). Here lane g
+// handles (point g / L, level g % L): the gradient read is contiguous, the point is an L1 broadcast. A
+// workgroup owns GB_PM_TILE points x all levels, keeps one LDS counter per (level, segment) and talks to the
+// global counters once per non-empty (level, segment).
+#define GB_PM_TILE 1024u
+
+template <typename T>
+__device__ __forceinline__ bool gb_load_pm(const T *__restrict__ grad, const float *__restrict__ inputs, uint64_t g, uint32_t L, uint64_t total,
+                                           uint32_t &level, float (&x)[3], float (&gv)[2]) {
+    if (g >= total) return false;
+    const uint32_t b = (uint32_t)(g / L);
+    level = (uint32_t)(g - (uint64_t)b * L);
+    if (ge_load_point<3>(inputs, b, x)) return false;
+    GeVec<T, 2>::ld(grad + g * 2, gv);
+    return (gv[0] != 0.0f) || (gv[1] != 0.0f);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GB_WG) k_gbin_count_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                                         GbHeader *__restrict__ hdr, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
+                                                         bool align_corners, uint32_t interp) {
+    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
+    __shared__ uint32_t s_size[GE_MAX_LEVELS];
+    const uint32_t nslots = L * GB_MAX_SEGS;
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) hist[i] = 0;
+    if (threadIdx.x < L) s_size[threadIdx.x] = (uint32_t)offsets[threadIdx.x + 1] - (uint32_t)offsets[threadIdx.x];
+    __syncthreads();
+    const uint64_t total = (uint64_t)B * L;
+    const uint64_t g0 = (uint64_t)blockIdx.x * GB_PM_TILE * L;
+    const uint32_t span = GB_PM_TILE * L;
+    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
+        uint32_t level; float x[3], g[2];
+        if (gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) {
+            uint32_t rows[8]; float ws[8];
+            gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG)
+        if (hist[i]) (void)__hip_atomic_fetch_add(&hdr->counts[i], hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                                           GbHeader *__restrict__ hdr, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L,
+                                                           GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];     // phase A: counts, phase B: running cursor
+    __shared__ uint32_t gbase[GE_MAX_LEVELS * GB_MAX_SEGS];
+    __shared__ uint32_t s_size[GE_MAX_LEVELS];
+    const uint32_t nslots = L * GB_MAX_SEGS;
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) hist[i] = 0;
+    if (threadIdx.x < L) s_size[threadIdx.x] = (uint32_t)offsets[threadIdx.x + 1] - (uint32_t)offsets[threadIdx.x];
+    __syncthreads();
+    const uint64_t total = (uint64_t)B * L;
+    const uint64_t g0 = (uint64_t)blockIdx.x * GB_PM_TILE * L;
+    const uint32_t span = GB_PM_TILE * L;
+    // phase A: this workgroup's record count per (level, segment)
+    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
+        uint32_t level; float x[3], g[2];
+        if (gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) {
+            uint32_t rows[8]; float ws[8];
+            gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+        }
+    }
+    __syncthreads();
+    // reserve one contiguous range per non-empty (level, segment)
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) {
+        const uint32_t h = hist[i];
+        gbase[i] = h ? hdr->base[i] + __hip_atomic_fetch_add(&hdr->cursor[i], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        hist[i] = 0;
+    }
+    __syncthreads();
+    // phase B: recompute (inputs and gradient are L1/L2 hits now) and write the records
+    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
+        uint32_t level; float x[3], g[2];
+        if (!gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) continue;
+        uint32_t rows[8]; float ws[8];
+        gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t slot = level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT);
+            const uint64_t at = (uint64_t)gbase[slot] + atomicAdd(&hist[slot], 1u);
+            if (at >= max_recs) continue;
+            const uint32_t lrow = rows[i] & (GB_SEG - 1u);
+            const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
+            if constexpr (sizeof(T) == 2) {
+                uint2 r;
+                r.x = lrow;
+                const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                r.y = *reinterpret_cast<const uint32_t *>(&hv);
+                reinterpret_cast<uint2 *>(recs)[at] = r;
+            } else {
+                uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
+                float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
+                rr[at] = lrow;
+                vv[at] = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
 // LDS accumulation is done in DOUBLE: on gfx950 ds_add_f32 on random addresses runs ~23x slower than
 // ds_add_u32 (measured 101 vs 2349 G records/s, tools/bench_lds_atomic.hip) while ds_add_f64 runs at
 // 1823 G/s — so the fp32-quality sum is kept in a 128 KiB f64 image (one workgroup per CU).
@@ -827,16 +934,24 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
     const uint64_t max_recs = gb_max_recs(B, L);
     if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
-    const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
-    const dim3 grid(ge_xcd_grid(chunks, L));
-    if (bl) hipLaunchKernelGGL((k_gbin_count<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
-    else hipLaunchKernelGGL((k_gbin_count<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
-    FOC_CHECK_LAUNCH("grid_encode_backward(count)");
-    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
-    FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
-    if (bl) hipLaunchKernelGGL((k_gbin_scatter<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
-    else hipLaunchKernelGGL((k_gbin_scatter<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
-    FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+    if (bl) {
+        const dim3 grid(foc_div_up(B, GB_PM_TILE));
+        hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp);
+        FOC_CHECK_LAUNCH("grid_encode_backward(count)");
+        hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
+        FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
+        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp);
+        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+    } else {
+        const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
+        const dim3 grid(ge_xcd_grid(chunks, L));
+        hipLaunchKernelGGL((k_gbin_count<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
+        FOC_CHECK_LAUNCH("grid_encode_backward(count)");
+        hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
+        FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
+        hipLaunchKernelGGL((k_gbin_scatter<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
+        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+    }
     const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;
     hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
     FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");

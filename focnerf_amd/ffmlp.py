@@ -109,3 +109,9 @@ class FFMLP(nn.Module):
         if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
             outputs = outputs[:B, :self.output_dim]
         return outputs
+
+    def forward_padded(self, inputs):
+        """The kernel's full [B, 16] output (columns >= output_dim are the padding neurons), without the slice copy —
+        used by the fused render path, whose composite kernel reads the 16-wide rows directly."""
+        return ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                             self.activation, self.output_activation, not self.training, inputs.requires_grad)

@@ -1,0 +1,136 @@
+"""Fused fixed-step render path (FOC's default: num_steps samples per ray, no occupancy grid).
+
+`render_fixed_steps(model, rays_o, rays_d, ...)` computes what `NeRFRenderer.run` computes
+(nerf/renderer.py:126-238 with upsample_steps=0) for a `focnerf_amd.network.NeRFNetwork`, with the torch
+glue replaced by the kernels of csrc/fixedstep.hip:
+
+    near_far_from_aabb -> fixed_sample -> grid_encode -> sigma_net -> [density head] -> color_net -> [composite]
+
+The two bracketed stages are autograd Functions defined here. The colour network is evaluated on every
+sample and masked by `weights > weight_thresh` inside the composite, which yields the same image and the
+same gradients as the reference's gather -> MLP -> scatter (masked-out samples get rgb = 0 and no gradient).
+SURVEY.md §8(f)-3. Parity is tested against `NeRFRenderer.run` on the same network (tests/test_gpu_fixedstep.py).
+"""
+import torch
+from torch.autograd import Function
+
+from . import raymarching
+from ._lib import lib, ptr, stream_of, check
+from .gridencoder import grid_encode
+
+
+def fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, bound, want_xyzs=False):
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    enc_in = torch.empty(N * T, 3, dtype=torch.float32, device=dev)
+    xyzs = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if want_xyzs else None
+    check(lib.foc_fixed_sample(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, T, float(bound), ptr(xyzs), ptr(enc_in),
+                               stream_of(rays_o)), "fixed_sample")
+    return enc_in, xyzs
+
+
+class _density_head(Function):
+    """h [M,16] half -> (weights [M], weights_sum [N], depth [N], sigma [M], cin [M,32] half)."""
+
+    @staticmethod
+    def forward(ctx, h, rays_d, nears, fars, noise, N, T, density_scale):
+        h = h.contiguous()
+        assert h.dtype == torch.float16 and h.shape == (N * T, 16)
+        dev = h.device
+        M = N * T
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        trans = torch.empty(M, dtype=torch.float32, device=dev)
+        weights = torch.empty(M, dtype=torch.float32, device=dev)
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        cin = torch.empty(M, 32, dtype=torch.float16, device=dev)
+        check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
+                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), stream_of(h)), "fixed_head_forward")
+        ctx.save_for_backward(h, sigma, trans, nears, fars, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.has_noise = noise is not None
+        ctx.dims = (N, T, float(density_scale))
+        ctx.mark_non_differentiable(sigma)
+        return weights, ws, depth, sigma, cin
+
+    @staticmethod
+    def backward(ctx, g_weights, g_ws, g_depth, g_sigma, g_cin):
+        h, sigma, trans, nears, fars, noise = ctx.saved_tensors
+        N, T, ds = ctx.dims
+        noise = noise if ctx.has_noise else None
+        g_weights = g_weights.contiguous().float() if g_weights is not None else None
+        g_ws = g_ws.contiguous().float() if g_ws is not None else None
+        g_depth = g_depth.contiguous().float() if g_depth is not None else None
+        g_cin = g_cin.contiguous().half() if g_cin is not None else None
+        grad_h = torch.empty_like(h)
+        check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(g_weights), ptr(g_ws), ptr(g_depth),
+                                          ptr(g_cin), N, T, ds, ptr(grad_h), stream_of(h)), "fixed_head_backward")
+        return grad_h, None, None, None, None, None, None, None
+
+
+class _fixed_composite(Function):
+    """c [M,16] half (colour-net output), weights [M] -> image [N,3] = sum w*sigmoid(c)*[w>thresh] + (1 - sum w)*bg."""
+
+    @staticmethod
+    def forward(ctx, c, weights, bg_ray, bg_scalar, N, T, thresh):
+        c = c.contiguous()
+        weights = weights.contiguous()
+        assert c.dtype == torch.float16 and c.shape == (N * T, 16) and weights.dtype == torch.float32
+        image = torch.empty(N, 3, dtype=torch.float32, device=c.device)
+        check(lib.foc_fixed_composite_forward(ptr(c), ptr(weights), ptr(bg_ray), float(bg_scalar), N, T, float(thresh), ptr(image), stream_of(c)),
+              "fixed_composite_forward")
+        ctx.save_for_backward(c, weights, bg_ray if bg_ray is not None else torch.empty(0, device=c.device))
+        ctx.has_bg = bg_ray is not None
+        ctx.dims = (N, T, float(thresh), float(bg_scalar))
+        return image
+
+    @staticmethod
+    def backward(ctx, g_image):
+        c, weights, bg_ray = ctx.saved_tensors
+        N, T, thresh, bg_scalar = ctx.dims
+        bg_ray = bg_ray if ctx.has_bg else None
+        g_image = g_image.contiguous().float()
+        grad_c = torch.empty_like(c)
+        grad_w = torch.empty_like(weights)
+        check(lib.foc_fixed_composite_backward(ptr(g_image), ptr(c), ptr(weights), ptr(bg_ray), bg_scalar, N, T, thresh, ptr(grad_c), ptr(grad_w),
+                                               stream_of(c)), "fixed_composite_backward")
+        return grad_c, grad_w, None, None, None, None, None
+
+
+def render_fixed_steps(model, rays_o, rays_d, num_steps=512, bg_color=None, perturb=False, weight_thresh=1e-10, return_fields=False, **kwargs):
+    """Drop-in for NeRFRenderer.run(..., upsample_steps=0) on a focnerf_amd NeRFNetwork (fp16 autocast semantics)."""
+    prefix = rays_o.shape[:-1]
+    rays_o = rays_o.contiguous().view(-1, 3).float()
+    rays_d = rays_d.contiguous().view(-1, 3).float()
+    N, T = rays_o.shape[0], int(num_steps)
+    dev = rays_o.device
+    aabb = model.aabb_train if model.training else model.aabb_infer
+    nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
+    noise = torch.rand(N * T, dtype=torch.float32, device=dev) if perturb else None
+    enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound)
+
+    enc = model.encoder
+    with torch.autocast("cuda", dtype=torch.float16):
+        feats = grid_encode(enc_in, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, enc.gridtype_id,
+                            enc.align_corners, enc.interp_id)
+        h = model.sigma_net(feats)                                        # [M,16] half
+        if h.shape[1] != 16:                                              # FFMLP slices to output_dim (= 16 here: 1 + geo_feat_dim 15)
+            raise RuntimeError("render_fixed_steps expects a 16-wide sigma head (1 + geo_feat_dim = 16)")
+        weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale)
+        c = model.color_net.forward_padded(cin)                            # [M,16] half, columns 0..2 = rgb logits
+
+    bg_ray, bg_scalar = None, 1.0
+    if bg_color is None:
+        bg_scalar = 1.0
+    elif torch.is_tensor(bg_color):
+        bg_ray = bg_color.to(dev, torch.float32).expand(N, 3).contiguous() if bg_color.numel() > 1 else None
+        bg_scalar = float(bg_color) if bg_ray is None else 0.0
+    else:
+        bg_scalar = float(bg_color)
+    image = _fixed_composite.apply(c, weights, bg_ray, bg_scalar, N, T, weight_thresh)
+
+    results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum}
+    if return_fields:
+        rgb = torch.sigmoid(c[:, :3]).float() * (weights > weight_thresh).unsqueeze(-1)
+        results['densities'] = sigma.view(N, T, 1)
+        results['rgbs'] = rgb.view(N, T, 3)
+    return results

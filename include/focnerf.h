@@ -273,6 +273,41 @@ int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const floa
                               const float *fars, uint32_t N, uint32_t T, float bg,
                               float *image4, float *depth, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Fixed-step render path as fused ops. No reference binding: these replace the torch
+ * code of nerf/renderer.py:145-221 (== COMBINED.py:451-534) and the glue of nerf/network_ff.py:51-134
+ * between the encoder and the two MLPs. M = N*T samples, ray-major. `noise` ([M] uniform(0,1), the
+ * reference's torch.rand for perturb) may be NULL.
+ * ------------------------------------------------------------------------- */
+
+/* z = near + (far-near)*linspace(0,1,T)[i] (+ (noise-0.5)*(far-near)/T); xyz = clip(o + d z, aabb) -> xyzs [M,3]
+ * and/or enc_in [M,3] = (xyz + bound)/(2 bound), the GridEncoder's normalised input (grid.py:149). */
+int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
+                     const float *aabb, const float *noise, uint32_t N, uint32_t T, float bound,
+                     float *xyzs, float *enc_in, void *stream);
+
+/* h [M,16] fp16 = sigma-net output. sigma = exp(h[:,0]); weights = alpha * cumprod(1-alpha+1e-15);
+ * trans [M] = transmittance before each sample; weights_sum/depth [N]; cin [M,32] fp16 =
+ * [SH16(dir) | h[:,1:16] | 0] (the colour-net input, network_ff.py:62-68) or NULL. */
+int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars,
+                           const float *noise, uint32_t N, uint32_t T, float density_scale,
+                           float *sigma, float *trans, float *weights, float *weights_sum, float *depth,
+                           void *cin, void *stream);
+/* grad_w [M], grad_ws [N], grad_depth [N], grad_cin [M,32] fp16 (each may be NULL) -> grad_h [M,16] fp16. */
+int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears,
+                            const float *fars, const float *noise, const float *grad_w, const float *grad_ws,
+                            const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
+                            float density_scale, void *grad_h, void *stream);
+
+/* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
+ * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL
+ * (then bg_scalar). */
+int foc_fixed_composite_forward(const void *c, const float *weights, const float *bg_ray, float bg_scalar,
+                                uint32_t N, uint32_t T, float thresh, float *image, void *stream);
+int foc_fixed_composite_backward(const float *grad_image, const void *c, const float *weights,
+                                 const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
+                                 void *grad_c, float *grad_w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
