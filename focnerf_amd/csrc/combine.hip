@@ -71,12 +71,12 @@ __global__ void __launch_bounds__(256) k_composite_fixed(const float *__restrict
         const bool valid = i < T;
         float alpha = 0, sigma = 0, c0 = 0, c1 = 0, c2 = 0, oz = 0;
         if (valid) {
-            const float l0 = (i < T / 2) ? (step * (float)i) : (1.0f - step * (float)(T - 1 - i));
+            const float l0 = (i < T / 2) ? (step * (float)i) : fmaf(-step, (float)(T - 1 - i), 1.0f);   // device linspace: see fixedstep.hip
             const float z = near + span * l0;
             float delta = sample_dist;
             if (i + 1 < T) {
                 const uint32_t i1 = i + 1;
-                const float l1 = (i1 < T / 2) ? (step * (float)i1) : (1.0f - step * (float)(T - 1 - i1));
+                const float l1 = (i1 < T / 2) ? (step * (float)i1) : fmaf(-step, (float)(T - 1 - i1), 1.0f);
                 delta = (near + span * l1) - z;
             }
             const uint64_t s = (uint64_t)n * T + i;

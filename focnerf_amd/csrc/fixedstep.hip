@@ -28,9 +28,11 @@ __device__ __forceinline__ FsGeom fs_geom(const float *__restrict__ nears, const
     g.step = 1.0f / (float)(T - 1);
     return g;
 }
-// torch.linspace(0, 1, T) as torch fills it (symmetric halves), then z = near + span * lin [+ (u - 0.5) * sample_dist]
+// torch.linspace(0, 1, T) as torch's DEVICE kernel fills it: symmetric halves, and the upper half `end - step*k` is one
+// fused multiply-add (the device compilers — nvcc for the reference, hipcc for torch-ROCm — contract it; torch's CPU kernel
+// and therefore the CPU oracle round twice). Then z = near + span * lin [+ (u - 0.5) * sample_dist], separate torch ops.
 __device__ __forceinline__ float fs_z(const FsGeom &g, uint32_t i, uint32_t T, const float *__restrict__ noise, uint64_t s) {
-    const float lin = (i < T / 2) ? (g.step * (float)i) : (1.0f - g.step * (float)(T - 1 - i));
+    const float lin = (i < T / 2) ? (g.step * (float)i) : fmaf(-g.step, (float)(T - 1 - i), 1.0f);
     float z = g.near + g.span * lin;
     if (noise) z = z + (noise[s] - 0.5f) * g.sample_dist;
     return z;

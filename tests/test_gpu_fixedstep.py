@@ -68,6 +68,10 @@ def test_fused_fields_match_oracle_composite():
     from focnerf_amd import raymarching
     m = _model(1, 5).eval()
     o, d = _rays(1, 32, 4)
+    # a few rays whose line misses the box: tangent direction at distance 2 > sqrt(3)
+    t = torch.cross(o[0, :7], torch.tensor([[0.3, -0.5, 0.8]], device="cuda").expand(7, 3), dim=-1)
+    d = d.clone()
+    d[0, :7] = t / t.norm(dim=-1, keepdim=True)
     with torch.no_grad():
         res = render_fixed_steps(m, o, d, num_steps=512, bg_color=1.0, perturb=False, return_fields=True)
     nears, fars = raymarching.near_far_from_aabb(o[0], d[0], m.aabb_infer, m.min_near)
