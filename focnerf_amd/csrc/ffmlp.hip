@@ -23,6 +23,7 @@
 //    fp32 atomics of whole 128-B row segments into a 16-KiB-per-layer workspace), replacing
 //    the reference's CUTLASS split-K GEMMs on side streams (ffmlp.cu:800-876).
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -475,6 +476,209 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) gw[i] = (_Float16)ws[i];
 }
 
+// ---------------------------------------------------------------- M2+M3 fused: activation gradients AND weight gradients in one pass
+// The two-kernel form writes every activation gradient to HBM (backward_buffer) and reads it, the forward activations and the
+// inputs back for the split-K weight-gradient GEMM: ~1.2 KB/sample. Here a workgroup (4 waves x 32*NB rows) walks the layers once:
+//   stage s: every wave puts its rows of D_s (grad for s = 0, else the masked delta it just computed) and of A_s (the layer's
+//            input: forward activations, or the network inputs for the last stage) into LDS as row-major tiles;
+//   barrier; wave w accumulates output tile w of dW_s = D_s^T A_s over ALL four waves' rows (operands read transposed with
+//            ds_read_b64_tr_b16) in registers that live across the whole batch loop;
+//   the same A_s tile is the ReLU mask of the next delta, which chains in registers exactly as in k_mlp_bwd; barrier.
+// HBM traffic drops to grad + forward activations + inputs (+ grad_inputs): ~0.4 KB/sample, and backward_buffer is only written
+// if the caller asks for it. Compile-time layer count (the stage loop must unroll for the accumulators to stay in registers).
+template <int HIDDEN, int NL, int NB>
+__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
+                                                             const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
+                                                             _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
+                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs) {
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
+    constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const bool with_dx = grad_inputs != nullptr;
+    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx);
+    const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
+    _Float16 *sD = lds + lds_w_halfs;                    // [4][RW][WD]
+    _Float16 *sA = sD + 4 * RW * WD;                     // [4][RW][WA]
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t MT0 = (in_dim + 31) / 32;
+    const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
+    const uint64_t first = (uint64_t)HIDDEN * in_dim, lsz = (uint64_t)HIDDEN * HIDDEN;
+    _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
+
+    f16v dwacc[NL + 1];
+#pragma unroll
+    for (int s = 0; s <= NL; s++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) dwacc[s][e] = 0.0f;
+
+    const uint32_t rows_per_group = 4 * RW;
+    const uint32_t n_groups = (B + rows_per_group - 1) / rows_per_group;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint64_t row0 = (uint64_t)grp * rows_per_group + wave * RW;     // this wave's first row
+        f16v acc[MT][NB];
+        h8 bf[KC][NB];
+#pragma unroll
+        for (int s = 0; s <= NL; s++) {
+            const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN;
+            const uint32_t IN = s < NL ? (uint32_t)HIDDEN : in_dim;
+            const _Float16 *Ap = s < NL ? fwd_buf + (uint64_t)(NL - 1 - s) * B * HIDDEN : inputs;
+            // ---- D_s tile of this wave -> LDS
+            if (s == 0) {
+                for (uint32_t idx = lane; idx < RW * 2; idx += 64) {
+                    const uint32_t rr = idx >> 1, cc = (idx & 1) * 8;
+                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(grad + (row0 + rr) * 16 + cc);
+                    *reinterpret_cast<h8 *>(myD + rr * WD + cc) = v;
+                }
+            } else {
+                // delta of forward layer NL-s: acc, already masked; rounded to fp16 (what the reference stores in backward_buffer)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const bool live = row0 + nb * 32 + c < B;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t col = 32 * mt + 8 * q + 4 * h;
+                            if (col < HIDDEN) {
+                                h4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = live ? (_Float16)acc[mt][nb][4 * q + e] : (_Float16)0;
+                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + col) = v;
+                            }
+                        }
+                        if (bwd_buf) store_tile<false>(bwd_buf + (uint64_t)(s - 1) * B * HIDDEN, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
+                    }
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) bf[kc][nb] = acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+            }
+            // ---- A_s tile of this wave -> LDS (rows past B as zeros: they must not reach dW)
+            for (uint32_t idx = lane; idx < RW * (IN / 8); idx += 64) {
+                const uint32_t rr = idx / (IN / 8), cc = (idx % (IN / 8)) * 8;
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
+                *reinterpret_cast<h8 *>(myA + rr * WA + cc) = v;
+            }
+            __syncthreads();
+            // ---- dW_s: output tile `wave` (MTo x NTi tiles, at most 4 for HIDDEN, in_dim <= 64)
+            {
+                const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32;
+                if (wave < MTo * NTi) {
+                    const uint32_t mt = wave / NTi, nt = wave % NTi;
+                    const uint32_t o = 32 * mt + (lane & 31), i = 32 * nt + (lane & 31);
+                    const int q = (lane & 15) >> 2, p = lane & 3, cg = 16 * ((lane >> 4) & 1);
+#pragma unroll
+                    for (int wv = 0; wv < 4; wv++) {
+                        const _Float16 *tD = sD + wv * RW * WD, *tA = sA + wv * RW * WA;
+#pragma unroll
+                        for (int ks = 0; ks < RW / 16; ks++) {
+                            const int k0 = 16 * ks + 8 * h + q;
+                            const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * p));
+                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 4) * WD + 32 * mt + cg + 4 * p));
+                            const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * p));
+                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 4) * WA + 32 * nt + cg + 4 * p));
+                            const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
+                            const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
+                            u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
+                            if (!(o < OUT)) av = u32x4{0u, 0u, 0u, 0u};
+                            if (!(i < IN)) bv = u32x4{0u, 0u, 0u, 0u};
+                            dwacc[s] = mfma16(__builtin_bit_cast(h8, av), __builtin_bit_cast(h8, bv), dwacc[s]);
+                        }
+                    }
+                }
+            }
+            // ---- next delta (chained in registers), masked by A_s read back in the accumulator layout from this wave's own tile
+            if (s == 0) {
+                h8 bg[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) bg[nb] = *reinterpret_cast<const h8 *>(myD + (nb * 32 + c) * WD + 8 * h);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h8 a = ld_frag(lds, mt, lane);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        f16v z;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) z[e] = 0.0f;
+                        acc[mt][nb] = mfma16(a, bg[nb], z);
+                    }
+                }
+            } else if (s < NL) {
+                const uint32_t fbase = f_hidden + (NL - 1 - s) * MT * KC;     // hidden matrix fl-1 with fl = NL - s
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const h8 a = ld_frag(lds, fbase + mt * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                    }
+            } else if (with_dx) {
+                for (uint32_t mt0 = 0; mt0 < MT0; mt0++) {
+                    f16v x[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) x[nb][e] = 0.0f;
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const h8 a = ld_frag(lds, f_dx + mt0 * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], x[nb]);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
+                }
+            }
+            if (s < NL && relu) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t col = 32 * mt + 8 * q + 4 * h;
+                            if (col < HIDDEN) {
+                                const h4 f = *reinterpret_cast<const h4 *>(myA + (nb * 32 + c) * WA + col);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) if (!(f[e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
+                            }
+                        }
+            }
+            __syncthreads();       // every wave is done reading sD / sA of this stage
+        }
+    }
+    // ---- flush the weight-gradient tiles
+#pragma unroll
+    for (int s = 0; s <= NL; s++) {
+        const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN;
+        const uint32_t IN = s < NL ? (uint32_t)HIDDEN : in_dim;
+        const uint32_t fl = NL - s;                                               // forward layer whose matrix this is (s = 0: output matrix)
+        const uint64_t ws_off = s == 0 ? first + (uint64_t)(NL - 1) * lsz : (fl == 0 ? 0 : first + (uint64_t)(fl - 1) * lsz);
+        const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32;
+        if (wave < MTo * NTi) {
+            const uint32_t mt = wave / NTi, nt = wave % NTi;
+            const uint32_t i = 32 * nt + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const uint32_t o = 32 * mt + acc_row(reg, h);
+                if (o < OUT && i < IN) (void)__hip_atomic_fetch_add(ws + ws_off + (uint64_t)o * IN + i, dwacc[s][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // ================================================================= host side
 static uint32_t g_num_cus = 0;
 static uint32_t mlp_num_cus() {
@@ -546,9 +750,47 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
     return FOC_E_INVALID;
 }
 
+template <int HIDDEN, int NL>
+static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, int relu,
+                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, hipStream_t st) {
+    constexpr int NB = 1, RW = 32 * NB, WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
+    const bool dx = grad_inputs != nullptr;
+    const size_t lds_w = mlp_bwd_lds<HIDDEN>(in_dim, NL, dx);
+    const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
+    const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16);
+    FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
+    auto kern = k_mlp_bwd_fused<HIDDEN, NL, NB>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
+    if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
+    uint32_t grid = foc_div_up(B, 4 * RW);
+    const uint32_t cap = mlp_num_cus() * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)));
+    FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
+    hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
+    FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
+    return FOC_OK;
+}
+
 template <int HIDDEN>
 static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim,
                           uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, hipStream_t st) {
+    // fused single-pass kernel for the shapes the NeRF networks use; FOC_MLP_BWD_FUSED=0 forces the two-kernel form (tuning / tests)
+    static int use_fused = -1;
+    if (use_fused < 0) { const char *e = getenv("FOC_MLP_BWD_FUSED"); use_fused = e ? atoi(e) : 1; }
+    if constexpr (HIDDEN <= 64) {
+        if (use_fused && in_dim <= 64) {
+            switch (num_layers) {
+                case 2: return mlp_bwd_fused_launch<HIDDEN, 2>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
+                case 3: return mlp_bwd_fused_launch<HIDDEN, 3>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
+                case 4: return mlp_bwd_fused_launch<HIDDEN, 4>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
+                default: break;
+            }
+        }
+    }
+    FOC_REQUIRE(bwd_buf, FOC_E_INVALID, "ffmlp_backward: backward_buffer is required for this shape (two-kernel path)");
     constexpr int NB = 2;
     const bool dx = grad_inputs != nullptr;
     const size_t lds = mlp_bwd_lds<HIDDEN>(in_dim, num_layers, dx);
@@ -566,7 +808,9 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
     if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t gx = foc_div_up(B, DW_CHUNK);
-    const uint32_t capx = foc_div_up(mlp_num_cus() * 2, num_layers + 1);
+    static int wgs_per_cu = 0;                   // split-K workgroups per CU over all layers (FOC_DW_WGS_PER_CU overrides, for tuning)
+    if (!wgs_per_cu) { const char *e = getenv("FOC_DW_WGS_PER_CU"); wgs_per_cu = e ? atoi(e) : 8; if (wgs_per_cu < 1) wgs_per_cu = 1; }
+    const uint32_t capx = foc_div_up(mlp_num_cus() * (uint32_t)wgs_per_cu, num_layers + 1);
     if (gx > capx) gx = capx;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL((k_mlp_dw<HIDDEN>), dim3(gx, num_layers + 1), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
@@ -596,7 +840,8 @@ uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
-    FOC_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
+    // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip (the two-kernel path checks it again)
+    FOC_REQUIRE(grad && inputs && weights && forward_buffer && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
     FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
     int rc = mlp_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc) return rc;

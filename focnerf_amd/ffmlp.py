@@ -8,6 +8,7 @@ Notes on behaviour kept from the reference:
 The stray `from turtle import ...` of ffmlp.py:2 is not reproduced.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -50,7 +51,10 @@ class _ffmlp_forward(Function):
         else:
             grad_inputs = torch.zeros(1, device=grad.device, dtype=grad.dtype)   # dummy, as in the reference (:70)
         grad_weights = torch.empty_like(weights)
-        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        # The fused backward keeps the activation gradients on chip; the [num_layers, B, hidden] buffer the reference allocates
+        # (ffmlp.py:73) is only needed by the two-kernel fallback (hidden_dim 128, input_dim > 64 or num_layers > 4).
+        fused_ok = hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4 and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0"
+        backward_buffer = None if fused_ok else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                 output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
         if calc_grad_inputs:

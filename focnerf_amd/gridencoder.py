@@ -67,14 +67,15 @@ class _grid_encode(Function):
         align_corners = ctx.align_corners
 
         grad = grad.to(embeddings.dtype)
-        if ctx.lbc:
+        lbc_bwd = ctx.lbc or os.environ.get("FOCNERF_GRID_BWD_LBC", "0") == "1"
+        if lbc_bwd:
             grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()     # grid.py:75
         else:
             grad = grad.contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
-                                      align_corners, interpolation, grad_bl=not ctx.lbc)
+                                      align_corners, interpolation, grad_bl=not lbc_bwd)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
