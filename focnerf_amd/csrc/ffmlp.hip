@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // HBM traffic drops to grad + forward activations + inputs (+ grad_inputs): ~0.4 KB/sample, and backward_buffer is only written
 // if the caller asks for it. Compile-time layer count (the stage loop must unroll for the accumulators to stay in registers).
 template <int HIDDEN, int NL, int NB>
-__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
+__global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
                                                              uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs) {

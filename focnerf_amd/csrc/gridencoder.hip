@@ -104,7 +104,11 @@ __device__ __forceinline__ uint32_t ge_index(uint32_t gridtype, bool align_corne
         for (uint32_t i = 0; i < D; i++) result ^= pos_grid[i] * primes[i];
         index = result;
     }
-    return index % hashmap_size;   // row index; caller multiplies by C
+    // `index % hashmap_size` (gridencoder.cu:83) without the integer division in the common cases: dense levels have
+    // index < size already, hashed levels have a power-of-two size (2^log2_hashmap_size); the generic path remains for
+    // tiled grids / odd sizes. A runtime u32 modulo is ~35 VALU instructions and this runs 8x per (point, level).
+    if (index >= hashmap_size) index = ((hashmap_size & (hashmap_size - 1u)) == 0u) ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
+    return index;                  // row index; caller multiplies by C
 }
 
 // Decode a linear block id into (level, chunk) so that all blocks of a level share
@@ -580,8 +584,8 @@ __device__ __forceinline__ bool gb_load_pm(const T *__restrict__ grad, const flo
 
 template <typename T>
 __global__ void __launch_bounds__(GB_WG) k_gbin_count_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                         GbHeader *__restrict__ hdr, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-                                                         bool align_corners, uint32_t interp) {
+                                                         GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv,
+                                                         uint32_t gridtype, bool align_corners, uint32_t interp) {
     __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
     __shared__ uint32_t s_size[GE_MAX_LEVELS];
     const uint32_t nslots = L * GB_MAX_SEGS;
@@ -601,66 +605,68 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_count_pm(const T *__restrict__ g
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG)
-        if (hist[i]) (void)__hip_atomic_fetch_add(&hdr->counts[i], hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // totals per (level, segment), and this workgroup's own counts ([slot][workgroup]) so that the scatter pass gets a
+    // precomputed, deterministic base per (workgroup, slot) and needs neither a second counting phase nor reservation atomics
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) {
+        const uint32_t hcount = hist[i];
+        if (hcount) (void)__hip_atomic_fetch_add(&hdr->counts[i], hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wg_hist[(uint64_t)i * gridDim.x + blockIdx.x] = hcount;
+    }
+}
+
+// per slot: exclusive scan over the workgroups' counts, offset by the slot's global base (in place)
+__global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t n_wg) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t slot = blockIdx.x;
+    uint32_t *col = wg_hist + (uint64_t)slot * n_wg;
+    const uint32_t per = (n_wg + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = min(n_wg, lo + per);
+    uint32_t local = 0;
+    for (uint32_t i = lo; i < hi; i++) local += col[i];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = (uint32_t)wave_incl_sum_i((int)local, (int)lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t k = 0; k < wave; k++) wbase += s_wave[k];
+    uint32_t run = hdr->base[slot] + wbase + (incl - local);
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = col[i]; col[i] = run; run += c; }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                           GbHeader *__restrict__ hdr, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L,
-                                                           GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
-    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];     // phase A: counts, phase B: running cursor
-    __shared__ uint32_t gbase[GE_MAX_LEVELS * GB_MAX_SEGS];
+                                                           const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B,
+                                                           uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+    __shared__ uint32_t cursor[GE_MAX_LEVELS * GB_MAX_SEGS];   // next free record of this workgroup's range, per (level, segment)
     __shared__ uint32_t s_size[GE_MAX_LEVELS];
     const uint32_t nslots = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) cursor[i] = wg_base[(uint64_t)i * gridDim.x + blockIdx.x];
     if (threadIdx.x < L) s_size[threadIdx.x] = (uint32_t)offsets[threadIdx.x + 1] - (uint32_t)offsets[threadIdx.x];
     __syncthreads();
     const uint64_t total = (uint64_t)B * L;
     const uint64_t g0 = (uint64_t)blockIdx.x * GB_PM_TILE * L;
     const uint32_t span = GB_PM_TILE * L;
-    // phase A: this workgroup's record count per (level, segment)
-    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
-        uint32_t level; float x[3], g[2];
-        if (gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) {
-            uint32_t rows[8]; float ws[8];
-            gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
-#pragma unroll
-            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
-        }
-    }
-    __syncthreads();
-    // reserve one contiguous range per non-empty (level, segment)
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) {
-        const uint32_t h = hist[i];
-        gbase[i] = h ? hdr->base[i] + __hip_atomic_fetch_add(&hdr->cursor[i], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        hist[i] = 0;
-    }
-    __syncthreads();
-    // phase B: recompute (inputs and gradient are L1/L2 hits now) and write the records
     for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
         uint32_t level; float x[3], g[2];
         if (!gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) continue;
         uint32_t rows[8]; float ws[8];
         gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+        uint32_t at[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) at[i] = atomicAdd(&cursor[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t slot = level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT);
-            const uint64_t at = (uint64_t)gbase[slot] + atomicAdd(&hist[slot], 1u);
-            if (at >= max_recs) continue;
+            if (at[i] >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
             const uint32_t lrow = rows[i] & (GB_SEG - 1u);
             const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
             if constexpr (sizeof(T) == 2) {
-                uint2 r;
-                r.x = lrow;
                 const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
-                r.y = *reinterpret_cast<const uint32_t *>(&hv);
-                reinterpret_cast<uint2 *>(recs)[at] = r;
+                reinterpret_cast<uint2 *>(recs)[at[i]] = make_uint2(lrow, *reinterpret_cast<const uint32_t *>(&hv));
             } else {
                 uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
                 float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-                rr[at] = lrow;
-                vv[at] = make_float2(v0, v1);
+                rr[at[i]] = lrow;
+                vv[at[i]] = make_float2(v0, v1);
             }
         }
     }
@@ -673,7 +679,8 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
                                                              const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
-    __shared__ double acc[GB_SEG * 2];             // 128 KiB
+    __shared__ double acc[GB_SEG * 2];             // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64)
+    unsigned long long *acci = reinterpret_cast<unsigned long long *>(acc);
     __shared__ uint32_t s_slot, s_lo, s_hi;
     const uint32_t n = L * GB_MAX_SEGS;
     const uint32_t total_chunks = hdr->chunk_prefix[n];
@@ -708,9 +715,11 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
                 if (cur[u].x != 0xFFFFFFFFu) {
+                    // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT
+                    // (and order independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
                     const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&cur[u].y));
-                    atomicAdd(&acc[cur[u].x * 2], (double)v.x);
-                    atomicAdd(&acc[cur[u].x * 2 + 1], (double)v.y);
+                    atomicAdd(&acci[cur[u].x * 2], (unsigned long long)(long long)(v.x * 16777216.0f));
+                    atomicAdd(&acci[cur[u].x * 2 + 1], (unsigned long long)(long long)(v.y * 16777216.0f));
                 }
             }
 #pragma unroll
@@ -750,7 +759,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     if constexpr (sizeof(T) == 2) {
         typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
         for (uint32_t r = threadIdx.x; r < nrows; r += GB_RTHREADS) {
-            const float a = (float)acc[2 * r], b = (float)acc[2 * r + 1];
+            const float a = (float)((double)(long long)acci[2 * r] * (1.0 / 16777216.0)), b = (float)((double)(long long)acci[2 * r + 1] * (1.0 / 16777216.0));
             if (a == 0.0f && b == 0.0f) continue;
             v2h hv; hv[0] = (_Float16)ge_opaque(a); hv[1] = (_Float16)ge_opaque(b);
             (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) v2h *)(dst + 2 * r), hv);
@@ -965,7 +974,12 @@ static uint64_t gb_max_recs(uint32_t B, uint32_t L) { return (uint64_t)B * 8u * 
 static uint64_t gb_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
     const uint64_t hdr = (sizeof(GbHeader) + 255) & ~(uint64_t)255;
     const uint64_t m = gb_max_recs(B, L);
-    return hdr + (dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 256;
+    const uint64_t wg = (uint64_t)foc_div_up(B, GB_PM_TILE) * L * GB_MAX_SEGS * 4;      // per-workgroup counts / bases of the point-major passes
+    return hdr + (dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 256 + wg + 256;
+}
+static uint64_t gb_recs_bytes(uint32_t B, uint32_t L, int dtype) {
+    const uint64_t m = gb_max_recs(B, L);
+    return ((dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 255) & ~(uint64_t)255;
 }
 
 template <typename T>
@@ -978,12 +992,16 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     static int use_pm = -1;                      // FOC_GBIN_PM=0 selects the level-major count/scatter for [B,L*C] gradients too (tuning)
     if (use_pm < 0) { const char *e = getenv("FOC_GBIN_PM"); use_pm = e ? atoi(e) : 1; }
     if (bl && use_pm) {
-        const dim3 grid(foc_div_up(B, GB_PM_TILE));
-        hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp);
+        const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
+        const dim3 grid(n_wg);
+        uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
+        hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
         FOC_CHECK_LAUNCH("grid_encode_backward(count)");
         hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
         FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
-        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp);
+        hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
+        FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
+        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp);
         FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     } else {
         const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
