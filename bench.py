@@ -219,7 +219,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--render-views", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the render / occupancy-path extras")
@@ -360,6 +360,47 @@ def main():
         result["occupancy_path"] = {"metric": "train_samples_per_sec", "value": world * per_step * n2 / el2, "unit": "samples/s",
                                     "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
                                     "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
+
+        # ---- configs[2] render half: full 800x800 view through the incremental march_rays / composite_rays loop
+        m2.eval()
+        ro2, rd2 = synthetic.get_rays(poses2[:1], intr, VIEW, VIEW)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            m2.render(ro2[:, :65536], rd2[:, :65536], staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.render_views):
+                m2.render(ro2, rd2, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4, device_compaction=True)
+            barrier()
+        rel2 = max_over_ranks(time.perf_counter() - t0)
+        result["render_occupancy"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel2, "unit": "rays/s",
+                                      "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2"}
+
+        # ---- configs[3]/[4]: per-sample multi-object combine, one object per rank (RCCL MAX all-reduce of keys + SUM of the winner's rgb)
+        try:
+            from focnerf_amd.combine import ObjectCombiner
+            from focnerf_amd import raymarching as rm
+            comb = ObjectCombiner(rank=rank, world_size=world)
+            chunk = 4096
+            co, cd = rays_o[0, :chunk].contiguous(), rays_d[0, :chunk].contiguous()
+            cn, cf = rm.near_far_from_aabb(co, cd, model.aabb_infer, model.min_near)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                fld = model.run(co[None], cd[None], num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused, return_fields=True)
+            dens, rgbf = fld["densities"].squeeze(-1).float().contiguous(), fld["rgbs"].float().contiguous()
+            for _ in range(2):
+                comb.render_chunk(dens, rgbf, cn, cf, bg=1.0)
+            barrier()
+            t0 = time.perf_counter()
+            nck = 20
+            for _ in range(nck):
+                comb.render_chunk(dens, rgbf, cn, cf, bg=1.0)
+            barrier()
+            elc = max_over_ranks(time.perf_counter() - t0)
+            result["combine"] = {"metric": "combine_rays_per_sec", "value": chunk * nck / elc, "unit": "rays/s", "objects": world,
+                                 "bytes_exchanged_per_chunk": (8 + 12) * chunk * NUM_STEPS if world > 1 else 0,
+                                 "path": "ObjectCombiner.render_chunk: key pack -> all-reduce(MAX) -> unpack -> all-reduce(SUM) -> ray-sliced composite -> all-gather "
+                                         "(field evaluation excluded; 4096-ray x 512-sample chunks)"}
+        except Exception as e:   # the combine extra must never take the headline number down with it
+            result["combine"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

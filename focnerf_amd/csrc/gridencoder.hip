@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict_
 template <typename T>
 __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
                                                            const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B,
-                                                           uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp) {
+                                                           uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t diag) {
     __shared__ uint32_t cursor[GE_MAX_LEVELS * GB_MAX_SEGS];   // next free record of this workgroup's range, per (level, segment)
     __shared__ uint32_t s_size[GE_MAX_LEVELS];
     const uint32_t nslots = L * GB_MAX_SEGS;
@@ -652,8 +652,20 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__
         uint32_t rows[8]; float ws[8];
         gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
         uint32_t at[8];
+        if (diag & 2u) {      // DIAGNOSTIC timing build (FOC_GBIN_DIAG): linear positions instead of the LDS cursor atomics — results are wrong
 #pragma unroll
-        for (int i = 0; i < 8; i++) at[i] = atomicAdd(&cursor[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+            for (int i = 0; i < 8; i++) at[i] = (uint32_t)((g0 + it) * 8 + i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) at[i] = atomicAdd(&cursor[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+        }
+        if (diag & 1u) {      // DIAGNOSTIC: skip the record stores (keep the values alive)
+            uint32_t keep = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) keep ^= at[i] ^ __float_as_uint(ws[i] * g[0]);
+            if (keep == 0xDEADBEEFu) reinterpret_cast<uint32_t *>(recs)[0] = keep;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (at[i] >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
@@ -1001,7 +1013,10 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
         hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
         FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
-        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp);
+        static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no cursor atomics); WRONG RESULTS
+        if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
+        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
+                           (uint32_t)diag);
         FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     } else {
         const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);

@@ -1,0 +1,24 @@
+"""Profile helper: configs[2] training step only (run under rocprofv3 --kernel-trace --stats)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+dev = torch.device("cuda", 0)
+m2 = bench.build_model(2, dev, cuda_ray=True, seed=0).train()
+opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+sc2 = torch.amp.GradScaler("cuda")
+poses2, intr = bench.make_training_rays(dev, 2, 8, seed=0)
+gen = torch.Generator().manual_seed(1)
+b2 = [bench.sample_batch(poses2, intr, dev, gen) for _ in range(4)]
+for i in range(17):
+    bench.cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+    if i == 15:
+        m2.mean_count = int(m2.step_counter[:16, 0].sum().item() / 16)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 20
+for i in range(n):
+    bench.cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+torch.cuda.synchronize()
+print("ms/step", 1000 * (time.perf_counter() - t0) / n, "samples/step", float(m2.step_counter[:, 0].float().mean()))
