@@ -684,6 +684,129 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__
     }
 }
 
+// Point-major tile, level-sequential, LDS-sorted scatter. The plain point-major scatter above is bound by the number of store
+// REQUESTS: 268 M separate 8-byte stores per 2 M-point step, each a partial 64-byte-line write (measured 1.2 ms of its 1.5 ms;
+// with the stores removed it runs in 0.26 ms). Here a workgroup still owns GB_PM_TILE points (so the per-workgroup bases of
+// k_gbin_count_pm apply and the [B, L*C] gradient lines are reused across levels out of L1/L2), but it walks the levels one at a
+// time: the workgroup's record count per segment is the difference of two neighbouring per-workgroup bases, so the segment
+// prefix inside the LDS staging array is known up front; each record takes its place with one LDS cursor atomic, and the staging
+// array is copied out flat, so a wave stores 512 contiguous bytes. Two barriers per level; the bases of the next level are
+// fetched while the current one is ranked.
+// One point per thread (1024-thread workgroups, two per CU for fp16 tables): the point and its whole [L*C] gradient row are
+// loaded once, as full 64-byte lines, and stay in registers for the walk over the levels.
+#define GB_PMS_WG 1024u
+template <typename T>
+__global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
+    const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
+    const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
+    bool align_corners, uint32_t interp, uint32_t diag) {
+    static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
+    constexpr uint32_t NREC = GB_PM_TILE * 8u;
+    __shared__ uint32_t cur[2][GB_MAX_SEGS];               // next free staging position per segment (double-buffered by level parity)
+    __shared__ uint32_t pre[2][GB_MAX_SEGS + 1];           // first staging position per segment; [64] = records of this level
+    __shared__ uint32_t gb[2][GB_MAX_SEGS];                // this workgroup's first global record per segment
+    __shared__ uint32_t s_row[NREC];                       // local row | segment << 16
+    __shared__ uint32_t s_v0[NREC];
+    __shared__ uint32_t s_v1[sizeof(T) == 2 ? 1 : NREC];
+    const uint32_t n_wg = gridDim.x;
+    const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
+    float x[3] = {0.f, 0.f, 0.f};
+    const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
+    // gradient row of this point: fp16 -> one dword (half2) per level, fp32 -> two
+    constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
+    uint32_t gq[GE_MAX_LEVELS * GW];
+    {
+        const uint32_t *gp = reinterpret_cast<const uint32_t *>(grad + (uint64_t)(b < B ? b : 0u) * L * 2);
+        const bool vec = ((L * GW) & 3u) == 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < GE_MAX_LEVELS * GW; i += 4) {
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (i < L * GW) {
+                if (vec) t = *reinterpret_cast<const uint4 *>(gp + i);
+                else {
+                    t.x = gp[i];
+                    if (i + 1 < L * GW) t.y = gp[i + 1];
+                    if (i + 2 < L * GW) t.z = gp[i + 2];
+                    if (i + 3 < L * GW) t.w = gp[i + 3];
+                }
+            }
+            gq[i] = t.x; gq[i + 1] = t.y; gq[i + 2] = t.z; gq[i + 3] = t.w;
+        }
+    }
+    // wave 0 keeps the (base, end) pair of the level about to be processed in registers
+    uint32_t nb0 = 0, nb1 = 0;
+    auto fetch_bases = [&](uint32_t level) {
+        if (threadIdx.x < GB_MAX_SEGS && level < L) {
+            const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
+            nb0 = wg_base[(uint64_t)slot * n_wg + blockIdx.x];
+            nb1 = blockIdx.x + 1 < n_wg ? wg_base[(uint64_t)slot * n_wg + blockIdx.x + 1] : hdr->base[slot] + hdr->counts[slot];
+        }
+    };
+    fetch_bases(0);
+#pragma unroll
+    for (uint32_t level = 0; level < GE_MAX_LEVELS; level++) {
+        if (level < L) {
+        const uint32_t pb = level & 1u;
+        if (threadIdx.x < GB_MAX_SEGS) {
+            const uint32_t hc = nb1 - nb0;
+            const uint32_t incl = (uint32_t)wave_incl_sum_i((int)hc, (int)threadIdx.x);
+            pre[pb][threadIdx.x] = incl - hc;
+            cur[pb][threadIdx.x] = incl - hc;
+            gb[pb][threadIdx.x] = nb0;
+            if (threadIdx.x == GB_MAX_SEGS - 1) pre[pb][GB_MAX_SEGS] = incl;
+            fetch_bases(level + 1);
+        }
+        __syncthreads();
+        float g[2];
+        if constexpr (sizeof(T) == 2) {
+            g[0] = __half2float(__ushort_as_half((unsigned short)(gq[level] & 0xFFFFu)));
+            g[1] = __half2float(__ushort_as_half((unsigned short)(gq[level] >> 16)));
+        } else {
+            g[0] = __uint_as_float(gq[level * 2]); g[1] = __uint_as_float(gq[level * 2 + 1]);
+        }
+        if (inside && (g[0] != 0.0f || g[1] != 0.0f)) {
+            const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+            uint32_t rows[8]; float ws[8];
+            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
+                const uint32_t pos = (diag & 8u) ? (threadIdx.x * 8u + i) : atomicAdd(&cur[pb][seg], 1u);   // DIAGNOSTIC bit 3: no cursor atomics
+                if (pos >= NREC) continue;                 // cannot happen when count and scatter agree
+                s_row[pos] = (rows[i] & (GB_SEG - 1u)) | (seg << 16);
+                const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
+                if constexpr (sizeof(T) == 2) {
+                    const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                    s_v0[pos] = *reinterpret_cast<const uint32_t *>(&hv);
+                } else {
+                    s_v0[pos] = __float_as_uint(v0);
+                    s_v1[pos] = __float_as_uint(v1);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t total = (diag & 2u) ? 0u : min(pre[pb][GB_MAX_SEGS], NREC);   // DIAGNOSTIC bit 1: no copy-out
+        for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
+            const uint32_t rw = s_row[j];
+            const uint32_t seg = rw >> 16;
+            const uint64_t at = (uint64_t)gb[pb][seg] + (j - pre[pb][seg]);
+            if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
+            if ((diag & 1u) && rw != 0xDEADBEEFu) continue;   // DIAGNOSTIC timing build (FOC_GBIN_DIAG=1): no record stores, WRONG RESULTS
+            if constexpr (sizeof(T) == 2) {
+                reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rw & 0xFFFFu, s_v0[j]);
+            } else {
+                uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
+                float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
+                rr[at] = rw & 0xFFFFu;
+                vv[at] = make_float2(__uint_as_float(s_v0[j]), __uint_as_float(s_v1[j]));
+            }
+        }
+        // no barrier here: the next level's setup writes the other parity of cur/pre/gb, and its staging writes come after
+        // the barrier that follows the setup, which every thread reaches only once its copy-out loop is done
+        }
+    }
+}
+
 // LDS accumulation is done in DOUBLE: on gfx950 ds_add_f32 on random addresses runs ~23x slower than
 // ds_add_u32 (measured 101 vs 2349 G records/s, tools/bench_lds_atomic.hip) while ds_add_f64 runs at
 // 1823 G/s — so the fp32-quality sum is kept in a 128 KiB f64 image (one workgroup per CU).
@@ -1015,8 +1138,14 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
         static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no cursor atomics); WRONG RESULTS
         if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
-        hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
-                           (uint32_t)diag);
+        static int sorted_scatter = -1;          // FOC_GBIN_SORTED=0 selects the unsorted point-major scatter (tuning)
+        if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
+        if (sorted_scatter)
+            hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
+                               (uint32_t)diag);
+        else
+            hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
+                               (uint32_t)diag);
         FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     } else {
         const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
