@@ -214,8 +214,9 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     }
 }
 
-// Level-major launch, outputs [L,B,C]: thread = point, block decodes (level, chunk) XCD-aware.
-template <typename T, uint32_t D, uint32_t C>
+// Level-major launch, outputs [L,B,C] (or, OUT_BL, [B,L*C]): thread = point, block decodes (level, chunk) XCD-aware,
+// so a level's table (<= 2 MiB at 2^19 x half2) stays in the L2 of the one XCD that works on it.
+template <typename T, uint32_t D, uint32_t C, bool OUT_BL>
 __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                       const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                       uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ 
     const bool oob = ge_load_point<D>(inputs, b, x);
     T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
     ge_forward_one<T, D, C>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                            outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+                            OUT_BL ? outputs + ((uint64_t)b * L + level) * C : outputs + ((uint64_t)level * B + b) * C, dy, gridtype,
+                            align_corners, interp);
 }
 
 // Point-major launch, outputs [B, L*C]: consecutive lanes = consecutive levels of one point, so
@@ -997,14 +999,20 @@ static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * ch
 template <typename T, uint32_t D, uint32_t C>
 static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
                              const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
-    if (bl) {
+    static int level_major = -1;                 // FOC_GRID_FWD_LM=1: level-major XCD-affine kernel for the [B,L*C] output too (tuning)
+    if (level_major < 0) { const char *e = getenv("FOC_GRID_FWD_LM"); level_major = e ? atoi(e) : 0; }
+    if (bl && level_major) {
+        const uint32_t chunks = foc_div_up(B, 256);
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, true>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks);
+    } else if (bl) {
         const uint64_t total = (uint64_t)B * L;
         const uint32_t grid = (uint32_t)((total + 255) / 256 > 0x7FFFFFFFull ? 0x7FFFFFFFull : (total + 255) / 256);
         hipLaunchKernelGGL((k_grid_fwd_bl<T, D, C>), dim3(grid), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv,
                            (T *)dy_dx, gridtype, ac, interp);
     } else {
         const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, false>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
