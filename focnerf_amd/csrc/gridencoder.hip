@@ -392,12 +392,9 @@ template <typename T> struct GbRec;
 template <> struct GbRec<__half> { static constexpr uint32_t bytes = 8; };    // {u32 local row, half2}
 template <> struct GbRec<float> { static constexpr uint32_t bytes = 12; };    // u32 rows[] + float2 vals[]
 
-// corner rows of one (point, level): same arithmetic as ge_backward_one
+// cell and in-cell position of one (point, level): same arithmetic as ge_backward_one
 template <uint32_t D>
-__device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
-                                           bool align_corners, uint32_t interp, uint32_t (&rows)[1u << D], float (&ws)[1u << D]) {
-    float pos[D];
-    uint32_t pos_grid[D];
+__device__ __forceinline__ void gb_cell(const float (&x)[D], float scale, bool align_corners, uint32_t interp, uint32_t (&pos_grid)[D], float (&pos)[D]) {
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
@@ -405,18 +402,70 @@ __device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap
         pos[d] -= (float)pos_grid[d];
         if (interp == 1) { const float v = pos[d]; pos[d] = v * v * fmaf(-2.0f, v, 3.0f); }
     }
+}
+template <uint32_t D>
+__device__ __forceinline__ void gb_cell_rows(const uint32_t (&pos_grid)[D], uint32_t hashmap_size, uint32_t resolution, uint32_t gridtype,
+                                             bool align_corners, uint32_t (&rows)[1u << D]) {
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1u);
+        rows[idx] = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+    }
+}
+template <uint32_t D>
+__device__ __forceinline__ void gb_cell_weights(const float (&pos)[D], float (&ws)[1u << D]) {
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
         float w = 1;
-        uint32_t pgl[D];
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
-            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
-        }
+        for (uint32_t d = 0; d < D; d++) w *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
         ws[idx] = w;
-        rows[idx] = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
     }
+}
+// corner rows + weights of one (point, level)
+template <uint32_t D>
+__device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
+                                           bool align_corners, uint32_t interp, uint32_t (&rows)[1u << D], float (&ws)[1u << D]) {
+    float pos[D];
+    uint32_t pos_grid[D];
+    gb_cell<D>(x, scale, align_corners, interp, pos_grid, pos);
+    gb_cell_weights<D>(pos, ws);
+    gb_cell_rows<D>(pos_grid, hashmap_size, resolution, gridtype, align_corners, rows);
+}
+
+// ---- run merging (one-point-per-thread kernels) -------------------------------------------------
+// Consecutive points are consecutive samples of a ray, so at the coarser levels neighbouring lanes fall into the SAME cell and
+// address the same 8 rows (512 samples/ray: ~18 samples per cell at resolution 16, ~1 at 300). Within each aligned group of 16
+// lanes a run of lanes with equal cells is summed on the lanes (segmented DPP scan, fp32) and only the run's last lane emits
+// records. The count and the scatter kernel derive the run structure from the same values with the same code, so their record
+// counts agree by construction.
+#define GB_MERGE_MAX_RES 320u                  // levels above this resolution are not merged (cells < 2^10 per axis needed for the key)
+template <int CTRL>
+__device__ __forceinline__ uint32_t gb_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+struct GbRun { uint32_t f0, f1, f2, f3; bool tail; };       // f_k: "do not add from lane - 2^k" at scan step k
+__device__ __forceinline__ GbRun gb_run_flags(bool inside, const uint32_t (&pos_grid)[3]) {
+    const uint32_t r = threadIdx.x & 15u;
+    const uint32_t key = inside ? (pos_grid[0] | (pos_grid[1] << 10) | (pos_grid[2] << 20)) : 0xFFFFFFFFu;
+    const uint32_t prev = gb_dpp<0x111>(key);                               // row_shr:1
+    const uint32_t head = (r == 0u || key != prev || !inside) ? 1u : 0u;
+    GbRun run;
+    run.f0 = head;
+    run.f1 = run.f0 | gb_dpp<0x111>(run.f0);
+    run.f2 = run.f1 | gb_dpp<0x112>(run.f1);
+    run.f3 = run.f2 | gb_dpp<0x114>(run.f2);
+    const uint32_t next_head = gb_dpp<0x101>(head);                         // row_shl:1
+    run.tail = inside && (r == 15u || next_head != 0u);
+    return run;
+}
+__device__ __forceinline__ float gb_run_sum(float v, const GbRun &run) {
+    float u;
+    u = __uint_as_float(gb_dpp<0x111>(__float_as_uint(v))); v = run.f0 ? v : v + u;
+    u = __uint_as_float(gb_dpp<0x112>(__float_as_uint(v))); v = run.f1 ? v : v + u;
+    u = __uint_as_float(gb_dpp<0x114>(__float_as_uint(v))); v = run.f2 ? v : v + u;
+    u = __uint_as_float(gb_dpp<0x118>(__float_as_uint(v))); v = run.f3 ? v : v + u;
+    return v;
 }
 
 template <typename T, bool GRAD_BL>
@@ -686,6 +735,40 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__
     }
 }
 
+// One point per thread count pass, the partner of k_gbin_scatter_pms (same tile, same run merging).
+#define GB_PMS_WG 1024u
+__global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__restrict__ inputs, const int32_t *__restrict__ offsets, GbHeader *__restrict__ hdr,
+                                                             uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
+                                                             bool align_corners, uint32_t interp) {
+    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
+    const uint32_t nslots = L * GB_MAX_SEGS;
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_PMS_WG) hist[i] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
+    float x[3] = {0.f, 0.f, 0.f};
+    const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
+    for (uint32_t level = 0; level < L; level++) {
+        const uint32_t resolution = lv.resolution[level];
+        uint32_t pg[3]; float pf[3];
+        gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
+        bool emit = inside;
+        if (resolution <= GB_MERGE_MAX_RES) emit = gb_run_flags(inside, pg).tail;
+        if (emit) {
+            const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+            uint32_t rows[8];
+            gb_cell_rows<3>(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+#pragma unroll
+            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nslots; i += GB_PMS_WG) {
+        const uint32_t hcount = hist[i];
+        if (hcount) (void)__hip_atomic_fetch_add(&hdr->counts[i], hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wg_hist[(uint64_t)i * gridDim.x + blockIdx.x] = hcount;
+    }
+}
+
 // Point-major tile, level-sequential, LDS-sorted scatter. The plain point-major scatter above is bound by the number of store
 // REQUESTS: 268 M separate 8-byte stores per 2 M-point step, each a partial 64-byte-line write (measured 1.2 ms of its 1.5 ms;
 // with the stores removed it runs in 0.26 ms). Here a workgroup still owns GB_PM_TILE points (so the per-workgroup bases of
@@ -696,7 +779,6 @@ __global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__
 // fetched while the current one is ranked.
 // One point per thread (1024-thread workgroups, two per CU for fp16 tables): the point and its whole [L*C] gradient row are
 // loaded once, as full 64-byte lines, and stay in registers for the walk over the levels.
-#define GB_PMS_WG 1024u
 template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
@@ -766,23 +848,48 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         } else {
             g[0] = __uint_as_float(gq[level * 2]); g[1] = __uint_as_float(gq[level * 2 + 1]);
         }
-        if (inside && (g[0] != 0.0f || g[1] != 0.0f)) {
-            const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
-            uint32_t rows[8]; float ws[8];
-            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
+        if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
+        {
+            const uint32_t resolution = lv.resolution[level];
+            uint32_t pg[3]; float pf[3];
+            gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
+            float ws[8];
+            gb_cell_weights<3>(pf, ws);
+            uint32_t pv0[8], pv1[8];                       // record values: fp16 -> half2 bits in pv0; fp32 -> two floats
+            bool emit = inside;
+            if (resolution <= GB_MERGE_MAX_RES) {
+                const GbRun run = gb_run_flags(inside, pg);
+                emit = run.tail;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
-                const uint32_t pos = (diag & 8u) ? (threadIdx.x * 8u + i) : atomicAdd(&cur[pb][seg], 1u);   // DIAGNOSTIC bit 3: no cursor atomics
-                if (pos >= NREC) continue;                 // cannot happen when count and scatter agree
-                s_row[pos] = (rows[i] & (GB_SEG - 1u)) | (seg << 16);
-                const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
-                if constexpr (sizeof(T) == 2) {
-                    const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
-                    s_v0[pos] = *reinterpret_cast<const uint32_t *>(&hv);
-                } else {
-                    s_v0[pos] = __float_as_uint(v0);
-                    s_v1[pos] = __float_as_uint(v1);
+                for (int i = 0; i < 8; i++) {
+                    const float v0 = gb_run_sum(ws[i] * g[0], run), v1 = gb_run_sum(ws[i] * g[1], run);
+                    if constexpr (sizeof(T) == 2) {
+                        const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                        pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
+                    } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
+                    if constexpr (sizeof(T) == 2) {
+                        const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                        pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
+                    } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
+                }
+            }
+            if (emit) {
+                const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+                uint32_t rows[8];
+                gb_cell_rows<3>(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
+                    const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
+                    if (pos >= NREC) continue;             // cannot happen when count and scatter agree
+                    s_row[pos] = (rows[i] & (GB_SEG - 1u)) | (seg << 16);
+                    s_v0[pos] = pv0[i];
+                    if constexpr (sizeof(T) != 2) s_v1[pos] = pv1[i];
                 }
             }
         }
@@ -1138,16 +1245,19 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
         const dim3 grid(n_wg);
         uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
-        hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
+        static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no copy-out); WRONG RESULTS
+        if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
+        static int sorted_scatter = -1;          // FOC_GBIN_SORTED=0 selects the unsorted, unmerged point-major count/scatter pair (tuning)
+        if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
+        if (sorted_scatter)
+            hipLaunchKernelGGL(k_gbin_count_pt, grid, dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
+        else
+            hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
         FOC_CHECK_LAUNCH("grid_encode_backward(count)");
         hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
         FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
         hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
         FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
-        static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no cursor atomics); WRONG RESULTS
-        if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
-        static int sorted_scatter = -1;          // FOC_GBIN_SORTED=0 selects the unsorted point-major scatter (tuning)
-        if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
         if (sorted_scatter)
             hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
                                (uint32_t)diag);

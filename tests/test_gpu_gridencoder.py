@@ -126,6 +126,53 @@ def test_backward(case, dtype, atomic, monkeypatch):
                 np.testing.assert_allclose(got_sum, want_sum, atol=tol)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("n_samples", [512, 100])
+def test_backward_ray_coherent(dtype, n_samples):
+    """Consecutive points = consecutive samples of a ray: neighbouring lanes share cells on the coarse levels, which is what the
+    binned backward's run merging (csrc/gridencoder.hip, gb_run_flags) acts on. Ragged batch (not a multiple of 1024 or 16),
+    out-of-range samples inside the runs, zero gradients, axis-parallel rays (very long runs)."""
+    D, C, L, H, lh, desired, gridtype, ac, interp = CASES[0]
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, dtype)
+    rng = np.random.default_rng(21)
+    n_rays = 9
+    o = rng.random((n_rays, 1, 3)).astype(np.float32) * 0.2
+    d = rng.random((n_rays, 1, 3)).astype(np.float32)
+    d[1] = (1.0, 0.0, 0.0)                                    # axis-parallel: every coarse-level run hits the 16-lane cap
+    d[2] = (0.0, 0.0, 0.0)                                    # a ray of identical points
+    t = np.linspace(0.0, 0.85, n_samples, dtype=np.float32)[None, :, None]
+    x = (o + d * t).reshape(-1, 3)[:-37].copy()               # ragged tail
+    B = x.shape[0]
+    x[5::97] = -0.25                                          # out-of-range samples break runs and emit nothing
+    x[200:260, 1] = 1.5
+    grad = (rng.standard_normal((L, B, C)) * 0.1).astype(dtype)
+    grad[:, 300:340] = 0
+    # expected sums in fp32 from the same (half-valued) gradients: the oracle's fp16 mode rounds its running sum at every add like the
+    # reference's half2 atomics, which for 512 addends per row says more about that rounding than about the kernel under test
+    ge_ref = oracle.grid_encode_backward(grad.astype(np.float32), x, off, int(off[-1]), D, C, L, S, H, None, gridtype, ac, interp)
+    tdt = torch.float32 if dtype == np.float32 else torch.float16
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    g = torch.from_numpy(grad).cuda().permute(1, 0, 2).reshape(B, L * C).contiguous()
+    ge = torch.zeros(int(off[-1]), C, dtype=tdt, device="cuda")
+    _be().grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=True)
+    got, want = to_np(ge).astype(np.float32), ge_ref.astype(np.float32)
+    if dtype == np.float32:
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
+    else:
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-3 * scale + 1e-3
+    inb = np.all((x >= 0) & (x <= 1), axis=1)
+    for l in range(L):
+        want_sum = grad[l][inb].astype(np.float64).sum(0)
+        got_sum = got[off[l]:off[l + 1]].astype(np.float64).sum(0)
+        np.testing.assert_allclose(got_sum, want_sum, atol=1e-3 if dtype == np.float32 else 0.5)
+    # deterministic: a second launch gives the same bits (fixed-point / f64 LDS sums, ordered record ranges)
+    ge2 = torch.zeros_like(ge)
+    _be().grid_encode_backward(g, xt, tt, ot, ge2, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=True)
+    if dtype == np.float16:
+        assert torch.equal(ge, ge2)
+
+
 def test_grid_encode_autograd_and_module():
     """GridEncoder module: fp32 and autocast(fp16) paths, both kernel layouts, gradients w.r.t. table and inputs."""
     import os
