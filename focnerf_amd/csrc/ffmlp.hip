@@ -70,10 +70,10 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
 //   output layer : Wout[r][chain_k(kc, h, j)]  for r < 16, else 0
 // Fragment order: layer0 [mt][kc0] | hidden layers [l][mt][kc] | out [kc].
 template <int HIDDEN>
-__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers) {
+__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_out = true) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const uint32_t KS0 = in_dim / 16;
-    const uint32_t n0 = MT * KS0, nh = (num_layers - 1) * MT * KC, total = n0 + nh + KC;
+    const uint32_t n0 = MT * KS0, nh = (num_layers - 1) * MT * KC, total = n0 + nh + (with_out ? KC : 0);
     const _Float16 *Wh = W + (size_t)HIDDEN * in_dim;
     const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
     for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
@@ -486,7 +486,13 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 //   the same A_s tile is the ReLU mask of the next delta, which chains in registers exactly as in k_mlp_bwd; barrier.
 // HBM traffic drops to grad + forward activations + inputs (+ grad_inputs): ~0.4 KB/sample, and backward_buffer is only written
 // if the caller asks for it. Compile-time layer count (the stage loop must unroll for the accumulators to stay in registers).
-template <int HIDDEN, int NL, int NB>
+//
+// RECOMP (forward_buffer == NULL at the ABI): the forward pass stored no activations; each wave re-evaluates the hidden layers of
+// its 32 rows from the inputs first — the same MFMA sequence as k_mlp_fwd, so the activations are the bits the forward pass saw —
+// and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
+// where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
+// and input rows are fetched while the current group is processed.
+template <int HIDDEN, int NL, int NB, bool RECOMP>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
@@ -499,6 +505,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
     _Float16 *sD = lds + lds_w_halfs;                    // [4][RW][WD]
     _Float16 *sA = sD + 4 * RW * WD;                     // [4][RW][WA]
+    _Float16 *ldsF = sA + 4 * RW * WA;                   // RECOMP: forward weight image (layer 0 + hidden matrices)
+    if constexpr (RECOMP) stage_weights_fwd<HIDDEN>(weights, ldsF, in_dim, NL, false);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,10 +524,89 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 
     const uint32_t rows_per_group = 4 * RW;
     const uint32_t n_groups = (B + rows_per_group - 1) / rows_per_group;
+    constexpr int KS0M = 4;                              // in_dim <= 64 on this path
+    const uint32_t KS0 = in_dim / 16;
+    // RECOMP: this wave's grad rows (D_0 tile order) and input rows (layer-0 B operand order) of the group about to be processed
+    h8 g_nxt[(RW * 2 + 63) / 64];
+    h8 x_nxt[KS0M][NB];
+    auto fetch_group = [&](uint32_t grp) {
+        const uint64_t r0 = (uint64_t)grp * rows_per_group + wave * RW;
+#pragma unroll
+        for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
+            const uint32_t idx = lane + 64 * it, rr = idx >> 1, cc = (idx & 1) * 8;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < RW * 2 && r0 + rr < B) v = *reinterpret_cast<const h8 *>(grad + (r0 + rr) * 16 + cc);
+            g_nxt[it] = v;
+        }
+#pragma unroll
+        for (int kc = 0; kc < KS0M; kc++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if ((uint32_t)kc < KS0) v = *reinterpret_cast<const h8 *>(inputs + min(r0 + nb * 32 + c, (uint64_t)B - 1) * in_dim + 16 * kc + 8 * h);
+                x_nxt[kc][nb] = v;
+            }
+    };
+    if constexpr (RECOMP) { if (blockIdx.x < n_groups) fetch_group(blockIdx.x); }
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const uint64_t row0 = (uint64_t)grp * rows_per_group + wave * RW;     // this wave's first row
         f16v acc[MT][NB];
         h8 bf[KC][NB];
+        h8 fa[RECOMP ? NL : 1][KC][NB];                  // RECOMP: post-activation of forward layer l, chained layout
+        h8 g_cur[(RW * 2 + 63) / 64];
+        h8 x_cur[KS0M][NB];
+        if constexpr (RECOMP) {
+#pragma unroll
+            for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) g_cur[it] = g_nxt[it];
+#pragma unroll
+            for (int kc = 0; kc < KS0M; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) x_cur[kc][nb] = x_nxt[kc][nb];
+            if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
+            // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+#pragma unroll
+            for (int kc = 0; kc < KS0M; kc++) {
+                if ((uint32_t)kc < KS0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const h8 a = ld_frag(ldsF, mt * KS0 + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], acc[mt][nb]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+                        fa[l][kc][nb] = relu ? acc_to_frag<true>(acc[kc >> 1][nb], kc & 1) : acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+                if (l + 1 < NL) {
+                    const uint32_t fbase = MT * KS0 + l * MT * KC;
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                            for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) {
+                            const h8 a = ld_frag(ldsF, fbase + mt * KC + kc, lane);
+#pragma unroll
+                            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, fa[l][kc][nb], acc[mt][nb]);
+                        }
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s <= NL; s++) {
             const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN;
@@ -527,11 +614,19 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             const _Float16 *Ap = s < NL ? fwd_buf + (uint64_t)(NL - 1 - s) * B * HIDDEN : inputs;
             // ---- D_s tile of this wave -> LDS
             if (s == 0) {
-                for (uint32_t idx = lane; idx < RW * 2; idx += 64) {
-                    const uint32_t rr = idx >> 1, cc = (idx & 1) * 8;
-                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(grad + (row0 + rr) * 16 + cc);
-                    *reinterpret_cast<h8 *>(myD + rr * WD + cc) = v;
+                if constexpr (RECOMP) {
+#pragma unroll
+                    for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
+                        const uint32_t idx = lane + 64 * it, rr = idx >> 1, cc = (idx & 1) * 8;
+                        if (idx < RW * 2) *reinterpret_cast<h8 *>(myD + rr * WD + cc) = g_cur[it];
+                    }
+                } else {
+                    for (uint32_t idx = lane; idx < RW * 2; idx += 64) {
+                        const uint32_t rr = idx >> 1, cc = (idx & 1) * 8;
+                        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(grad + (row0 + rr) * 16 + cc);
+                        *reinterpret_cast<h8 *>(myD + rr * WD + cc) = v;
+                    }
                 }
             } else {
                 // delta of forward layer NL-s: acc, already masked; rounded to fp16 (what the reference stores in backward_buffer)
@@ -557,12 +652,34 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) bf[kc][nb] = acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
             }
-            // ---- A_s tile of this wave -> LDS (rows past B as zeros: they must not reach dW)
-            for (uint32_t idx = lane; idx < RW * (IN / 8); idx += 64) {
-                const uint32_t rr = idx / (IN / 8), cc = (idx % (IN / 8)) * 8;
-                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
-                *reinterpret_cast<h8 *>(myA + rr * WA + cc) = v;
+            // ---- A_s tile of this wave -> LDS
+            if constexpr (RECOMP) {
+                // from registers; rows past B hold values computed from a clamped (finite) input row and meet all-zero rows of D_s
+                if (s < NL) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) {
+                            const h8 v = fa[NL - 1 - s][kc][nb];
+                            _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 4 * h;
+                            *reinterpret_cast<h4 *>(dst) = h4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<h4 *>(dst + 8) = h4{v[4], v[5], v[6], v[7]};
+                        }
+                } else {
+#pragma unroll
+                    for (int kc = 0; kc < KS0M; kc++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+                            if ((uint32_t)kc < KS0) *reinterpret_cast<h8 *>(myA + (nb * 32 + c) * WA + 16 * kc + 8 * h) = x_cur[kc][nb];
+                }
+            } else {
+                // rows past B as zeros: they must not reach dW
+                for (uint32_t idx = lane; idx < RW * (IN / 8); idx += 64) {
+                    const uint32_t rr = idx / (IN / 8), cc = (idx % (IN / 8)) * 8;
+                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (row0 + rr < B) v = *reinterpret_cast<const h8 *>(Ap + (row0 + rr) * IN + cc);
+                    *reinterpret_cast<h8 *>(myA + rr * WA + cc) = v;
+                }
             }
             __syncthreads();
             // ---- dW_s: output tile `wave` (MTo x NTi tiles, at most 4 for HIDDEN, in_dim <= 64)
@@ -650,9 +767,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                         for (int q = 0; q < 4; q++) {
                             const uint32_t col = 32 * mt + 8 * q + 4 * h;
                             if (col < HIDDEN) {
-                                const h4 f = *reinterpret_cast<const h4 *>(myA + (nb * 32 + c) * WA + col);
+                                if constexpr (RECOMP) {
+                                    // neuron 32mt + 8q + 4h + e = chain_k(2mt + (q>>1), h, 4(q&1) + e)
 #pragma unroll
-                                for (int e = 0; e < 4; e++) if (!(f[e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
+                                    for (int e = 0; e < 4; e++)
+                                        if (!(fa[NL - 1 - s][2 * mt + (q >> 1)][nb][4 * (q & 1) + e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
+                                } else {
+                                    const h4 f = *reinterpret_cast<const h4 *>(myA + (nb * 32 + c) * WA + col);
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) if (!(f[e] > (_Float16)0)) acc[mt][nb][4 * q + e] = 0.0f;
+                                }
                             }
                         }
             }
@@ -757,9 +881,11 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const bool dx = grad_inputs != nullptr;
     const size_t lds_w = mlp_bwd_lds<HIDDEN>(in_dim, NL, dx);
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
-    const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16);
+    const bool recomp = fwd_buf == nullptr;
+    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
-    auto kern = k_mlp_bwd_fused<HIDDEN, NL, NB>;
+    auto kern = recomp ? k_mlp_bwd_fused<HIDDEN, NL, NB, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
     if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
@@ -790,7 +916,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
             }
         }
     }
-    FOC_REQUIRE(bwd_buf, FOC_E_INVALID, "ffmlp_backward: backward_buffer is required for this shape (two-kernel path)");
+    FOC_REQUIRE(bwd_buf && fwd_buf, FOC_E_INVALID, "ffmlp_backward: forward_buffer and backward_buffer are required for this shape (two-kernel path)");
     constexpr int NB = 2;
     const bool dx = grad_inputs != nullptr;
     const size_t lds = mlp_bwd_lds<HIDDEN>(in_dim, num_layers, dx);
@@ -825,6 +951,8 @@ extern "C" {
 
 int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                       uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *forward_buffer, void *outputs, void *stream) {
+    // forward_buffer == NULL: nothing is kept for the backward pass (foc_ffmlp_backward re-evaluates the activations)
+    if (!forward_buffer) return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream);
     return mlp_fwd<true>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs, stream);
 }
 
@@ -840,8 +968,9 @@ uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
-    // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip (the two-kernel path checks it again)
-    FOC_REQUIRE(grad && inputs && weights && forward_buffer && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
+    // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip; forward_buffer may be NULL: the fused kernel
+    // then re-evaluates the activations from the inputs (the two-kernel path checks both again)
+    FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
     FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
     int rc = mlp_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc) return rc;

@@ -18,6 +18,11 @@ from torch.amp import custom_bwd, custom_fwd
 from .backend import _ffmlp as _backend
 
 
+def _fused_backward_ok(input_dim, hidden_dim, num_layers):
+    """Shapes served by the single-pass backward kernel (csrc/ffmlp.hip, k_mlp_bwd_fused)."""
+    return hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4 and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0"
+
+
 class _ffmlp_forward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
@@ -28,7 +33,11 @@ class _ffmlp_forward(Function):
         weights = weights.contiguous()
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if not inference:
-            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            # The reference keeps every hidden activation for the backward pass ([num_layers, B, hidden], ffmlp.py:31). For the
+            # shapes the fused backward kernel covers it re-evaluates them on chip from `inputs` instead (same MFMA sequence, same
+            # bits), so nothing is written here and nothing is read back there; FOC_MLP_RECOMPUTE=0 keeps the stored form.
+            recompute = _fused_backward_ok(input_dim, hidden_dim, num_layers) and os.environ.get("FOC_MLP_RECOMPUTE", "1") != "0"
+            forward_buffer = None if recompute else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                                    forward_buffer, outputs)
             ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
@@ -53,7 +62,7 @@ class _ffmlp_forward(Function):
         grad_weights = torch.empty_like(weights)
         # The fused backward keeps the activation gradients on chip; the [num_layers, B, hidden] buffer the reference allocates
         # (ffmlp.py:73) is only needed by the two-kernel fallback (hidden_dim 128, input_dim > 64 or num_layers > 4).
-        fused_ok = hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4 and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0"
+        fused_ok = _fused_backward_ok(input_dim, hidden_dim, num_layers)
         backward_buffer = None if fused_ok else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                 output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)

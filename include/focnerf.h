@@ -217,7 +217,10 @@ int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B
  * ------------------------------------------------------------------------- */
 
 /* ffmlp.cu:635-671  ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers,
- *       activation, output_activation, forward_buffer [num_layers,B,hidden], outputs) */
+ *       activation, output_activation, forward_buffer [num_layers,B,hidden], outputs)
+ * forward_buffer may be NULL: no activations are kept (outputs are the same bits); pass NULL
+ * to foc_ffmlp_backward as well and it re-evaluates them from `inputs` on chip (hidden_dim <= 64,
+ * input_dim <= 64, num_layers 2..4 — the shapes of the fused backward kernel). */
 int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                       uint32_t activation, uint32_t output_activation,
@@ -232,6 +235,8 @@ int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uin
 /* ffmlp.cu:749-895  ffmlp_backward(grad [B,16], inputs, weights, forward_buffer, B, input_dim,
  *       output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs,
  *       backward_buffer [num_layers,B,hidden], grad_inputs [B,input_dim], grad_weights (blob))
+ * forward_buffer NULL: see foc_ffmlp_forward. backward_buffer may be NULL for the same shapes (the
+ * activation gradients then never leave the chip); other shapes need both (FOC_E_INVALID otherwise).
  * workspace: device fp32, foc_ffmlp_backward_workspace_bytes() bytes, caller-owned; holds
  * the fp32 split-K partial sums of the weight gradients (the reference's CUTLASS split-K
  * workspace, cutlass_matmul.h:335-363, is a process-global map instead). */

@@ -223,3 +223,60 @@ def test_ragged_batch_matches_oracle(B):
     assert_half_close(to_np(bbv), bb_r, ulps=6, atol=2e-4, what="backward_buffer")
     assert_half_close(to_np(gi[:B]), gi_r, ulps=8, atol=5e-4, what="grad_inputs")
     assert_half_close(to_np(gw), gw_r, ulps=4.0, atol=2e-3, what="grad_weights")
+
+
+@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (16, 16, 2), (64, 64, 4)])
+@pytest.mark.parametrize("B", [1000, 128 * 300 + 17])
+@pytest.mark.parametrize("act", [0, 6])
+def test_backward_recompute_is_bit_identical(I, Hd, nl, B, act):
+    """forward_buffer = NULL at the C ABI: the forward stores no activations and the fused backward re-evaluates them from
+    the inputs. Same MFMA sequence as the forward kernel -> activations, masks, backward_buffer, grad_inputs are the same bits;
+    grad_weights are fp32 sums of the same products (atomics across workgroups: order may differ in the last fp32 bit)."""
+    be = _be()
+    rng = np.random.default_rng(I + Hd + nl + B)
+    W = (rng.uniform(-1, 1, _n_params(I, Hd, nl)) * math.sqrt(3 / Hd)).astype(np.float16)
+    x = rng.standard_normal((B, I)).astype(np.float16)
+    g = (rng.standard_normal((B, 16)) * 0.05).astype(np.float16)
+    t = lambda a: torch.from_numpy(a).cuda()
+    xt, Wt, gt = t(x), t(W), t(g)
+    out_s = torch.empty(B, 16, dtype=torch.float16, device="cuda")
+    fb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
+    be.ffmlp_forward(xt, Wt, B, I, 16, Hd, nl, act, 6, fb, out_s)
+    out_r = torch.empty_like(out_s)
+    be.ffmlp_forward(xt, Wt, B, I, 16, Hd, nl, act, 6, None, out_r)
+    assert torch.equal(out_s, out_r)
+    res = {}
+    for name, buf in (("stored", fb), ("recompute", None)):
+        bb = torch.full((nl, B, Hd), 3.0, dtype=torch.float16, device="cuda")
+        gi = torch.full((B + 8, I), 7.0, dtype=torch.float16, device="cuda")
+        gw = torch.empty(W.size, dtype=torch.float16, device="cuda")
+        be.ffmlp_backward(gt, xt, Wt, buf, B, I, 16, Hd, nl, act, 6, True, bb, gi[:B], gw)
+        assert torch.all(gi[B:] == 7.0)
+        res[name] = (bb, gi[:B].clone(), gw)
+    assert torch.equal(res["stored"][0], res["recompute"][0]), "backward_buffer"
+    assert torch.equal(res["stored"][1], res["recompute"][1]), "grad_inputs"
+    # fp32 atomics from ~1000 workgroups in arbitrary order: absolute error scales with the magnitude of the partial sums
+    gw_tol = 5e-4 * max(1.0, float(res["stored"][2].float().abs().max()))
+    assert_half_close(to_np(res["recompute"][2]), to_np(res["stored"][2]), ulps=2.0, atol=gw_tol, what="grad_weights")
+    # and without backward_buffer / grad_inputs
+    gw2 = torch.empty(W.size, dtype=torch.float16, device="cuda")
+    be.ffmlp_backward(gt, xt, Wt, None, B, I, 16, Hd, nl, act, 6, False, None, torch.zeros(1, dtype=torch.float16, device="cuda"), gw2)
+    assert_half_close(to_np(gw2), to_np(res["stored"][2]), ulps=2.0, atol=gw_tol, what="grad_weights (no dx)")
+
+
+def test_module_recompute_env(monkeypatch):
+    """FFMLP autograd through both storage policies gives the same gradients."""
+    from focnerf_amd.ffmlp import FFMLP
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FOC_MLP_RECOMPUTE", mode)
+        net = FFMLP(32, 3, 64, 3).cuda().train()
+        torch.manual_seed(5)
+        x = torch.randn(777, 32, device="cuda", dtype=torch.float16, requires_grad=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = net(x)
+        (y.float() ** 2).sum().backward()
+        grads[mode] = (x.grad.clone(), net.weights.grad.clone(), y.detach().clone())
+    assert torch.equal(grads["1"][2], grads["0"][2])
+    assert torch.equal(grads["1"][0], grads["0"][0])
+    assert torch.allclose(grads["1"][1], grads["0"][1], rtol=2e-3, atol=1e-4)
