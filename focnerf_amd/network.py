@@ -4,6 +4,8 @@ nerf/network_ff.py:10-148 (sigma-net 32->64->64->16 with trunc_exp on channel 0,
 The reference file cannot be constructed from its own tree (it imports the missing `encoding`
 module); with focnerf_amd/dropin on PYTHONPATH it can.
 """
+import os
+
 import torch
 
 from .activation import trunc_exp
@@ -28,7 +30,21 @@ class NeRFNetwork(NeRFRenderer):
         self.in_dim_color += self.geo_feat_dim + 1   # pad to 32 (network_ff.py:44)
         self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=self.hidden_dim_color, num_layers=self.num_layers_color)
 
+    def _fused_head_ok(self, x):
+        """The fused glue of csrc/head.hip covers the FOC default shapes: degree-4 SH directions, 15 geometry features,
+        both MLPs on FFMLP with 16-wide padded outputs, fp16 autocast, flat [M,3] CUDA inputs."""
+        from .shencoder import SHEncoder
+        return (x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and self.geo_feat_dim == 15
+                and isinstance(self.encoder_dir, SHEncoder) and getattr(self.encoder_dir, "degree", 0) == 4
+                and isinstance(self.sigma_net, FFMLP) and isinstance(self.color_net, FFMLP) and self.in_dim_color == 32
+                and os.environ.get("FOC_FUSED_HEAD", "1") != "0")
+
     def forward(self, x, d):
+        if self._fused_head_ok(x):
+            from .head import sample_head, rgb_head
+            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))     # [M,16] half
+            sigma, cin = sample_head(h, d)
+            return sigma, rgb_head(self.color_net.forward_padded(cin))
         x = self.encoder(x, bound=self.bound)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])

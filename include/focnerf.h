@@ -313,6 +313,24 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
                                  const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
                                  void *grad_c, float *grad_w, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Per-sample network glue for callers with arbitrary sample lists (the occupancy-grid paths): the torch
+ * expressions of nerf/network_ff.py:51-75 between the sigma network, the SH-encoded direction and the
+ * colour network. No reference binding (the reference runs them as ~25 torch kernels per call).
+ * ------------------------------------------------------------------------- */
+
+/* h [M,16] fp16 = sigma-net output, dirs [M,3] fp32. sigma [M] fp32 = trunc_exp(h[:,0]) (activation.py:8-13);
+ * cin [M,32] fp16 = [SH degree 4 of dir | h[:,1:16] | 0] (network_ff.py:62-68). sigma or cin may be NULL. */
+int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, void *stream);
+/* grad_sigma [M] fp32, grad_cin [M,32] fp16 (either may be NULL) -> grad_h [M,16] fp16
+ * (column 0: grad_sigma * exp(clamp(h0,-15,15)), activation.py:16-18; columns 1..15: grad_cin[:,16:31]). */
+int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M,
+                             void *grad_h, void *stream);
+/* c [M,16] fp16 = colour-net output -> rgb [M,3] fp32 = sigmoid(c[:, :3]) rounded to fp16 (network_ff.py:73). */
+int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream);
+/* grad_rgb [M,3] fp32 -> grad_c [M,16] fp16 (columns 3..15 zero). */
+int foc_rgb_head_backward(const void *c, const float *grad_rgb, uint64_t M, void *grad_c, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

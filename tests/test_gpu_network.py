@@ -115,3 +115,38 @@ def test_fixed_step_run_matches_oracle_composite():
     im4, dp = composite_fixed_steps(res["densities"].squeeze(-1).float().contiguous(), res["rgbs"].float().contiguous(), nears, fars, 1.0)
     np.testing.assert_allclose(to_np(im4)[hit], np.clip(img4[hit], 0, 1), atol=1e-4)
     np.testing.assert_allclose(to_np(dp)[hit], depth[hit], atol=1e-4)
+
+
+def test_fused_head_matches_torch_glue(monkeypatch):
+    """NeRFNetwork.forward through csrc/head.hip (sample_head / rgb_head) against the torch expressions of
+    nerf/network_ff.py:51-75 that it replaces: same sigma and rgb, same parameter gradients."""
+    m = _model(1, False).train()
+    B = 5000 + 37
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(B, 3, device="cuda", generator=gen) * 2 - 1
+    d = torch.randn(B, 3, device="cuda", generator=gen)
+    d = d / d.norm(dim=-1, keepdim=True)
+    w_s = torch.rand(B, device="cuda", generator=gen)
+    w_c = torch.rand(B, 3, device="cuda", generator=gen)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FOC_FUSED_HEAD", mode)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = m(x, d)
+        assert sigma.dtype == torch.float32 and sigma.shape == (B,) and rgb.shape == (B, 3)
+        ((sigma * w_s).sum() * 1e-2 + (rgb.float() * w_c).sum()).backward()
+        out[mode] = (sigma.detach().clone(), rgb.detach().float().clone(), m.sigma_net.weights.grad.clone(), m.color_net.weights.grad.clone(),
+                     m.encoder.embeddings.grad.clone())
+    a, b = out["1"], out["0"]
+    assert torch.allclose(a[0], b[0], rtol=2e-6, atol=0), "sigma = exp(h0) in fp32"
+    assert torch.equal(a[1], b[1]), "rgb: half-rounded sigmoid"
+    for k, name in ((2, "sigma_net"), (3, "color_net"), (4, "embeddings")):
+        scale = b[k].abs().max().item()
+        assert (a[k] - b[k]).abs().max().item() <= 4e-3 * scale + 1e-6, name
+    # inference mode gives the same values as training mode
+    m.eval()
+    monkeypatch.setenv("FOC_FUSED_HEAD", "1")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s2, r2 = m(x, d)
+    assert torch.equal(s2, a[0]) and torch.equal(r2.float(), a[1])
