@@ -308,7 +308,11 @@ def main():
         result["kernels"] = {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "share_of_step": round(v["total_ms"] / (1000.0 * el), 4)}
                              for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])}
 
-    if not args.no_extras:
+    from focnerf_amd import synthetic
+    rays_o, rays_d = synthetic.get_rays(poses[:1], intr, VIEW, VIEW)
+    # single-GPU properties (other paths of the same object) are reported at N = 1 only; the multi-rank runs keep to the headline
+    # step plus the one exchange step the path has (combine), so that no rank-local failure can leave the others in a collective
+    if not args.no_extras and world == 1:
         # ---- the same step through the reference caller's torch glue (NeRFRenderer.run) instead of the fused kernels
         if fused:
             for i in range(3):
@@ -323,9 +327,7 @@ def main():
             result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
                                          "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
         # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
-        from focnerf_amd import synthetic
         model.eval()
-        rays_o, rays_d = synthetic.get_rays(poses[:1], intr, VIEW, VIEW)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             model.render(rays_o[:, :8192], rays_d[:, :8192], staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
             barrier()
@@ -375,7 +377,9 @@ def main():
         result["render_occupancy"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel2, "unit": "rays/s",
                                       "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2"}
 
+    if not args.no_extras:
         # ---- configs[3]/[4]: per-sample multi-object combine, one object per rank (RCCL MAX all-reduce of keys + SUM of the winner's rgb)
+        model.eval()
         try:
             from focnerf_amd.combine import ObjectCombiner
             from focnerf_amd import raymarching as rm
