@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--render-views", type=int, default=1)
+    ap.add_argument("--render-views", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the render / occupancy-path extras")
     ap.add_argument("--no-fused", action="store_true", help="headline step through the torch glue of NeRFRenderer.run instead of csrc/fixedstep.hip")
@@ -329,7 +329,8 @@ def main():
         # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
         model.eval()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            model.render(rays_o[:, :8192], rays_d[:, :8192], staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
+            # one untimed full view first: the caching allocator sizes its blocks for the view's chunk shapes
+            model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.render_views):
@@ -367,7 +368,7 @@ def main():
         m2.eval()
         ro2, rd2 = synthetic.get_rays(poses2[:1], intr, VIEW, VIEW)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            m2.render(ro2[:, :65536], rd2[:, :65536], staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4)
+            m2.render(ro2, rd2, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4, device_compaction=True)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.render_views):

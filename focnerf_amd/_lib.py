@@ -60,6 +60,8 @@ SIGNATURES = {
     "foc_ffmlp_backward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32,
                                  c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_ffmlp_backward_workspace_bytes": (u64, [u32, u32, u32]),
+    "foc_ffmlp_forward_planar": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp]),
+    "foc_ffmlp_backward_planar": (i32, [c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32, c_vp, c_vp, c_vp, c_vp]),
     "foc_allocate_splitk": (i32, [u64]),
     "foc_free_splitk": (i32, []),
     "foc_combine_select": (i32, [c_vp, c_vp, c_vp, c_vp, u64, c_vp]),

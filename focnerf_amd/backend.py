@@ -235,6 +235,23 @@ class _ffmlp:
                                      ptr(grad_weights), ptr(ws), stream_of(grad)), "ffmlp_backward")
 
     @staticmethod
+    def ffmlp_forward_planar(inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, outputs):
+        """inputs_planar: [input_dim/2, B, 2] half — the encoder's native [L,B,C] output (include/focnerf.h)."""
+        require_cuda(inputs_planar, weights, outputs); _half(inputs_planar, weights, outputs); _contig(inputs_planar, weights, outputs)
+        check(lib.foc_ffmlp_forward_planar(ptr(inputs_planar), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                           output_activation, ptr(outputs), stream_of(inputs_planar)), "ffmlp_forward_planar")
+
+    @staticmethod
+    def ffmlp_backward_planar(grad, inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                              calc_grad_inputs, grad_inputs_planar, grad_weights):
+        ts = (grad, inputs_planar, weights, grad_inputs_planar, grad_weights)
+        require_cuda(*ts); _half(*ts); _contig(*ts)
+        ws = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), grad.device)
+        check(lib.foc_ffmlp_backward_planar(ptr(grad), ptr(inputs_planar), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
+                                            activation, output_activation, int(bool(calc_grad_inputs)), ptr(grad_inputs_planar),
+                                            ptr(grad_weights), ptr(ws), stream_of(grad)), "ffmlp_backward_planar")
+
+    @staticmethod
     def allocate_splitk(size):
         check(lib.foc_allocate_splitk(int(size)), "allocate_splitk")
 

@@ -63,6 +63,15 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
     return r;
 }
 
+// Planar network inputs: [in_dim/2][B] dwords (half2), i.e. the hash-grid encoder's native [L, B, C=2] output (gridencoder.cu:218)
+// read without the permute to [B, L*C]. Element (row, 16kc + 8h + 2j + {0,1}) lives in plane 8kc + 4h + j; for one j the 32 lanes
+// of a lane-half read 128 contiguous bytes.
+__device__ __forceinline__ h8 ld_planar8(const _Float16 *__restrict__ base, uint64_t B, uint64_t row, uint32_t kc, int h) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(base) + (uint64_t)(8 * kc + 4 * h) * B + row;
+    const u32x4 v = {p[0], p[B], p[2 * B], p[3 * B]};
+    return __builtin_bit_cast(h8, v);
+}
+
 // ---------------------------------------------------------------- weight staging
 // Forward image. Fragment f holds, for lane (r = lane&31, h = lane>>5), the 8 halfs
 //   layer 0      : W0[32*mt + r][16*kc + 8*h + j]                       (natural k: B comes from global inputs)
@@ -172,7 +181,7 @@ __device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t 
 template <int HIDDEN, int NB, bool TRAIN>
 __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
                                                        _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
-                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu) {
+                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu, int planar) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
@@ -199,8 +208,10 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restric
         for (uint32_t kc = 0; kc < KS0; kc++) {
             h8 b[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                b[nb] = *reinterpret_cast<const h8 *>(inputs + min(row0 + nb * 32 + c, (uint64_t)B - 1) * in_dim + 16 * kc + 8 * h);
+            for (int nb = 0; nb < NB; nb++) {
+                const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
+                b[nb] = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
@@ -496,7 +507,7 @@ template <int HIDDEN, int NL, int NB, bool RECOMP>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
-                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs) {
+                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs, int planar) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -543,7 +554,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
                 h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if ((uint32_t)kc < KS0) v = *reinterpret_cast<const h8 *>(inputs + min(r0 + nb * 32 + c, (uint64_t)B - 1) * in_dim + 16 * kc + 8 * h);
+                if ((uint32_t)kc < KS0) {
+                    const uint64_t row = min(r0 + nb * 32 + c, (uint64_t)B - 1);
+                    v = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
+                }
                 x_nxt[kc][nb] = v;
             }
     };
@@ -755,7 +769,27 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                         for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], x[nb]);
                     }
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
+                    for (int nb = 0; nb < NB; nb++) {
+                        if (RECOMP && planar) {
+                            // [in_dim/2][B] half2 planes (the encoder's [L,B,C] gradient layout): register quad q = features 32mt0 + 8q + 4h .. +3
+                            const uint64_t row = row0 + nb * 32 + c;
+                            if (row < B) {
+                                uint32_t *gp = reinterpret_cast<uint32_t *>(grad_inputs);
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const uint32_t col = 32 * mt0 + 8 * q + 4 * h;
+                                    if (col < in_dim) {
+                                        const h4 v = {(_Float16)x[nb][4 * q], (_Float16)x[nb][4 * q + 1], (_Float16)x[nb][4 * q + 2], (_Float16)x[nb][4 * q + 3]};
+                                        const u32x2 w = __builtin_bit_cast(u32x2, v);
+                                        gp[(uint64_t)(col / 2) * B + row] = w.x;
+                                        gp[(uint64_t)(col / 2 + 1) * B + row] = w.y;
+                                    }
+                                }
+                            }
+                        } else {
+                            store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
+                        }
+                    }
                 }
             }
             if (s < NL && relu) {
@@ -839,7 +873,7 @@ static size_t mlp_bwd_lds(uint32_t in_dim, uint32_t num_layers, bool dx) {
 
 template <int HIDDEN, bool TRAIN>
 static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
-                          void *fwd_buf, void *outputs, hipStream_t st) {
+                          void *fwd_buf, void *outputs, int planar, hipStream_t st) {
     constexpr int NB = 2;
     const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
@@ -850,14 +884,14 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu);
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu, planar);
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
 
 template <bool TRAIN>
 static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
-                   uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *buffer, void *outputs, void *stream) {
+                   uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *buffer, void *outputs, void *stream, int planar = 0) {
     const char *who = TRAIN ? "ffmlp_forward" : "ffmlp_inference";
     FOC_REQUIRE(inputs && weights && outputs && (!TRAIN || buffer), FOC_E_INVALID, "%s: null pointer", who);
     int rc = mlp_check(who, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
@@ -866,17 +900,18 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
     const int relu = activation == 0;
     hipStream_t st = (hipStream_t)stream;
     switch (hidden_dim) {
-        case 16: return mlp_fwd_launch<16, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
-        case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
-        case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
-        case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, st);
+        case 16: return mlp_fwd_launch<16, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
+        case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
+        case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
+        case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
     }
     return FOC_E_INVALID;
 }
 
 template <int HIDDEN, int NL>
 static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, int relu,
-                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, hipStream_t st) {
+                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
+    FOC_REQUIRE(!planar || fwd_buf == nullptr, FOC_E_INVALID, "ffmlp_backward: planar inputs need the re-evaluating form (forward_buffer NULL)");
     constexpr int NB = 1, RW = 32 * NB, WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     const bool dx = grad_inputs != nullptr;
     const size_t lds_w = mlp_bwd_lds<HIDDEN>(in_dim, NL, dx);
@@ -893,7 +928,7 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const uint32_t cap = mlp_num_cus() * 2;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)));
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)), planar);
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
     hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
     FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
@@ -902,21 +937,22 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
 
 template <int HIDDEN>
 static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim,
-                          uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, hipStream_t st) {
+                          uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
     // fused single-pass kernel for the shapes the NeRF networks use; FOC_MLP_BWD_FUSED=0 forces the two-kernel form (tuning / tests)
     static int use_fused = -1;
     if (use_fused < 0) { const char *e = getenv("FOC_MLP_BWD_FUSED"); use_fused = e ? atoi(e) : 1; }
     if constexpr (HIDDEN <= 64) {
         if (use_fused && in_dim <= 64) {
             switch (num_layers) {
-                case 2: return mlp_bwd_fused_launch<HIDDEN, 2>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
-                case 3: return mlp_bwd_fused_launch<HIDDEN, 3>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
-                case 4: return mlp_bwd_fused_launch<HIDDEN, 4>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, st);
+                case 2: return mlp_bwd_fused_launch<HIDDEN, 2>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, planar, st);
+                case 3: return mlp_bwd_fused_launch<HIDDEN, 3>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, planar, st);
+                case 4: return mlp_bwd_fused_launch<HIDDEN, 4>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, planar, st);
                 default: break;
             }
         }
     }
     FOC_REQUIRE(bwd_buf && fwd_buf, FOC_E_INVALID, "ffmlp_backward: forward_buffer and backward_buffer are required for this shape (two-kernel path)");
+    FOC_REQUIRE(!planar, FOC_E_INVALID, "ffmlp_backward: planar inputs are served by the fused kernel only (hidden_dim <= 64, input_dim <= 64, 2..4 layers)");
     constexpr int NB = 2;
     const bool dx = grad_inputs != nullptr;
     const size_t lds = mlp_bwd_lds<HIDDEN>(in_dim, num_layers, dx);
@@ -965,9 +1001,9 @@ uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_
     return (uint64_t)hidden_dim * (input_dim + (uint64_t)hidden_dim * (num_layers - 1) + 16) * sizeof(float);
 }
 
-int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
-                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
-                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
+static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
+                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                         int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, int planar, void *stream) {
     // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip; forward_buffer may be NULL: the fused kernel
     // then re-evaluates the activations from the inputs (the two-kernel path checks both again)
     FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
@@ -979,12 +1015,31 @@ int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights
     hipStream_t st = (hipStream_t)stream;
     void *gi = calc_grad_inputs ? grad_inputs : nullptr;
     switch (hidden_dim) {
-        case 16: return mlp_bwd_launch<16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
-        case 32: return mlp_bwd_launch<32>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
-        case 64: return mlp_bwd_launch<64>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
-        case 128: return mlp_bwd_launch<128>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, st);
+        case 16: return mlp_bwd_launch<16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
+        case 32: return mlp_bwd_launch<32>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
+        case 64: return mlp_bwd_launch<64>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
+        case 128: return mlp_bwd_launch<128>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
     }
     return FOC_E_INVALID;
+}
+
+int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
+                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
+    return mlp_bwd_entry(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                         calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, 0, stream);
+}
+
+int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                             uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *outputs, void *stream) {
+    return mlp_fwd<false>(inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream, 1);
+}
+
+int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                              uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                              void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream) {
+    return mlp_bwd_entry(grad, inputs_planar, weights, nullptr, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                         calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
 }
 
 int foc_allocate_splitk(uint64_t size) { (void)size; return FOC_OK; }

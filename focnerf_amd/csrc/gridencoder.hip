@@ -220,9 +220,10 @@ template <typename T, uint32_t D, uint32_t C, bool OUT_BL>
 __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                       const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                       uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
-                                                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks) {
+                                                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks, uint32_t plain) {
     uint32_t level, chunk;
-    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+    if (plain) { level = blockIdx.x / chunks; chunk = blockIdx.x - level * chunks; }
+    else if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
     const uint32_t b = chunk * 256 + threadIdx.x;
     if (b >= B) return;
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -783,7 +784,7 @@ template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-    bool align_corners, uint32_t interp, uint32_t diag) {
+    bool align_corners, uint32_t interp, uint32_t diag, bool grad_bl) {
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
     constexpr uint32_t NREC = GB_PM_TILE * 8u;
     __shared__ uint32_t cur[2][GB_MAX_SEGS];               // next free staging position per segment (double-buffered by level parity)
@@ -799,7 +800,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     // gradient row of this point: fp16 -> one dword (half2) per level, fp32 -> two
     constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
     uint32_t gq[GE_MAX_LEVELS * GW];
-    {
+    if (grad_bl) {                                         // [B, L*C]: one 64-byte row per point
         const uint32_t *gp = reinterpret_cast<const uint32_t *>(grad + (uint64_t)(b < B ? b : 0u) * L * 2);
         const bool vec = ((L * GW) & 3u) == 0u;
 #pragma unroll
@@ -815,6 +816,13 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 }
             }
             gq[i] = t.x; gq[i + 1] = t.y; gq[i + 2] = t.z; gq[i + 3] = t.w;
+        }
+    } else {                                               // [L, B, C] (the reference's layout, gridencoder.cu:283): a plane per level, coalesced
+        const uint32_t *gp = reinterpret_cast<const uint32_t *>(grad) + (uint64_t)(b < B ? b : 0u) * GW;
+#pragma unroll
+        for (uint32_t l = 0; l < GE_MAX_LEVELS; l++) {
+#pragma unroll
+            for (uint32_t w = 0; w < GW; w++) gq[l * GW + w] = l < L ? gp[(uint64_t)l * B * GW + w] : 0u;
         }
     }
     // wave 0 keeps the (base, end) pair of the level about to be processed in registers
@@ -1108,10 +1116,12 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
                              const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
     static int level_major = -1;                 // FOC_GRID_FWD_LM=1: level-major XCD-affine kernel for the [B,L*C] output too (tuning)
     if (level_major < 0) { const char *e = getenv("FOC_GRID_FWD_LM"); level_major = e ? atoi(e) : 0; }
+    static int lm_plain = -1;                    // FOC_GRID_LM_PLAIN=0: pin each level to one XCD instead of walking the levels chip-wide (tuning)
+    if (lm_plain < 0) { const char *e = getenv("FOC_GRID_LM_PLAIN"); lm_plain = e ? atoi(e) : 1; }
     if (bl && level_major) {
         const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, true>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
-                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks);
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, true>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain);
     } else if (bl) {
         const uint64_t total = (uint64_t)B * L;
         const uint32_t grid = (uint32_t)((total + 255) / 256 > 0x7FFFFFFFull ? 0x7FFFFFFFull : (total + 255) / 256);
@@ -1119,8 +1129,8 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
                            (T *)dy_dx, gridtype, ac, interp);
     } else {
         const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, false>), dim3(ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
-                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks);
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, false>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
     return FOC_OK;
@@ -1241,14 +1251,14 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
     static int use_pm = -1;                      // FOC_GBIN_PM=0 selects the level-major count/scatter for [B,L*C] gradients too (tuning)
     if (use_pm < 0) { const char *e = getenv("FOC_GBIN_PM"); use_pm = e ? atoi(e) : 1; }
-    if (bl && use_pm) {
+    static int sorted_scatter = -1;              // FOC_GBIN_SORTED=0 selects the unsorted, unmerged count/scatter pairs (tuning)
+    if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
+    if ((bl || sorted_scatter) && use_pm) {
         const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
         const dim3 grid(n_wg);
         uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
         static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no copy-out); WRONG RESULTS
         if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
-        static int sorted_scatter = -1;          // FOC_GBIN_SORTED=0 selects the unsorted, unmerged point-major count/scatter pair (tuning)
-        if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
         if (sorted_scatter)
             hipLaunchKernelGGL(k_gbin_count_pt, grid, dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
         else
@@ -1260,7 +1270,7 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
         if (sorted_scatter)
             hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
-                               (uint32_t)diag);
+                               (uint32_t)diag, bl);
         else
             hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
                                (uint32_t)diag);

@@ -109,10 +109,19 @@ def render_fixed_steps(model, rays_o, rays_d, num_steps=512, bg_color=None, pert
     enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound)
 
     enc = model.encoder
+    from .field import field_fusable, _hashgrid_mlp
     with torch.autocast("cuda", dtype=torch.float16):
-        feats = grid_encode(enc_in, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, enc.gridtype_id,
-                            enc.align_corners, enc.interp_id)
-        h = model.sigma_net(feats)                                        # [M,16] half
+        if field_fusable(enc, model.sigma_net):
+            import numpy as np
+            mlp = model.sigma_net
+            h = _hashgrid_mlp.apply(enc_in, enc.embeddings, mlp.weights, enc.offsets,
+                                    (float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners, enc.interp_id),
+                                    (mlp.input_dim, mlp.hidden_dim, mlp.num_layers, mlp.activation, mlp.output_activation),
+                                    mlp.training and torch.is_grad_enabled())
+        else:
+            feats = grid_encode(enc_in, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, enc.gridtype_id,
+                                enc.align_corners, enc.interp_id)
+            h = model.sigma_net(feats)                                    # [M,16] half
         if h.shape[1] != 16:                                              # FFMLP slices to output_dim (= 16 here: 1 + geo_feat_dim 15)
             raise RuntimeError("render_fixed_steps expects a 16-wide sigma head (1 + geo_feat_dim = 16)")
         weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale)

@@ -42,7 +42,11 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d):
         if self._fused_head_ok(x):
             from .head import sample_head, rgb_head
-            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))     # [M,16] half
+            from .field import field_fusable, hashgrid_mlp
+            if field_fusable(self.encoder, self.sigma_net):
+                h = hashgrid_mlp(self.encoder, self.sigma_net, x, self.bound)          # [M,16] half, encoding kept in [L,B,C]
+            else:
+                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
             sigma, cin = sample_head(h, d)
             return sigma, rgb_head(self.color_net.forward_padded(cin))
         x = self.encoder(x, bound=self.bound)

@@ -248,6 +248,20 @@ int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights
                        void *workspace, void *stream);
 uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
 
+/* Planar-input forms for the encoder -> MLP pair. `inputs_planar` is [input_dim/2][B] half2 planes: exactly the
+ * [L, B, C=2] tensor foc_grid_encode_forward writes (gridencoder.cu:218), consumed here without the
+ * permute + copy to [B, L*C] the reference wrapper makes (grid.py:57); `grad_inputs_planar` has the same layout,
+ * i.e. the [L, B, C] gradient foc_grid_encode_backward(_binned) reads (grid.py:75 builds it with another permute).
+ * Semantics otherwise as foc_ffmlp_forward / foc_ffmlp_backward with forward_buffer and backward_buffer NULL
+ * (same shape limits: hidden_dim <= 64, input_dim <= 64, num_layers 2..4 for the backward). */
+int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim,
+                             uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                             uint32_t activation, uint32_t output_activation, void *outputs, void *stream);
+int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B,
+                              uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                              uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                              void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream);
+
 /* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
  * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the
  * backward launch sequence on the caller's stream, so both are no-ops kept for API parity. */

@@ -150,3 +150,31 @@ def test_fused_head_matches_torch_glue(monkeypatch):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         s2, r2 = m(x, d)
     assert torch.equal(s2, a[0]) and torch.equal(r2.float(), a[1])
+
+
+@pytest.mark.parametrize("B", [4096, 1000 + 13])
+def test_fused_field_matches_separate_nodes(B, monkeypatch):
+    """hashgrid_mlp (encoder output kept as [L,B,C] planes, planar-input MLP kernels) == sigma_net.forward_padded(encoder(x)):
+    identical h bits, same parameter gradients (fp32 atomics / fixed-point sums: tolerance)."""
+    from focnerf_amd.field import hashgrid_mlp, field_fusable
+    m = _model(1, False).train()
+    assert field_fusable(m.encoder, m.sigma_net)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(B, 3, device="cuda", generator=gen) * 2 - 1
+    gh = (torch.randn(B, 16, device="cuda", generator=gen) * 0.1).half()
+    res = {}
+    for mode in ("fused", "separate"):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            h = hashgrid_mlp(m.encoder, m.sigma_net, x, m.bound) if mode == "fused" else m.sigma_net.forward_padded(m.encoder(x, bound=m.bound))
+        h.backward(gh)
+        res[mode] = (h.detach().clone(), m.sigma_net.weights.grad.clone(), m.encoder.embeddings.grad.clone())
+    assert torch.equal(res["fused"][0], res["separate"][0])
+    for k, name in ((1, "mlp weights"), (2, "embeddings")):
+        scale = res["separate"][k].abs().max().item()
+        assert (res["fused"][k] - res["separate"][k]).abs().max().item() <= 2e-3 * scale + 1e-7, name
+    # no-grad / eval calls keep nothing
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        h2 = hashgrid_mlp(m.encoder, m.sigma_net, x, m.bound)
+    assert torch.equal(h2, res["fused"][0])
