@@ -178,11 +178,12 @@ __device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t 
 }
 
 // ---------------------------------------------------------------- M1: fused forward / inference
-template <int HIDDEN, int NB, bool TRAIN>
+template <int HIDDEN, int NB, bool TRAIN, bool PLANAR>
 __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
                                                        _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
-                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu, int planar) {
+                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
+    constexpr bool planar = PLANAR;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
     __syncthreads();
@@ -503,12 +504,13 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
 // where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
 // and input rows are fetched while the current group is processed.
-template <int HIDDEN, int NL, int NB, bool RECOMP>
+template <int HIDDEN, int NL, int NB, bool RECOMP, bool PLANAR>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
-                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs, int planar) {
+                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
+    constexpr bool planar = PLANAR;
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const bool with_dx = grad_inputs != nullptr;
@@ -770,7 +772,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        if (RECOMP && planar) {
+                        if constexpr (RECOMP && PLANAR) {
                             // [in_dim/2][B] half2 planes (the encoder's [L,B,C] gradient layout): register quad q = features 32mt0 + 8q + 4h .. +3
                             const uint64_t row = row0 + nb * 32 + c;
                             if (row < B) {
@@ -877,14 +879,15 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     constexpr int NB = 2;
     const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
-    auto kern = k_mlp_fwd<HIDDEN, NB, TRAIN>;
+    FOC_REQUIRE(!(planar && TRAIN), FOC_E_INVALID, "ffmlp_forward: planar inputs go with the activation-free forward");
+    auto kern = planar ? k_mlp_fwd<HIDDEN, NB, false, true> : k_mlp_fwd<HIDDEN, NB, TRAIN, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_tiles = foc_div_up(B, 32 * NB);
     uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu, planar);
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu);
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
@@ -920,7 +923,8 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
-    auto kern = recomp ? k_mlp_bwd_fused<HIDDEN, NL, NB, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, false>;
+    auto kern = recomp ? (planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, false>)
+                       : k_mlp_bwd_fused<HIDDEN, NL, NB, false, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
     if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
@@ -928,7 +932,7 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const uint32_t cap = mlp_num_cus() * 2;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)), planar);
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)));
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
     hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
     FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
