@@ -330,16 +330,27 @@ def main():
         model.eval()
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             # one untimed full view first: the caching allocator sizes its blocks for the view's chunk shapes
-            model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
+            rkw = dict(staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
+            model.render(rays_o, rays_d, return_fields=False, **rkw)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.render_views):
-                model.render(rays_o, rays_d, staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
+                model.render(rays_o, rays_d, return_fields=False, **rkw)
             barrier()
         rel = max_over_ranks(time.perf_counter() - t0)
         result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",
                             "samples_per_sec": world * VIEW * VIEW * NUM_STEPS * args.render_views / rel, "views": args.render_views,
-                            "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks"}
+                            "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks, image + depth"}
+        # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            model.render(rays_o, rays_d, return_fields=True, **rkw)
+            barrier()
+            t0 = time.perf_counter()
+            model.render(rays_o, rays_d, return_fields=True, **rkw)
+            barrier()
+        relf = max_over_ranks(time.perf_counter() - t0)
+        result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
+                                        "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
 
         # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
         m2 = build_model(2, device, cuda_ray=True, seed=rank).train()

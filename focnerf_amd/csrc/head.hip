@@ -35,7 +35,17 @@ __device__ __forceinline__ void hd_sh16(float x, float y, float z, float (&o)[16
 
 // h [M,16] fp16 (sigma-net output), dirs [M,3] fp32 -> sigma [M] fp32 = exp(h[:,0]), cin [M,32] fp16 = [SH16(dir) | h[:,1:16] | 0]
 __global__ void __launch_bounds__(256) k_head_fwd(const _Float16 *__restrict__ h, const float *__restrict__ dirs, uint64_t M,
-                                                  float *__restrict__ sigma, _Float16 *__restrict__ cin) {
+                                                  float *__restrict__ sigma, _Float16 *__restrict__ cin, const _Float16 *__restrict__ obj, uint32_t cin_ld) {
+    // 48-wide form (FOC network with a per-image object feature, nerf/network_tcnn.py:641): [SH16 | h[:,1:16] | obj16 | 0]
+    h8 ob1 = {0, 0, 0, 0, 0, 0, 0, 0}, ob2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    _Float16 ob0 = (_Float16)0;
+    if (cin && obj) {
+        ob0 = obj[0];
+#pragma unroll
+        for (int k = 0; k < 8; k++) ob1[k] = obj[1 + k];
+#pragma unroll
+        for (int k = 0; k < 7; k++) ob2[k] = obj[9 + k];
+    }
     for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < M; s += (uint64_t)gridDim.x * 256) {
         const h8 r0 = *reinterpret_cast<const h8 *>(h + s * 16), r1 = *reinterpret_cast<const h8 *>(h + s * 16 + 8);
         if (sigma) sigma[s] = expf((float)r0[0]);
@@ -47,9 +57,10 @@ __global__ void __launch_bounds__(256) k_head_fwd(const _Float16 *__restrict__ h
             for (int k = 0; k < 8; k++) { c0[k] = (_Float16)sh[k]; c1[k] = (_Float16)sh[8 + k]; }
 #pragma unroll
             for (int k = 0; k < 7; k++) { c2[k] = r0[k + 1]; c3[k] = r1[k + 1]; }
-            c2[7] = r1[0]; c3[7] = (_Float16)0;
-            h8 *dst = reinterpret_cast<h8 *>(cin + s * 32);
+            c2[7] = r1[0]; c3[7] = ob0;
+            h8 *dst = reinterpret_cast<h8 *>(cin + s * cin_ld);
             dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+            if (cin_ld == 48) { dst[4] = ob1; dst[5] = ob2; }
         }
     }
 }
@@ -57,10 +68,10 @@ __global__ void __launch_bounds__(256) k_head_fwd(const _Float16 *__restrict__ h
 // grad_sigma [M] fp32, grad_cin [M,32] fp16 (either may be null) -> grad_h [M,16] fp16:
 // column 0 = grad_sigma * exp(clamp(h0, -15, 15)) (activation.py:16-18), columns 1..15 = grad_cin[:, 16:31]
 __global__ void __launch_bounds__(256) k_head_bwd(const _Float16 *__restrict__ h, const float *__restrict__ grad_sigma,
-                                                  const _Float16 *__restrict__ grad_cin, uint64_t M, _Float16 *__restrict__ grad_h) {
+                                                  const _Float16 *__restrict__ grad_cin, uint64_t M, _Float16 *__restrict__ grad_h, uint32_t cin_ld) {
     for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < M; s += (uint64_t)gridDim.x * 256) {
         h8 g2 = {0, 0, 0, 0, 0, 0, 0, 0}, g3 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (grad_cin) { g2 = *reinterpret_cast<const h8 *>(grad_cin + s * 32 + 16); g3 = *reinterpret_cast<const h8 *>(grad_cin + s * 32 + 24); }
+        if (grad_cin) { g2 = *reinterpret_cast<const h8 *>(grad_cin + s * cin_ld + 16); g3 = *reinterpret_cast<const h8 *>(grad_cin + s * cin_ld + 24); }
         float g0 = 0.0f;
         if (grad_sigma) {
             float x = (float)h[s * 16];
@@ -107,19 +118,23 @@ __global__ void __launch_bounds__(256) k_rgb_bwd(const _Float16 *__restrict__ c,
 
 extern "C" {
 
-int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, void *stream) {
+int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, const void *obj_feat, uint32_t cin_width, void *stream) {
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(h && (sigma || cin) && (!cin || dirs), FOC_E_INVALID, "sample_head_forward: null pointer");
-    hipLaunchKernelGGL(k_head_fwd, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, dirs, M, sigma, (_Float16 *)cin);
+    FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "sample_head_forward: cin_width must be 32 or 48 (got %u)", cin_width);
+    FOC_REQUIRE(!obj_feat || cin_width == 48, FOC_E_INVALID, "sample_head_forward: an object feature needs the 48-wide colour input");
+    hipLaunchKernelGGL(k_head_fwd, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, dirs, M, sigma, (_Float16 *)cin,
+                       (const _Float16 *)obj_feat, cin_width);
     FOC_CHECK_LAUNCH("sample_head_forward");
     return FOC_OK;
 }
 
-int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M, void *grad_h, void *stream) {
+int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M, void *grad_h, uint32_t cin_width, void *stream) {
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(h && grad_h, FOC_E_INVALID, "sample_head_backward: null pointer");
+    FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "sample_head_backward: cin_width must be 32 or 48 (got %u)", cin_width);
     hipLaunchKernelGGL(k_head_bwd, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, grad_sigma,
-                       (const _Float16 *)grad_cin, M, (_Float16 *)grad_h);
+                       (const _Float16 *)grad_cin, M, (_Float16 *)grad_h, cin_width);
     FOC_CHECK_LAUNCH("sample_head_backward");
     return FOC_OK;
 }

@@ -33,7 +33,8 @@ class _density_head(Function):
     """h [M,16] half -> (weights [M], weights_sum [N], depth [N], sigma [M], cin [M,32] half)."""
 
     @staticmethod
-    def forward(ctx, h, rays_d, nears, fars, noise, N, T, density_scale):
+    def forward(ctx, h, rays_d, nears, fars, noise, N, T, density_scale, obj_feat=None):
+        """obj_feat: None -> cin [M,32]; [16] half (FOC network's encoded object feature) -> cin [M,48]."""
         h = h.contiguous()
         assert h.dtype == torch.float16 and h.shape == (N * T, 16)
         dev = h.device
@@ -43,12 +44,17 @@ class _density_head(Function):
         weights = torch.empty(M, dtype=torch.float32, device=dev)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
-        cin = torch.empty(M, 32, dtype=torch.float16, device=dev)
+        width = 32 if obj_feat is None else 48
+        if obj_feat is not None:
+            obj_feat = obj_feat.detach().reshape(-1).half().contiguous()
+            assert obj_feat.numel() == 16
+        cin = torch.empty(M, width, dtype=torch.float16, device=dev)
         check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
-                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), stream_of(h)), "fixed_head_forward")
+                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), ptr(obj_feat), width, stream_of(h)), "fixed_head_forward")
         ctx.save_for_backward(h, sigma, trans, nears, fars, noise if noise is not None else torch.empty(0, device=dev))
         ctx.has_noise = noise is not None
         ctx.dims = (N, T, float(density_scale))
+        ctx.width = width
         ctx.mark_non_differentiable(sigma)
         return weights, ws, depth, sigma, cin
 
@@ -63,8 +69,11 @@ class _density_head(Function):
         g_cin = g_cin.contiguous().half() if g_cin is not None else None
         grad_h = torch.empty_like(h)
         check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(g_weights), ptr(g_ws), ptr(g_depth),
-                                          ptr(g_cin), N, T, ds, ptr(grad_h), stream_of(h)), "fixed_head_backward")
-        return grad_h, None, None, None, None, None, None, None
+                                          ptr(g_cin), N, T, ds, ptr(grad_h), ctx.width, stream_of(h)), "fixed_head_backward")
+        g_obj = None
+        if ctx.width == 48 and ctx.needs_input_grad[8] and g_cin is not None:
+            g_obj = g_cin[:, 31:47].float().sum(0)                 # one feature vector feeds every sample
+        return grad_h, None, None, None, None, None, None, None, g_obj
 
 
 class _fixed_composite(Function):
@@ -96,8 +105,14 @@ class _fixed_composite(Function):
         return grad_c, grad_w, None, None, None, None, None
 
 
-def render_fixed_steps(model, rays_o, rays_d, num_steps=512, bg_color=None, perturb=False, weight_thresh=1e-10, return_fields=False, **kwargs):
-    """Drop-in for NeRFRenderer.run(..., upsample_steps=0) on a focnerf_amd NeRFNetwork (fp16 autocast semantics)."""
+def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, bg_color=None, perturb=False, weight_thresh=1e-10,
+                       return_fields=None, **kwargs):
+    """Drop-in for NeRFRenderer.run(..., upsample_steps=0) on a focnerf_amd NeRFNetwork (fp16 autocast semantics); same result
+    dictionary (`return_fields` None = on in eval mode, like the reference's run(), off in training)."""
+    import time
+    if return_fields is None:
+        return_fields = not model.training
+    t_start = time.time()
     prefix = rays_o.shape[:-1]
     rays_o = rays_o.contiguous().view(-1, 3).float()
     rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -124,8 +139,16 @@ def render_fixed_steps(model, rays_o, rays_d, num_steps=512, bg_color=None, pert
             h = model.sigma_net(feats)                                    # [M,16] half
         if h.shape[1] != 16:                                              # FFMLP slices to output_dim (= 16 here: 1 + geo_feat_dim 15)
             raise RuntimeError("render_fixed_steps expects a 16-wide sigma head (1 + geo_feat_dim = 16)")
-        weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale)
+        obj_feat = None
+        if getattr(model, "uses_object_feature", False):                  # FOC network (network_foc.py): encoded YOLO feature in the colour input
+            obj_feat = model.encode_object_feature(yolo_details, dev)
+        weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale, obj_feat)
+        criterion_outside_mask = None
+        if model.training and yolo_details is not None:                   # nerf/renderer.py:163-165
+            from .activation import trunc_exp
+            criterion_outside_mask = torch.norm(trunc_exp(h[:, 0]).view(N, T)[~yolo_details[0].squeeze(0)] - 0)
         c = model.color_net.forward_padded(cin)                            # [M,16] half, columns 0..2 = rgb logits
+    t_mid = time.time()
 
     bg_ray, bg_scalar = None, 1.0
     if bg_color is None:
@@ -137,7 +160,8 @@ def render_fixed_steps(model, rays_o, rays_d, num_steps=512, bg_color=None, pert
         bg_scalar = float(bg_color)
     image = _fixed_composite.apply(c, weights, bg_ray, bg_scalar, N, T, weight_thresh)
 
-    results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum}
+    results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum,
+               'criterion_outside_mask': criterion_outside_mask, 'timing': [t_mid - t_start, time.time() - t_mid]}
     if return_fields:
         rgb = torch.sigmoid(c[:, :3]).float() * (weights > weight_thresh).unsqueeze(-1)
         results['densities'] = sigma.view(N, T, 1)

@@ -16,16 +16,22 @@ from ._lib import lib, ptr, stream_of, check
 
 class _sample_head(Function):
     @staticmethod
-    def forward(ctx, h, dirs):
+    def forward(ctx, h, dirs, obj_feat=None):
+        """obj_feat: None -> 32-wide colour input; [16] half (one encoded object feature for all samples) -> 48-wide."""
         h = h.contiguous()
         dirs = dirs.contiguous().float()
         assert h.is_cuda and h.dtype == torch.float16 and h.dim() == 2 and h.shape[1] == 16
         M = h.shape[0]
         assert dirs.shape == (M, 3)
+        width = 32 if obj_feat is None else 48
+        if obj_feat is not None:
+            obj_feat = obj_feat.detach().reshape(-1).half().contiguous()
+            assert obj_feat.numel() == 16
         sigma = torch.empty(M, dtype=torch.float32, device=h.device)
-        cin = torch.empty(M, 32, dtype=torch.float16, device=h.device)
-        check(lib.foc_sample_head_forward(ptr(h), ptr(dirs), M, ptr(sigma), ptr(cin), stream_of(h)), "sample_head_forward")
+        cin = torch.empty(M, width, dtype=torch.float16, device=h.device)
+        check(lib.foc_sample_head_forward(ptr(h), ptr(dirs), M, ptr(sigma), ptr(cin), ptr(obj_feat), width, stream_of(h)), "sample_head_forward")
         ctx.save_for_backward(h)
+        ctx.width = width
         return sigma, cin
 
     @staticmethod
@@ -34,8 +40,11 @@ class _sample_head(Function):
         g_sigma = g_sigma.contiguous().float() if g_sigma is not None else None
         g_cin = g_cin.contiguous().half() if g_cin is not None else None
         grad_h = torch.empty_like(h)
-        check(lib.foc_sample_head_backward(ptr(h), ptr(g_sigma), ptr(g_cin), h.shape[0], ptr(grad_h), stream_of(h)), "sample_head_backward")
-        return grad_h, None
+        check(lib.foc_sample_head_backward(ptr(h), ptr(g_sigma), ptr(g_cin), h.shape[0], ptr(grad_h), ctx.width, stream_of(h)), "sample_head_backward")
+        g_obj = None
+        if ctx.width == 48 and ctx.needs_input_grad[2] and g_cin is not None:
+            g_obj = g_cin[:, 31:47].float().sum(0)                 # one feature vector feeds every sample
+        return grad_h, None, g_obj
 
 
 class _rgb_head(Function):

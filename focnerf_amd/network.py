@@ -86,14 +86,14 @@ class NeRFNetwork(NeRFRenderer):
             rgbs = h
         return rgbs
 
-    def run(self, rays_o, rays_d, fused=False, **kwargs):
+    def run(self, rays_o, rays_d, yolo_details=None, fused=False, **kwargs):
         """`fused=True` routes the fixed-step path through csrc/fixedstep.hip (same image, depth and gradients as the
         torch code of NeRFRenderer.run, which stays the default)."""
         if fused and kwargs.get("upsample_steps", 0) == 0 and self.bg_radius <= 0:
             from .fixedstep import render_fixed_steps
             kwargs.pop("upsample_steps", None)
-            return render_fixed_steps(self, rays_o, rays_d, **kwargs)
-        return super().run(rays_o, rays_d, **kwargs)
+            return render_fixed_steps(self, rays_o, rays_d, yolo_details=yolo_details, **kwargs)
+        return super().run(rays_o, rays_d, yolo_details, **kwargs)
 
     def get_params(self, lr):
         return [

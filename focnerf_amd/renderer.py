@@ -15,6 +15,8 @@ Additions over the reference caller (both optional, both default to reference be
 """
 import math
 
+import time
+
 import torch
 import torch.nn as nn
 
@@ -70,10 +72,18 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # ------------------------------------------------------------------ fixed-step path
-    def run(self, rays_o, rays_d, num_steps=512, upsample_steps=0, bg_color=None, perturb=False, weight_thresh=1e-10,
-            return_fields=False, **kwargs):
-        """nerf/renderer.py:126-238 (upsample_steps must be 0, FOC's setting main_nerf.py:31-32)."""
+    def run(self, rays_o, rays_d, yolo_details=None, num_steps=512, upsample_steps=0, bg_color=None, perturb=False, weight_thresh=1e-10,
+            return_fields=None, **kwargs):
+        """nerf/renderer.py:126-238 (upsample_steps must be 0, FOC's setting main_nerf.py:31-32).
+
+        `yolo_details` = (ray mask [1,N] bool, bbox, object feature) as produced by nerf/utils.py:57-154; it is handed to
+        `color()` and, in training, gives the outside-mask density penalty of :165. `return_fields` (None = the reference's
+        behaviour in eval mode, off in training where only image/criterion are consumed) adds `densities [N,T,1]` and
+        `rgbs [N,T,3]`, the per-sample fields COMBINED.py merges."""
         assert upsample_steps == 0, "only the FOC configuration (upsample_steps=0) is implemented"
+        if return_fields is None:
+            return_fields = not self.training
+        t_start = time.time()
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -95,6 +105,9 @@ class NeRFRenderer(nn.Module):
         xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
 
         density_outputs = self.density(xyzs.reshape(-1, 3))
+        criterion_outside_mask = None
+        if self.training and yolo_details is not None:      # :163-165
+            criterion_outside_mask = torch.norm(density_outputs['sigma'].view(N, num_steps)[~yolo_details[0].squeeze(0)] - 0)
         for k, v in density_outputs.items():
             density_outputs[k] = v.view(N, num_steps, -1)
 
@@ -110,8 +123,9 @@ class NeRFRenderer(nn.Module):
             density_outputs[k] = v.view(-1, v.shape[-1])
 
         mask = weights > weight_thresh
-        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **density_outputs)
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), yolo_details=yolo_details, **density_outputs)
         rgbs = rgbs.view(N, -1, 3)
+        t_mid = time.time()
 
         weights_sum = weights.sum(dim=-1)
         ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
@@ -129,6 +143,8 @@ class NeRFRenderer(nn.Module):
             'depth': depth.view(*prefix),
             'image': image.view(*prefix, 3),
             'weights_sum': weights_sum,
+            'criterion_outside_mask': criterion_outside_mask,
+            'timing': [t_mid - t_start, time.time() - t_mid],     # host-side stage times, as the reference reports them (:190,226)
         }
         if return_fields:   # what COMBINED.py's run() hands to the combiner (:528-534)
             results['densities'] = sigma_field
@@ -274,14 +290,21 @@ class NeRFRenderer(nn.Module):
         thresh = min(self.mean_density, self.density_thresh) if density_thresh is None else density_thresh
         self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
 
-    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
-        """legacy/nerf/renderer.py:539-573."""
-        _run = self.run_cuda if self.cuda_ray else self.run
+    def render(self, rays_o, rays_d, yolo_details=None, staged=False, max_ray_batch=4096, **kwargs):
+        """nerf/renderer.py:511-560 (and legacy/nerf/renderer.py:539-573, which has no `yolo_details`).
+
+        Staged rendering assembles `densities [B,N,T]` and `rgbs [B,N,T,3]` for the whole view like the reference when the
+        chunks carry them (`return_fields`, default on in eval mode): 1.3 + 3.9 GB per 800x800x512 view."""
+        if self.cuda_ray:
+            _run = self.run_cuda                         # takes no yolo_details (renderer.py:243)
+        else:
+            _run = lambda o, d, **kw: self.run(o, d, yolo_details, **kw)
         B, N = rays_o.shape[:2]
         device = rays_o.device
         if staged and not self.cuda_ray:
             depth = torch.empty((B, N), device=device)
             image = torch.empty((B, N, 3), device=device)
+            densities = rgbs = None
             for b in range(B):
                 head = 0
                 while head < N:
@@ -289,8 +312,18 @@ class NeRFRenderer(nn.Module):
                     results_ = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
                     depth[b:b + 1, head:tail] = results_['depth']
                     image[b:b + 1, head:tail] = results_['image']
+                    if 'densities' in results_:
+                        if densities is None:
+                            T = results_['densities'].shape[1]
+                            densities = torch.empty((B, N, T), device=device)
+                            rgbs = torch.empty((B, N, T, 3), device=device)
+                        densities[b:b + 1, head:tail] = results_['densities'].permute(2, 0, 1)
+                        rgbs[b:b + 1, head:tail] = results_['rgbs']
                     head += max_ray_batch
-            results = {'depth': depth, 'image': image}
+            results = {'depth': depth, 'image': image, 'timing': results_.get('timing')}
+            if densities is not None:
+                results['densities'] = densities
+                results['rgbs'] = rgbs
         else:
             results = _run(rays_o, rays_d, **kwargs)
         return results

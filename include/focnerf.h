@@ -306,17 +306,20 @@ int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *near
                      float *xyzs, float *enc_in, void *stream);
 
 /* h [M,16] fp16 = sigma-net output. sigma = exp(h[:,0]); weights = alpha * cumprod(1-alpha+1e-15);
- * trans [M] = transmittance before each sample; weights_sum/depth [N]; cin [M,32] fp16 =
- * [SH16(dir) | h[:,1:16] | 0] (the colour-net input, network_ff.py:62-68) or NULL. */
+ * trans [M] = transmittance before each sample; weights_sum/depth [N]; cin [M,cin_width] fp16 or NULL:
+ *   cin_width 32: [SH16(dir) | h[:,1:16] | 0]                 (the colour-net input, network_ff.py:62-68)
+ *   cin_width 48: [SH16(dir) | h[:,1:16] | obj_feat[16] | 0]  (FOC network with the encoded YOLO object feature,
+ *                 nerf/network_tcnn.py:641-643; obj_feat = 16 fp16 values shared by all samples, NULL = zeros). */
 int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars,
                            const float *noise, uint32_t N, uint32_t T, float density_scale,
                            float *sigma, float *trans, float *weights, float *weights_sum, float *depth,
-                           void *cin, void *stream);
-/* grad_w [M], grad_ws [N], grad_depth [N], grad_cin [M,32] fp16 (each may be NULL) -> grad_h [M,16] fp16. */
+                           void *cin, const void *obj_feat, uint32_t cin_width, void *stream);
+/* grad_w [M], grad_ws [N], grad_depth [N], grad_cin [M,cin_width] fp16 (each may be NULL) -> grad_h [M,16] fp16
+ * (the object-feature gradient is the column sum of grad_cin[:,31:47], left to the caller). */
 int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears,
                             const float *fars, const float *noise, const float *grad_w, const float *grad_ws,
                             const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
-                            float density_scale, void *grad_h, void *stream);
+                            float density_scale, void *grad_h, uint32_t cin_width, void *stream);
 
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL
@@ -334,12 +337,14 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
  * ------------------------------------------------------------------------- */
 
 /* h [M,16] fp16 = sigma-net output, dirs [M,3] fp32. sigma [M] fp32 = trunc_exp(h[:,0]) (activation.py:8-13);
- * cin [M,32] fp16 = [SH degree 4 of dir | h[:,1:16] | 0] (network_ff.py:62-68). sigma or cin may be NULL. */
-int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, void *stream);
-/* grad_sigma [M] fp32, grad_cin [M,32] fp16 (either may be NULL) -> grad_h [M,16] fp16
+ * cin [M,cin_width] fp16 = [SH degree 4 of dir | h[:,1:16] | 0] (cin_width 32, network_ff.py:62-68) or
+ * [SH | h[:,1:16] | obj_feat[16] | 0] (cin_width 48, see foc_fixed_head_forward). sigma or cin may be NULL. */
+int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin,
+                            const void *obj_feat, uint32_t cin_width, void *stream);
+/* grad_sigma [M] fp32, grad_cin [M,cin_width] fp16 (either may be NULL) -> grad_h [M,16] fp16
  * (column 0: grad_sigma * exp(clamp(h0,-15,15)), activation.py:16-18; columns 1..15: grad_cin[:,16:31]). */
 int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M,
-                             void *grad_h, void *stream);
+                             void *grad_h, uint32_t cin_width, void *stream);
 /* c [M,16] fp16 = colour-net output -> rgb [M,3] fp32 = sigmoid(c[:, :3]) rounded to fp16 (network_ff.py:73). */
 int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream);
 /* grad_rgb [M,3] fp32 -> grad_c [M,16] fp16 (columns 3..15 zero). */
