@@ -44,7 +44,7 @@ static void run(const uint4 *table, uint32_t mask16, uint32_t *out, const char *
     CHECK(hipEventSynchronize(b));
     float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
     const double loads = 5.0 * blocks * 256.0 * iters;
-    printf("%-28s width %2d B  share %2d : %8.1f G lane-loads/s  (%.3f ms per 268M)\n", what, W, SHARE, loads / ms / 1e6, 268.4e6 / (loads / ms / 1e3) );
+    printf("%-28s width %2d B  share %2d : %8.1f G lane-loads/s  (%.3f ms per 268 M loads)\n", what, W, SHARE, loads / ms / 1e6, 268.4e6 / (loads / ms));
 }
 
 int main() {
