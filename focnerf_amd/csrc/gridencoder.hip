@@ -933,6 +933,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
                                                              const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
     __shared__ double acc[GB_SEG * 2];             // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64)
     unsigned long long *acci = reinterpret_cast<unsigned long long *>(acc);
+    __shared__ uint32_t s_bad[GB_SEG / 32];        // fp16 tables: rows that received an inf/NaN addend (an overflowed AMP step) -> NaN out
     __shared__ uint32_t s_slot, s_lo, s_hi;
     const uint32_t n = L * GB_MAX_SEGS;
     const uint32_t total_chunks = hdr->chunk_prefix[n];
@@ -949,6 +950,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
         s_hi = hdr->base[lo] + min(cnt, (c + 1) * GB_CHUNK);
     }
     for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += GB_RTHREADS) acc[i] = 0.0;
+    if (threadIdx.x < GB_SEG / 32) s_bad[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t slot = s_slot, lo = s_lo, hi = s_hi;
     // Software pipeline: the next UNR records per lane are in flight while the current ones go through the LDS adds
@@ -970,6 +972,10 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
                     // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT
                     // (and order independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
                     const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&cur[u].y));
+                    if (!(fabsf(v.x) <= 65504.0f) || !(fabsf(v.y) <= 65504.0f)) {      // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
+                        atomicOr(&s_bad[cur[u].x >> 5], 1u << (cur[u].x & 31u));
+                        continue;
+                    }
                     atomicAdd(&acci[cur[u].x * 2], (unsigned long long)(long long)(v.x * 16777216.0f));
                     atomicAdd(&acci[cur[u].x * 2 + 1], (unsigned long long)(long long)(v.y * 16777216.0f));
                 }
@@ -1011,7 +1017,8 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     if constexpr (sizeof(T) == 2) {
         typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
         for (uint32_t r = threadIdx.x; r < nrows; r += GB_RTHREADS) {
-            const float a = (float)((double)(long long)acci[2 * r] * (1.0 / 16777216.0)), b = (float)((double)(long long)acci[2 * r + 1] * (1.0 / 16777216.0));
+            float a = (float)((double)(long long)acci[2 * r] * (1.0 / 16777216.0)), b = (float)((double)(long long)acci[2 * r + 1] * (1.0 / 16777216.0));
+            if ((s_bad[r >> 5] >> (r & 31u)) & 1u) { a = __builtin_nanf(""); b = __builtin_nanf(""); }
             if (a == 0.0f && b == 0.0f) continue;
             v2h hv; hv[0] = (_Float16)ge_opaque(a); hv[1] = (_Float16)ge_opaque(b);
             (void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) v2h *)(dst + 2 * r), hv);

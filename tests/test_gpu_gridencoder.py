@@ -284,3 +284,27 @@ def test_freq_encoder():
         y.backward(g)
         gref = oracle.freq_encode_backward(to_np(g), to_np(y), 3, deg)
         np.testing.assert_allclose(to_np(x.grad), gref, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("atomic", ["0", "1"])
+def test_backward_propagates_non_finite_gradients(atomic, monkeypatch):
+    """An overflowed AMP step hands inf/NaN gradients to the encoder backward; torch's GradScaler skips the step only if it can SEE
+    them in the parameter gradients. The reference's half2 atomics leave inf/NaN in the touched rows; so must the binned path
+    (whose exact fixed-point sum has no encoding for them)."""
+    monkeypatch.setenv("FOCNERF_GRID_ATOMIC", atomic)
+    D, C, L, H, lh, desired, gridtype, ac, interp = CASES[0]
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, np.float16)
+    B = 3000
+    x = _points(B, D, 4, oob=False)
+    grad = (np.random.default_rng(1).standard_normal((B, L * C)) * 0.1).astype(np.float16)
+    grad[100, 5] = np.inf          # level 2, channel 1
+    grad[2000, 20] = np.nan        # level 10, channel 0
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    ge = torch.zeros(int(off[-1]), C, dtype=torch.float16, device="cuda")
+    _be().grid_encode_backward(torch.from_numpy(grad).cuda(), xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=True)
+    got = to_np(ge).astype(np.float32)
+    for l, n_bad_min in ((2, 1), (10, 1)):
+        assert (~np.isfinite(got[off[l]:off[l + 1]])).sum() >= n_bad_min, f"level {l}: non-finite gradient was swallowed"
+    for l in (0, 1, 3, 9, 11, 15):
+        assert np.isfinite(got[off[l]:off[l + 1]]).all(), f"level {l} must stay finite"
+    assert not torch.isfinite(ge).all()      # what GradScaler's unscale_ looks at
