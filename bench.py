@@ -313,81 +313,97 @@ def main():
     # single-GPU properties (other paths of the same object) are reported at N = 1 only; the multi-rank runs keep to the headline
     # step plus the one exchange step the path has (combine), so that no rank-local failure can leave the others in a collective
     if not args.no_extras and world == 1:
-        # ---- the same step through the reference caller's torch glue (NeRFRenderer.run) instead of the fused kernels
-        if fused:
-            for i in range(3):
-                train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
-            barrier()
-            t0 = time.perf_counter()
-            nu = max(5, args.steps // 2)
-            for i in range(nu):
-                train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
-            barrier()
-            elu = max_over_ranks(time.perf_counter() - t0)
-            result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
-                                         "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
-        # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
-        model.eval()
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            # one untimed full view first: the caching allocator sizes its blocks for the view's chunk shapes
-            rkw = dict(staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
-            model.render(rays_o, rays_d, return_fields=False, **rkw)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.render_views):
+        try:
+            # ---- the same step through the reference caller's torch glue (NeRFRenderer.run) instead of the fused kernels
+            if fused:
+                for i in range(3):
+                    train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+                barrier()
+                t0 = time.perf_counter()
+                nu = max(5, args.steps // 2)
+                for i in range(nu):
+                    train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+                barrier()
+                elu = max_over_ranks(time.perf_counter() - t0)
+                result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
+                                             "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
+            # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
+            model.eval()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                # one untimed full view first: the caching allocator sizes its blocks for the view's chunk shapes
+                rkw = dict(staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused)
                 model.render(rays_o, rays_d, return_fields=False, **rkw)
-            barrier()
-        rel = max_over_ranks(time.perf_counter() - t0)
-        result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",
-                            "samples_per_sec": world * VIEW * VIEW * NUM_STEPS * args.render_views / rel, "views": args.render_views,
-                            "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks, image + depth"}
-        # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            model.render(rays_o, rays_d, return_fields=True, **rkw)
-            barrier()
-            t0 = time.perf_counter()
-            model.render(rays_o, rays_d, return_fields=True, **rkw)
-            barrier()
-        relf = max_over_ranks(time.perf_counter() - t0)
-        result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
-                                        "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.render_views):
+                    model.render(rays_o, rays_d, return_fields=False, **rkw)
+                barrier()
+            rel = max_over_ranks(time.perf_counter() - t0)
+            result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",
+                                "samples_per_sec": world * VIEW * VIEW * NUM_STEPS * args.render_views / rel, "views": args.render_views,
+                                "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks, image + depth"}
+            # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                model.render(rays_o, rays_d, return_fields=True, **rkw)
+                barrier()
+                t0 = time.perf_counter()
+                model.render(rays_o, rays_d, return_fields=True, **rkw)
+                barrier()
+            relf = max_over_ranks(time.perf_counter() - t0)
+            result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
+                                            "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
 
-        # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
-        m2 = build_model(2, device, cuda_ray=True, seed=rank).train()
-        opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
-        sc2 = torch.amp.GradScaler("cuda")
-        poses2, _ = make_training_rays(device, 2, 8, seed=rank)
-        b2 = [sample_batch(poses2, intr, device, gen) for _ in range(4)]
-        for i in range(17):
-            cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
-            if i == 15:
-                m2.mean_count = int(m2.step_counter[:16, 0].sum().item() / 16)    # what update_extra_state would set (renderer.py:533)
-        barrier()
-        n2 = max(args.steps, 10)
-        c0 = 0
-        t0 = time.perf_counter()
-        for i in range(n2):
-            cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
-        barrier()
-        el2 = max_over_ranks(time.perf_counter() - t0)
-        per_step = float(m2.step_counter[:, 0].float().mean().item())
-        result["occupancy_path"] = {"metric": "train_samples_per_sec", "value": world * per_step * n2 / el2, "unit": "samples/s",
-                                    "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
-                                    "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
-
-        # ---- configs[2] render half: full 800x800 view through the incremental march_rays / composite_rays loop
-        m2.eval()
-        ro2, rd2 = synthetic.get_rays(poses2[:1], intr, VIEW, VIEW)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            m2.render(ro2, rd2, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4, device_compaction=True)
+            # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
+            m2 = build_model(2, device, cuda_ray=True, seed=rank).train()
+            opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+            sc2 = torch.amp.GradScaler("cuda")
+            poses2, _ = make_training_rays(device, 2, 8, seed=rank)
+            b2 = [sample_batch(poses2, intr, device, gen) for _ in range(4)]
+            for i in range(17):
+                cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+                if i == 15:
+                    m2.mean_count = int(m2.step_counter[:16, 0].sum().item() / 16)    # what update_extra_state would set (renderer.py:533)
             barrier()
+            n2 = max(args.steps, 10)
+            c0 = 0
             t0 = time.perf_counter()
-            for _ in range(args.render_views):
+            for i in range(n2):
+                cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+            barrier()
+            el2 = max_over_ranks(time.perf_counter() - t0)
+            per_step = float(m2.step_counter[:, 0].float().mean().item())
+            result["occupancy_path"] = {"metric": "train_samples_per_sec", "value": world * per_step * n2 / el2, "unit": "samples/s",
+                                        "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
+                                        "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
+
+            # ---- configs[2] render half: full 800x800 view through the incremental march_rays / composite_rays loop
+            m2.eval()
+            ro2, rd2 = synthetic.get_rays(poses2[:1], intr, VIEW, VIEW)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 m2.render(ro2, rd2, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4, device_compaction=True)
-            barrier()
-        rel2 = max_over_ranks(time.perf_counter() - t0)
-        result["render_occupancy"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel2, "unit": "rays/s",
-                                      "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2"}
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.render_views):
+                    m2.render(ro2, rd2, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thresh=1e-4, device_compaction=True)
+                barrier()
+            rel2 = max_over_ranks(time.perf_counter() - t0)
+            result["render_occupancy"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel2, "unit": "rays/s",
+                                          "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2"}
+            # ---- density-grid maintenance (update_extra_state, every 16 steps in the reference trainer, utils.py:850-852), timed on its own:
+            # running it inside the loop above would replace the analytic occupancy grid by the untrained network's density
+            m2.train()
+            with torch.autocast("cuda", dtype=torch.float16):
+                for _ in range(17):                      # the first 16 calls sweep the full grid (renderer.py:461-476)
+                    m2.update_extra_state()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    m2.update_extra_state()
+                barrier()
+            result["occupancy_path"]["grid_update_ms"] = 1000 * (time.perf_counter() - t0) / 5
+            result["occupancy_path"]["grid_update_note"] = "update_extra_state, steady-state branch, once per 16 training steps; not inside ms_per_step"
+        except Exception as e:   # an extra must never take the headline number down with it
+            result["extras_error"] = repr(e)
 
     if not args.no_extras:
         # ---- configs[3]/[4]: per-sample multi-object combine, one object per rank (RCCL MAX all-reduce of keys + SUM of the winner's rgb)
