@@ -61,8 +61,11 @@ class NeRFNetwork(NeRFRenderer):
         return sigma, rgb
 
     def density(self, x):
-        x = self.encoder(x, bound=self.bound)
-        h = self.sigma_net(x)
+        from .field import field_fusable, hashgrid_mlp
+        if x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and field_fusable(self.encoder, self.sigma_net):
+            h = hashgrid_mlp(self.encoder, self.sigma_net, x, self.bound)       # same values; encoding kept in [L,B,C] planes
+        else:
+            h = self.sigma_net(self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
         return {'sigma': sigma, 'geo_feat': geo_feat}

@@ -11,8 +11,12 @@ Additions over the reference caller (both optional, both default to reference be
   * `device_compaction=True` in the inference loop keeps the alive-ray list on the device
     between iterations for the compaction itself (order preserving), instead of the boolean
     mask of legacy/nerf/renderer.py:363;
-  * `weight_thresh` makes the colour-query mask threshold explicit (1e-10 FOC / 1e-4 legacy).
+  * `weight_thresh` makes the colour-query mask threshold explicit (1e-10 FOC / 1e-4 legacy);
+  * density-grid maintenance (`mark_untrained_grid`, `update_extra_state`) runs on the device through
+    csrc/densitygrid.hip; `FOC_FUSED_GRID_UPDATE=0` selects the torch expressions of the
+    reference, which stay in this file as the parity baseline.
 """
+import os
 import math
 
 import time
@@ -46,11 +50,25 @@ class NeRFRenderer(nn.Module):
         if cuda_ray:
             self.register_buffer('density_grid', torch.zeros([self.cascade, self.grid_size ** 3]))
             self.register_buffer('density_bitfield', torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
-            self.mean_density = 0
+            self._mean_density = 0
+            self._mean_density_dev = None            # fused update: the mean stays on the device until someone reads `mean_density`
             self.iter_density = 0
             self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
             self.mean_count = 0
             self.local_step = 0
+
+    @property
+    def mean_density(self):
+        """Python float like the reference's attribute (renderer.py:497); synchronises only if a fused update left it on the device."""
+        if getattr(self, "_mean_density_dev", None) is not None:
+            self._mean_density = float(self._mean_density_dev.item())
+            self._mean_density_dev = None
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_density = value
+        self._mean_density_dev = None
 
     def forward(self, x, d):
         raise NotImplementedError()
@@ -222,10 +240,81 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ density grid maintenance
     @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """nerf/renderer.py:356-418 / legacy :380-443: cells no training camera sees get density -1 (never marched, never updated)."""
+        if not self.cuda_ray:
+            return
+        import numpy as np
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        dev = self.density_bitfield.device
+        poses = poses.to(dev).float()
+        if dev.type == "cuda" and os.environ.get("FOC_FUSED_GRID_UPDATE", "1") != "0":
+            from . import densitygrid
+            count = densitygrid.mark_untrained_grid(poses, intrinsic, self.bound, self.cascade, self.grid_size, self.density_grid, return_count=True)
+        else:
+            B = poses.shape[0]
+            fx, fy, cx, cy = intrinsic
+            X = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            count = torch.zeros_like(self.density_grid)
+            for xs in X:
+                for ys in X:
+                    for zs in X:
+                        xx, yy, zz = custom_meshgrid(xs, ys, zs)
+                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                        indices = raymarching.morton3D(coords).long()
+                        world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
+                        for cas in range(self.cascade):
+                            bound = min(2 ** cas, self.bound)
+                            half_grid_size = bound / self.grid_size
+                            cas_world_xyzs = world_xyzs * (bound - half_grid_size)
+                            head = 0
+                            while head < B:
+                                tail = min(head + S, B)
+                                cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
+                                cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
+                                mask_z = cam_xyzs[:, :, 2] > 0
+                                mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
+                                mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
+                                mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
+                                count[cas, indices] += mask
+                                head += S
+            self.density_grid[count == 0] = -1
+        return count
+
+    @torch.no_grad()
+    def _update_extra_state_fused(self, decay):
+        """update_extra_state through csrc/densitygrid.hip: same sampling scheme, EMA and threshold, one host read (mean_count)."""
+        from . import densitygrid
+        dev = self.density_bitfield.device
+        C, H = self.cascade, self.grid_size
+        if self.iter_density < 16:
+            jitter = torch.rand(C * H ** 3, 3, device=dev)
+            xyzs = densitygrid.grid_cells_xyz(C, H, self.bound, jitter, dev)
+            indices = None
+        else:
+            N = H ** 3 // 4
+            rand_coords = torch.randint(0, H, (C, N, 3), device=dev, dtype=torch.int32)
+            rand_pick = torch.rand(C, N, device=dev)
+            jitter = torch.rand(C * 2 * N, 3, device=dev)
+            indices, xyzs = densitygrid.grid_update_sample(self.density_grid, C, H, self.bound, rand_coords, rand_pick, jitter)
+        sigmas = self.density(xyzs)['sigma'].reshape(-1).detach()
+        mean_dev = torch.empty(1, dtype=torch.float32, device=dev)
+        densitygrid.grid_update_apply(self.density_grid, C, H, sigmas, indices, self.density_scale, decay, self.density_thresh, self.density_bitfield, mean_dev)
+        self._mean_density_dev = mean_dev
+        self.iter_density += 1
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
         """legacy/nerf/renderer.py:445-536."""
         if not self.cuda_ray:
             return
+        if self.density_bitfield.is_cuda and os.environ.get("FOC_FUSED_GRID_UPDATE", "1") != "0":
+            return self._update_extra_state_fused(decay)
         tmp_grid = - torch.ones_like(self.density_grid)
         dev = self.density_bitfield.device
         if self.iter_density < 16:

@@ -350,6 +350,38 @@ int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream);
 /* grad_rgb [M,3] fp32 -> grad_c [M,16] fp16 (columns 3..15 zero). */
 int foc_rgb_head_backward(const void *c, const float *grad_rgb, uint64_t M, void *grad_c, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Occupancy-grid maintenance on the device (csrc/densitygrid.hip). Reference: the torch code of
+ * NeRFRenderer.mark_untrained_grid (nerf/renderer.py:356-418) and NeRFRenderer.update_extra_state
+ * (nerf/renderer.py:420-508), which the reference runs from Python (no binding). density_grid is
+ * [cascade, H^3] fp32 in Morton order, bitfield uint8 [cascade * H^3 / 8]; random numbers come in as
+ * arrays so that a call can be replayed by the oracle.
+ * ------------------------------------------------------------------------- */
+
+/* poses [B,4,4] fp32 camera-to-world, row-major. count (int32 [cascade,H^3], may be NULL) = cameras that see
+ * the cell; density_grid[count == 0] = -1 (renderer.py:416). */
+int foc_mark_untrained_grid(const float *poses, uint32_t B, float fx, float fy, float cx, float cy, float bound,
+                            uint32_t cascade, uint32_t H, float *density_grid, int32_t *count, void *stream);
+/* Query points of the full sweep (the first 16 updates, renderer.py:430-453): xyzs [cascade*H^3,3], cell m of a
+ * cascade at row m (Morton order); jitter [cascade*H^3,3] uniform in [0,1) or NULL. */
+int foc_grid_cells_xyz(uint32_t cascade, uint32_t H, float bound, const float *jitter, float *xyzs, void *stream);
+/* Query points of the steady-state update (renderer.py:476-493): per cascade N uniformly random cells
+ * (rand_coords int32 [cascade,N,3] in [0,H)) followed by N cells drawn uniformly from the occupied ones
+ * (density_grid > 0; pick k = floor(rand_pick * n_occupied), rand_pick fp32 [cascade,N] in [0,1)).
+ * Outputs indices int32 [cascade,2N] (Morton), xyzs [cascade*2N,3] jittered by jitter [cascade*2N,3]. */
+uint64_t foc_grid_update_sample_workspace_bytes(uint32_t cascade, uint32_t H);
+int foc_grid_update_sample(const float *density_grid, uint32_t cascade, uint32_t H, float bound, uint32_t N,
+                           const int32_t *rand_coords, const float *rand_pick, const float *jitter,
+                           int32_t *indices, float *xyzs, void *workspace, uint64_t workspace_bytes, void *stream);
+/* tmp = -1; tmp[cas, indices] = sigmas * density_scale (largest on duplicates); where density_grid >= 0 and tmp >= 0:
+ * density_grid = max(density_grid * decay, tmp); mean_out (device fp32, may be NULL) = mean(clamp(density_grid, 0));
+ * bitfield = packbits(density_grid, min(mean, density_thresh))  (renderer.py:428, :493-503). sigmas fp32 [cascade*Mc];
+ * indices int32 [cascade*Mc], or NULL when sigmas cover every cell in Morton order (Mc == H^3). No host synchronisation. */
+uint64_t foc_grid_update_apply_workspace_bytes(uint32_t cascade, uint32_t H);
+int foc_grid_update_apply(float *density_grid, uint32_t cascade, uint32_t H, const float *sigmas, const int32_t *indices,
+                          uint32_t Mc, float density_scale, float decay, float density_thresh, uint8_t *bitfield,
+                          float *mean_out, void *workspace, uint64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

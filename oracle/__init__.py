@@ -87,6 +87,47 @@ def packbits(grid, thresh):
     return out
 
 
+# ---------------------------------------------------------------- density-grid maintenance
+def mark_untrained_grid(poses, intrinsics, bound, C, H, density_grid):
+    """Returns (density_grid with -1 where no camera sees the cell, count [C,H^3])."""
+    poses = _c(poses, np.float32).reshape(-1, 16)
+    grid = _c(density_grid, np.float32).copy()
+    count = np.empty(grid.shape, np.int32)
+    fx, fy, cx, cy = intrinsics
+    lib().orc_mark_untrained_grid(_p(poses), u32(poses.shape[0]), f32(fx), f32(fy), f32(cx), f32(cy), f32(bound), u32(C), u32(H), _p(grid), _p(count))
+    return grid, count
+
+
+def grid_cells_xyz(C, H, bound, jitter=None):
+    out = np.empty((C * H ** 3, 3), np.float32)
+    jit = _c(jitter, np.float32) if jitter is not None else None
+    lib().orc_grid_cells_xyz(u32(C), u32(H), f32(bound), _p(jit), _p(out))
+    return out
+
+
+def grid_update_sample(density_grid, C, H, bound, rand_coords, rand_pick, jitter):
+    grid = _c(density_grid, np.float32)
+    rc, rp, jit = _c(rand_coords, np.int32), _c(rand_pick, np.float32), _c(jitter, np.float32)
+    N = rc.shape[1]
+    idx = np.empty((C, 2 * N), np.int32)
+    xyz = np.empty((C * 2 * N, 3), np.float32)
+    lib().orc_grid_update_sample(_p(grid), u32(C), u32(H), f32(bound), u32(N), _p(rc), _p(rp), _p(jit), _p(idx), _p(xyz))
+    return idx, xyz
+
+
+def grid_update_apply(density_grid, C, H, sigmas, indices, density_scale, decay, density_thresh):
+    """Returns (new density_grid, bitfield, mean_density)."""
+    grid = _c(density_grid, np.float32).copy()
+    sig = _c(sigmas, np.float32)
+    idx = _c(indices, np.int32) if indices is not None else None
+    Mc = sig.size // C
+    bits = np.empty(C * H ** 3 // 8, np.uint8)
+    fn = lib().orc_grid_update_apply
+    fn.restype = ctypes.c_float
+    mean = fn(_p(grid), u32(C), u32(H), _p(sig), _p(idx), u32(Mc), f32(density_scale), f32(decay), f32(density_thresh), _p(bits))
+    return grid, bits, float(mean)
+
+
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises, counter=None):
     rays_o, rays_d = _c(rays_o, np.float32), _c(rays_d, np.float32)
     grid = _c(grid, np.uint8)

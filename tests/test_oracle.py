@@ -255,3 +255,56 @@ def test_combine_select_tie_rule():
     m, b = oracle.combine_select(dens, rgb, maxd, best)
     assert list(m) == [2.0, 2.0, 2.0, 0.0]
     assert list(b[:, 0]) == [0.0, 9.0, 0.0, 0.0]               # strict '>': ties keep the earlier object
+
+
+# ---------------------------------------------------------------- density-grid maintenance (nerf/renderer.py:356-508)
+def test_mark_untrained_grid_known_answers():
+    """One camera at (0,0,-3) looking along +z (identity rotation): cells in front within the frustum are seen, a camera
+    looking away sees nothing; the count is the number of cameras."""
+    H, C, bound = 16, 1, 1
+    pose = np.eye(4, dtype=np.float32)
+    pose[2, 3] = -3.0
+    intr = (100.0, 100.0, 50.0, 50.0)          # tan(half fov) = 0.5
+    grid = np.ones((C, H ** 3), np.float32)
+    g, cnt = oracle.mark_untrained_grid(pose[None], intr, bound, C, H, grid)
+    assert (cnt == 1).all() and (g == 1).all()                     # the whole unit cube is inside a 53-degree frustum from z = -3
+    back = pose.copy()
+    back[:3, :3] = np.diag([1, 1, -1]).astype(np.float32)           # looking along -z
+    g, cnt = oracle.mark_untrained_grid(back[None], intr, bound, C, H, grid)
+    assert (cnt == 0).all() and (g == -1).all()
+    g, cnt = oracle.mark_untrained_grid(np.stack([pose, pose, back]), intr, bound, C, H, grid)
+    assert (cnt == 2).all()
+    # a narrow camera (tan = 0.05) sees only the cells near its axis: |x| < 0.05 * (z + 3) + 2 * half_cell
+    narrow = (1000.0, 1000.0, 50.0, 50.0)
+    g, cnt = oracle.mark_untrained_grid(pose[None], narrow, bound, C, H, grid)
+    coords = oracle.morton3D_invert(np.arange(H ** 3, dtype=np.int32)).astype(np.float64)
+    w = (2 * coords / (H - 1) - 1) * (1 - 1 / H)
+    lim = 0.05 * (w[:, 2] + 3) + 2.0 / H
+    want = (np.abs(w[:, 0]) < lim) & (np.abs(w[:, 1]) < lim)
+    assert (cnt[0] > 0).sum() == want.sum() and np.array_equal(cnt[0] > 0, want)
+
+
+def test_grid_update_known_answers():
+    H, C = 8, 2
+    H3 = H ** 3
+    grid = np.zeros((C, H3), np.float32)
+    grid[0, 5] = 2.0
+    grid[1, 7] = -1.0                                               # untrained: never updated
+    idx = np.array([[5, 5, 9], [7, 3, 3]], np.int32)
+    sig = np.array([1.0, 1.5, 4.0, 9.0, 0.25, 0.5], np.float32)
+    g, bits, mean = oracle.grid_update_apply(grid, C, H, sig, idx, 2.0, 0.5, 100.0)
+    assert g[0, 5] == 3.0                   # max(2.0 * 0.5, max(1.0, 1.5) * 2.0)
+    assert g[0, 9] == 8.0 and g[1, 3] == 1.0 and g[1, 7] == -1.0
+    assert abs(mean - (3.0 + 8.0 + 1.0) / (C * H3)) < 1e-9
+    want = np.zeros(C * H3, np.uint8)
+    want[[5, 9, H3 + 3]] = 1                # threshold = min(mean, 100) = mean ~ 0.0117
+    assert np.array_equal(np.unpackbits(bits, bitorder="little"), want)
+    # sampling: with one occupied cell every pick lands on it; the first half are the random cells
+    rc = np.array([[[1, 2, 3], [0, 0, 0]], [[7, 7, 7], [1, 0, 0]]], np.int32)
+    occ = np.zeros((C, H3), np.float32)
+    occ[0, 100] = 1.0
+    idx2, xyz = oracle.grid_update_sample(occ, C, H, 2, rc, np.array([[0.0, 0.999], [0.3, 0.7]], np.float32), np.full((C * 4, 3), 0.5, np.float32))
+    assert list(idx2[0]) == [int(oracle.morton3D(rc[0])[0]), 0, 100, 100]
+    assert list(idx2[1]) == [511, 1, 511, 1]                         # cascade 1 has no occupied cell: the random cells are repeated
+    c = oracle.morton3D_invert(np.array([100], np.int32))[0].astype(np.float32)
+    assert np.array_equal(xyz[2], (2 * c / (H - 1) - 1) * np.float32(1 - 1 / H))     # jitter 0.5 -> centre of the cell, cascade 0 scale
