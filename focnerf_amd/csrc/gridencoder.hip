@@ -214,9 +214,10 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     }
 }
 
-// Level-major launch, outputs [L,B,C] (or, OUT_BL, [B,L*C]): thread = point, block decodes (level, chunk) XCD-aware,
-// so a level's table (<= 2 MiB at 2^19 x half2) stays in the L2 of the one XCD that works on it.
-template <typename T, uint32_t D, uint32_t C, bool OUT_BL>
+// Level-major launch, outputs [L,B,C]: thread = point. `plain`: blocks are numbered level by level, so the whole chip walks ONE
+// level at a time and every XCD's 4 MiB L2 holds that level's table (<= 2 MiB at 2^19 x half2); otherwise a level is pinned to one
+// XCD (ge_decode_block), which balances badly because the cost of a level grows ~5x from level 0 to 15 (tools/time_levels.py).
+template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                       const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                       uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
@@ -232,8 +233,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ 
     const bool oob = ge_load_point<D>(inputs, b, x);
     T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
     ge_forward_one<T, D, C>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                            OUT_BL ? outputs + ((uint64_t)b * L + level) * C : outputs + ((uint64_t)level * B + b) * C, dy, gridtype,
-                            align_corners, interp);
+                            outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
 }
 
 // Point-major launch, outputs [B, L*C]: consecutive lanes = consecutive levels of one point, so
@@ -379,7 +379,6 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
 #define GB_SEG (1u << GB_SEG_SHIFT)            // rows per segment
 #define GB_MAX_SEGS 64u                        // per level: covers 2^19-row levels
 #define GB_CHUNK 65536u                        // records per reduce workgroup
-#define GB_SPT 4u                              // samples per thread in count/scatter
 #define GB_WG 256u
 
 struct GbHeader {                              // lives at the start of the workspace
@@ -469,42 +468,6 @@ __device__ __forceinline__ float gb_run_sum(float v, const GbRun &run) {
     return v;
 }
 
-template <typename T, bool GRAD_BL>
-__device__ __forceinline__ bool gb_load(const T *__restrict__ grad, const float *__restrict__ inputs, uint32_t b, uint32_t level, uint32_t B,
-                                        uint32_t L, float (&x)[3], float (&g)[2]) {
-    if (b >= B) return false;
-    if (ge_load_point<3>(inputs, b, x)) return false;
-    const T *gp = GRAD_BL ? grad + ((uint64_t)b * L + level) * 2 : grad + ((uint64_t)level * B + b) * 2;
-    GeVec<T, 2>::ld(gp, g);
-    return (g[0] != 0.0f) || (g[1] != 0.0f);
-}
-
-template <typename T, bool GRAD_BL>
-__global__ void __launch_bounds__(GB_WG) k_gbin_count(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                      GbHeader *__restrict__ hdr, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-                                                      bool align_corners, uint32_t interp, uint32_t chunks) {
-    __shared__ uint32_t hist[GB_MAX_SEGS];
-    uint32_t level, chunk;
-    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
-    if (threadIdx.x < GB_MAX_SEGS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
-#pragma unroll
-    for (uint32_t s = 0; s < GB_SPT; s++) {
-        const uint32_t b = (chunk * GB_SPT + s) * GB_WG + threadIdx.x;
-        float x[3], g[2];
-        if (gb_load<T, GRAD_BL>(grad, inputs, b, level, B, L, x, g)) {
-            uint32_t rows[8]; float ws[8];
-            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
-#pragma unroll
-            for (int i = 0; i < 8; i++) atomicAdd(&hist[rows[i] >> GB_SEG_SHIFT], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < GB_MAX_SEGS && hist[threadIdx.x])
-        (void)__hip_atomic_fetch_add(&hdr->counts[level * GB_MAX_SEGS + threadIdx.x], hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // single workgroup: prefix sums over L * 64 segment counts
 __global__ void __launch_bounds__(1024) k_gbin_scan(GbHeader *__restrict__ hdr, uint32_t L) {
     __shared__ uint32_t s_rec[GE_MAX_LEVELS * GB_MAX_SEGS];
@@ -527,144 +490,10 @@ __global__ void __launch_bounds__(1024) k_gbin_scan(GbHeader *__restrict__ hdr, 
     }
 }
 
-// Level-major scatter. The workgroup's GB_WG*GB_SPT*8 = 8192 records are first SORTED BY SEGMENT in LDS (rank inside the
-// segment from an LDS returning atomic, exclusive prefix over the 64 segment counts), then copied out flat: consecutive lanes
-// carry consecutive records of one segment, so a wave stores 512 contiguous bytes instead of 64 scattered 8-byte pieces
-// (the scattered form ran at 175 G stores/s: 1.5 ms for the 268 M records of a 2 M-point step).
-template <typename T, bool GRAD_BL>
-__global__ void __launch_bounds__(GB_WG) k_gbin_scatter(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                        GbHeader *__restrict__ hdr, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L,
-                                                        GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks) {
-    constexpr uint32_t NREC = GB_WG * GB_SPT * 8u;
-    __shared__ uint32_t hist[GB_MAX_SEGS];
-    __shared__ uint32_t prefix[GB_MAX_SEGS + 1];
-    __shared__ uint32_t gbase[GB_MAX_SEGS];
-    __shared__ uint32_t s_row[NREC];              // local row | segment << 16
-    __shared__ uint32_t s_v0[NREC];               // fp16: packed half2 ; fp32: channel 0 bits
-    __shared__ uint32_t s_v1[sizeof(T) == 2 ? 1 : NREC];
-    uint32_t level, chunk;
-    if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
-    if (threadIdx.x < GB_MAX_SEGS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
-    uint32_t key[GB_SPT][8];          // (segment << 26) | rank-in-workgroup     (rank < 8192)
-    uint32_t lrow[GB_SPT][8];
-    float val[GB_SPT][8][2];
-    bool live[GB_SPT];
-#pragma unroll
-    for (uint32_t s = 0; s < GB_SPT; s++) {
-        const uint32_t b = (chunk * GB_SPT + s) * GB_WG + threadIdx.x;
-        float x[3], g[2];
-        live[s] = gb_load<T, GRAD_BL>(grad, inputs, b, level, B, L, x, g);
-        if (live[s]) {
-            uint32_t rows[8]; float ws[8];
-            gb_corners<3>(x, hashmap_size, lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
-                const uint32_t rank = atomicAdd(&hist[seg], 1u);
-                key[s][i] = (seg << 26) | rank;
-                lrow[s][i] = rows[i] & (GB_SEG - 1u);
-                val[s][i][0] = ws[i] * g[0];
-                val[s][i][1] = ws[i] * g[1];
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                       // one wave: exclusive prefix of the 64 counts + the global reservations
-        const uint32_t h = hist[threadIdx.x];
-        const uint32_t incl = (uint32_t)wave_incl_sum_i((int)h, (int)threadIdx.x);
-        prefix[threadIdx.x] = incl - h;
-        if (threadIdx.x == 63) prefix[64] = incl;
-        const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
-        gbase[threadIdx.x] = h ? hdr->base[slot] + __hip_atomic_fetch_add(&hdr->cursor[slot], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t s = 0; s < GB_SPT; s++) {
-        if (!live[s]) continue;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t seg = key[s][i] >> 26;
-            const uint32_t pos = prefix[seg] + (key[s][i] & 0x3FFFFFFu);
-            s_row[pos] = lrow[s][i] | (seg << 16);
-            if constexpr (sizeof(T) == 2) {
-                const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(val[s][i][0])), __float2half_rn(ge_opaque(val[s][i][1])));
-                s_v0[pos] = *reinterpret_cast<const uint32_t *>(&hv);
-            } else {
-                s_v0[pos] = __float_as_uint(val[s][i][0]);
-                s_v1[pos] = __float_as_uint(val[s][i][1]);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t total = prefix[64];
-    for (uint32_t j = threadIdx.x; j < total; j += GB_WG) {
-        const uint32_t rw = s_row[j];
-        const uint32_t seg = rw >> 16;
-        const uint64_t at = (uint64_t)gbase[seg] + (j - prefix[seg]);
-        if (at >= max_recs) continue;              // cannot happen when count and scatter agree; keeps a logic slip from faulting
-        if constexpr (sizeof(T) == 2) {
-            reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rw & 0xFFFFu, s_v0[j]);
-        } else {
-            uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
-            float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));   // values follow the row array (8-B aligned)
-            rr[at] = rw & 0xFFFFu;
-            vv[at] = make_float2(__uint_as_float(s_v0[j]), __uint_as_float(s_v1[j]));
-        }
-    }
-}
-
-// ---- point-major count / scatter for the [B, L*C] gradient layout -----------------------------
-// With grad laid out [B, L*C] a level-major kernel reads 4 bytes per 64-byte line and every level runs on a
-// different XCD, so each line is fetched 16 times (PMC: 2.5 GB per pass for 134 MB of gradient). Here lane g
-// handles (point g / L, level g % L): the gradient read is contiguous, the point is an L1 broadcast. A
-// workgroup owns GB_PM_TILE points x all levels, keeps one LDS counter per (level, segment) and talks to the
-// global counters once per non-empty (level, segment).
+// ---- one-point-per-thread count / scatter -------------------------------------------------------
+// A workgroup owns GB_PM_TILE points x all levels, keeps one LDS counter per (level, segment) and talks to the global counters
+// once per non-empty (level, segment); its own counts per slot give it a deterministic record range (k_gbin_wgscan).
 #define GB_PM_TILE 1024u
-
-template <typename T>
-__device__ __forceinline__ bool gb_load_pm(const T *__restrict__ grad, const float *__restrict__ inputs, uint64_t g, uint32_t L, uint64_t total,
-                                           uint32_t &level, float (&x)[3], float (&gv)[2]) {
-    if (g >= total) return false;
-    const uint32_t b = (uint32_t)(g / L);
-    level = (uint32_t)(g - (uint64_t)b * L);
-    if (ge_load_point<3>(inputs, b, x)) return false;
-    GeVec<T, 2>::ld(grad + g * 2, gv);
-    return (gv[0] != 0.0f) || (gv[1] != 0.0f);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(GB_WG) k_gbin_count_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                         GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv,
-                                                         uint32_t gridtype, bool align_corners, uint32_t interp) {
-    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
-    __shared__ uint32_t s_size[GE_MAX_LEVELS];
-    const uint32_t nslots = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) hist[i] = 0;
-    if (threadIdx.x < L) s_size[threadIdx.x] = (uint32_t)offsets[threadIdx.x + 1] - (uint32_t)offsets[threadIdx.x];
-    __syncthreads();
-    const uint64_t total = (uint64_t)B * L;
-    const uint64_t g0 = (uint64_t)blockIdx.x * GB_PM_TILE * L;
-    const uint32_t span = GB_PM_TILE * L;
-    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
-        uint32_t level; float x[3], g[2];
-        if (gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) {
-            uint32_t rows[8]; float ws[8];
-            gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
-#pragma unroll
-            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
-        }
-    }
-    __syncthreads();
-    // totals per (level, segment), and this workgroup's own counts ([slot][workgroup]) so that the scatter pass gets a
-    // precomputed, deterministic base per (workgroup, slot) and needs neither a second counting phase nor reservation atomics
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) {
-        const uint32_t hcount = hist[i];
-        if (hcount) (void)__hip_atomic_fetch_add(&hdr->counts[i], hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wg_hist[(uint64_t)i * gridDim.x + blockIdx.x] = hcount;
-    }
-}
 
 // per slot: exclusive scan over the workgroups' counts, offset by the slot's global base (in place)
 __global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t n_wg) {
@@ -683,57 +512,6 @@ __global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict_
     for (uint32_t k = 0; k < wave; k++) wbase += s_wave[k];
     uint32_t run = hdr->base[slot] + wbase + (incl - local);
     for (uint32_t i = lo; i < hi; i++) { const uint32_t c = col[i]; col[i] = run; run += c; }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(GB_WG) k_gbin_scatter_pm(const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
-                                                           const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B,
-                                                           uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t diag) {
-    __shared__ uint32_t cursor[GE_MAX_LEVELS * GB_MAX_SEGS];   // next free record of this workgroup's range, per (level, segment)
-    __shared__ uint32_t s_size[GE_MAX_LEVELS];
-    const uint32_t nslots = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_WG) cursor[i] = wg_base[(uint64_t)i * gridDim.x + blockIdx.x];
-    if (threadIdx.x < L) s_size[threadIdx.x] = (uint32_t)offsets[threadIdx.x + 1] - (uint32_t)offsets[threadIdx.x];
-    __syncthreads();
-    const uint64_t total = (uint64_t)B * L;
-    const uint64_t g0 = (uint64_t)blockIdx.x * GB_PM_TILE * L;
-    const uint32_t span = GB_PM_TILE * L;
-    for (uint32_t it = threadIdx.x; it < span; it += GB_WG) {
-        uint32_t level; float x[3], g[2];
-        if (!gb_load_pm<T>(grad, inputs, g0 + it, L, total, level, x, g)) continue;
-        uint32_t rows[8]; float ws[8];
-        gb_corners<3>(x, s_size[level], lv.scale[level], lv.resolution[level], gridtype, align_corners, interp, rows, ws);
-        uint32_t at[8];
-        if (diag & 2u) {      // DIAGNOSTIC timing build (FOC_GBIN_DIAG): linear positions instead of the LDS cursor atomics — results are wrong
-#pragma unroll
-            for (int i = 0; i < 8; i++) at[i] = (uint32_t)((g0 + it) * 8 + i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) at[i] = atomicAdd(&cursor[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
-        }
-        if (diag & 1u) {      // DIAGNOSTIC: skip the record stores (keep the values alive)
-            uint32_t keep = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) keep ^= at[i] ^ __float_as_uint(ws[i] * g[0]);
-            if (keep == 0xDEADBEEFu) reinterpret_cast<uint32_t *>(recs)[0] = keep;
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (at[i] >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
-            const uint32_t lrow = rows[i] & (GB_SEG - 1u);
-            const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
-            if constexpr (sizeof(T) == 2) {
-                const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
-                reinterpret_cast<uint2 *>(recs)[at[i]] = make_uint2(lrow, *reinterpret_cast<const uint32_t *>(&hv));
-            } else {
-                uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
-                float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-                rr[at[i]] = lrow;
-                vv[at[i]] = make_float2(v0, v1);
-            }
-        }
-    }
 }
 
 // One point per thread count pass, the partner of k_gbin_scatter_pms (same tile, same run merging).
@@ -770,21 +548,19 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
     }
 }
 
-// Point-major tile, level-sequential, LDS-sorted scatter. The plain point-major scatter above is bound by the number of store
-// REQUESTS: 268 M separate 8-byte stores per 2 M-point step, each a partial 64-byte-line write (measured 1.2 ms of its 1.5 ms;
-// with the stores removed it runs in 0.26 ms). Here a workgroup still owns GB_PM_TILE points (so the per-workgroup bases of
-// k_gbin_count_pm apply and the [B, L*C] gradient lines are reused across levels out of L1/L2), but it walks the levels one at a
-// time: the workgroup's record count per segment is the difference of two neighbouring per-workgroup bases, so the segment
-// prefix inside the LDS staging array is known up front; each record takes its place with one LDS cursor atomic, and the staging
-// array is copied out flat, so a wave stores 512 contiguous bytes. Two barriers per level; the bases of the next level are
-// fetched while the current one is ranked.
-// One point per thread (1024-thread workgroups, two per CU for fp16 tables): the point and its whole [L*C] gradient row are
-// loaded once, as full 64-byte lines, and stay in registers for the walk over the levels.
+// Level-sequential, LDS-sorted scatter, one point per thread (1024-thread workgroups, two per CU for fp16 tables).
+// Writing each 8-byte record straight to its slot is bound by the number of store REQUESTS: 268 M partial 64-byte-line writes per
+// 2 M-point step (measured 1.2 of 1.5 ms; 0.26 ms with the stores compiled out). Here the point and its gradient (a 64-byte
+// [B, L*C] row, or 16 coalesced dwords from the [L,B,C] planes) are loaded once and stay in registers; the workgroup walks the levels
+// one at a time: its record count per segment is the difference of two neighbouring per-workgroup bases, so the segment prefix
+// inside the LDS staging array is known up front; each record takes its place with one LDS cursor atomic, and the staging array is
+// copied out flat, so a wave stores 512 contiguous bytes. Two barriers per level; the bases of the next level are fetched while the
+// current one is ranked.
 template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-    bool align_corners, uint32_t interp, uint32_t diag, bool grad_bl) {
+    bool align_corners, uint32_t interp, bool grad_bl) {
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
     constexpr uint32_t NREC = GB_PM_TILE * 8u;
     __shared__ uint32_t cur[2][GB_MAX_SEGS];               // next free staging position per segment (double-buffered by level parity)
@@ -902,13 +678,12 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             }
         }
         __syncthreads();
-        const uint32_t total = (diag & 2u) ? 0u : min(pre[pb][GB_MAX_SEGS], NREC);   // DIAGNOSTIC bit 1: no copy-out
+        const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
         for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
             const uint32_t rw = s_row[j];
             const uint32_t seg = rw >> 16;
             const uint64_t at = (uint64_t)gb[pb][seg] + (j - pre[pb][seg]);
             if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
-            if ((diag & 1u) && rw != 0xDEADBEEFu) continue;   // DIAGNOSTIC timing build (FOC_GBIN_DIAG=1): no record stores, WRONG RESULTS
             if constexpr (sizeof(T) == 2) {
                 reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rw & 0xFFFFu, s_v0[j]);
             } else {
@@ -1121,22 +896,16 @@ static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * ch
 template <typename T, uint32_t D, uint32_t C>
 static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
                              const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
-    static int level_major = -1;                 // FOC_GRID_FWD_LM=1: level-major XCD-affine kernel for the [B,L*C] output too (tuning)
-    if (level_major < 0) { const char *e = getenv("FOC_GRID_FWD_LM"); level_major = e ? atoi(e) : 0; }
     static int lm_plain = -1;                    // FOC_GRID_LM_PLAIN=0: pin each level to one XCD instead of walking the levels chip-wide (tuning)
     if (lm_plain < 0) { const char *e = getenv("FOC_GRID_LM_PLAIN"); lm_plain = e ? atoi(e) : 1; }
-    if (bl && level_major) {
-        const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, true>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
-                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain);
-    } else if (bl) {
+    if (bl) {
         const uint64_t total = (uint64_t)B * L;
         const uint32_t grid = (uint32_t)((total + 255) / 256 > 0x7FFFFFFFull ? 0x7FFFFFFFull : (total + 255) / 256);
         hipLaunchKernelGGL((k_grid_fwd_bl<T, D, C>), dim3(grid), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv,
                            (T *)dy_dx, gridtype, ac, interp);
     } else {
         const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C, false>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
@@ -1256,44 +1025,18 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
     const uint64_t max_recs = gb_max_recs(B, L);
     if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
-    static int use_pm = -1;                      // FOC_GBIN_PM=0 selects the level-major count/scatter for [B,L*C] gradients too (tuning)
-    if (use_pm < 0) { const char *e = getenv("FOC_GBIN_PM"); use_pm = e ? atoi(e) : 1; }
-    static int sorted_scatter = -1;              // FOC_GBIN_SORTED=0 selects the unsorted, unmerged count/scatter pairs (tuning)
-    if (sorted_scatter < 0) { const char *e = getenv("FOC_GBIN_SORTED"); sorted_scatter = e ? atoi(e) : 1; }
-    if ((bl || sorted_scatter) && use_pm) {
-        const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
-        const dim3 grid(n_wg);
-        uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
-        static int diag = -1;                    // FOC_GBIN_DIAG: timing-only builds of the scatter pass (bit 0: no stores, bit 1: no copy-out); WRONG RESULTS
-        if (diag < 0) { const char *e = getenv("FOC_GBIN_DIAG"); diag = e ? atoi(e) : 0; }
-        if (sorted_scatter)
-            hipLaunchKernelGGL(k_gbin_count_pt, grid, dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
-        else
-            hipLaunchKernelGGL((k_gbin_count_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
-        FOC_CHECK_LAUNCH("grid_encode_backward(count)");
-        hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
-        FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
-        hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
-        FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
-        if (sorted_scatter)
-            hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
-                               (uint32_t)diag, bl);
-        else
-            hipLaunchKernelGGL((k_gbin_scatter_pm<T>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, wg_hist, recs, max_recs, B, L, lv, gridtype, ac, interp,
-                               (uint32_t)diag);
-        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
-    } else {
-        const uint32_t chunks = foc_div_up(B, GB_WG * GB_SPT);
-        const dim3 grid(ge_xcd_grid(chunks, L));
-        if (bl) hipLaunchKernelGGL((k_gbin_count<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
-        else hipLaunchKernelGGL((k_gbin_count<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, B, L, lv, gridtype, ac, interp, chunks);
-        FOC_CHECK_LAUNCH("grid_encode_backward(count)");
-        hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
-        FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
-        if (bl) hipLaunchKernelGGL((k_gbin_scatter<T, true>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
-        else hipLaunchKernelGGL((k_gbin_scatter<T, false>), grid, dim3(GB_WG), 0, st, (const T *)grad, inputs, offsets, hdr, recs, max_recs, B, L, lv, gridtype, ac, interp, chunks);
-        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
-    }
+    const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
+    const dim3 grid(n_wg);
+    uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
+    hipLaunchKernelGGL(k_gbin_count_pt, grid, dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
+    FOC_CHECK_LAUNCH("grid_encode_backward(count)");
+    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
+    hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
+    FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
+    hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
+                       interp, bl);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;
     hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
     FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
