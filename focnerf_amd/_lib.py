@@ -35,7 +35,7 @@ SIGNATURES = {
     "foc_packbits": (i32, [c_vp, u32, f32, c_vp, c_vp]),
     "foc_march_rays_train": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "foc_march_rays_train_scratch_bytes": (u64, [u32]),
+    "foc_march_rays_train_scratch_bytes": (u64, [u32, u32]),
     "foc_composite_rays_train_forward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp]),
     "foc_composite_rays_train_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32,
                                                 c_vp, c_vp, c_vp]),

@@ -82,7 +82,7 @@ class _raymarching:
         require_cuda(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
         _f32(rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises); _contig(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
         assert grid.dtype == torch.uint8 and rays.dtype == torch.int32 and counter.dtype == torch.int32
-        scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(N), rays_o.device)
+        scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(N, max_steps), rays_o.device)
         check(lib.foc_march_rays_train(ptr(rays_o), ptr(rays_d), ptr(grid), bound, dt_gamma, max_steps, N, C, H, M, ptr(nears), ptr(fars),
                                        ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(counter), ptr(noises), ptr(scratch),
                                        stream_of(rays_o)), "march_rays_train")

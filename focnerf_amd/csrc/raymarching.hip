@@ -199,7 +199,7 @@ static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, 
 __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                               const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
                               const float *__restrict__ nears, const float *__restrict__ fars,
-                              const float *__restrict__ noises, int32_t *__restrict__ counts) {
+                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
@@ -210,8 +210,12 @@ __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ ra
     t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
     uint32_t num_steps = 0;
     RmCell c;
+    // The marching loop is a chain of dependent L2 lookups: running it a second time to write the samples (as the reference does,
+    // raymarching.cu:415-479) doubles that latency-bound cost. The `t` of every emitted sample is kept in a per-ray strip instead
+    // (max_steps floats per ray), from which k_march_emit rebuilds position, dt and the two deltas with the loop's own expressions.
+    float *strip = tstrip + (uint64_t)n * max_steps;
     while (t < far && num_steps < max_steps) {
-        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) { num_steps++; t += c.dt; }
+        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) { strip[num_steps] = t; num_steps++; t += c.dt; }
         else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
     }
     counts[n] = (int32_t)num_steps;
@@ -253,37 +257,38 @@ __global__ void __launch_bounds__(1024) k_march_scan(const int32_t *__restrict__
     if (tid == 0) { counter[0] = base0 + s_total; counter[1] = ray0 + (int32_t)N; }
 }
 
-// ---------------------------------------------------------------- R6 pass 3: write (raymarching.cu:415-479)
-__global__ void __launch_bounds__(64) k_march_write(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                              const uint8_t *__restrict__ grid, RmParams p, uint32_t N, uint32_t M,
-                              const float *__restrict__ nears, const float *__restrict__ fars,
-                              const float *__restrict__ noises, const int32_t *__restrict__ rays,
-                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+// ---------------------------------------------------------------- R6 pass 3: emit (raymarching.cu:415-479)
+// One wave per ray, lane k = sample k: t_k from the strip; xyz = clamp(o + t d), dt = clamp(t dt_gamma) exactly as rm_cell forms them;
+// deltas = (dt_k, (t_k + dt_k) - last_t) with last_t = t_{k-1} + dt_{k-1} (the start t for k = 0), as the loop accumulates them.
+// Stores are contiguous across the wave (768 B of xyz per 64 samples).
+__global__ void __launch_bounds__(256) k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, RmParams p, uint32_t max_steps,
+                                                    uint32_t N, uint32_t M, const float *__restrict__ nears, const float *__restrict__ noises,
+                                                    const int32_t *__restrict__ rays, const float *__restrict__ tstrip,
+                                                    float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t point_index = (uint32_t)rays[n * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
     if (num_steps == 0) return;
-    if (point_index + num_steps > M) return;
+    if (point_index + num_steps > M) return;                       // raymarching.cu:413
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    const float far = fars[n];
-    float t = nears[n];
-    t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
-    float last_t = t;
-    float *px = xyzs + (uint64_t)point_index * 3, *pd = dirs + (uint64_t)point_index * 3, *pl = deltas + (uint64_t)point_index * 2;
-    uint32_t step = 0;
-    RmCell c;
-    while (t < far && step < num_steps) {
-        if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
-            px[0] = c.x; px[1] = c.y; px[2] = c.z;
-            pd[0] = dx; pd[1] = dy; pd[2] = dz;
-            t += c.dt;
-            pl[0] = c.dt; pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2; step++;
-        } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+    float t0 = nears[n];
+    t0 = fmaf(rm_clamp(t0 * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t0);
+    const float *strip = tstrip + (uint64_t)n * max_steps;
+    for (uint32_t k = lane; k < num_steps; k += 64) {
+        const float t = strip[k];
+        const float dt = rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max);
+        float last_t = t0;
+        if (k > 0) { const float tp = strip[k - 1]; last_t = tp + rm_clamp(tp * p.dt_gamma, p.dt_min, p.dt_max); }
+        const uint64_t s = (uint64_t)point_index + k;
+        xyzs[s * 3] = rm_clamp(fmaf(t, dx, ox), -p.bound, p.bound);
+        xyzs[s * 3 + 1] = rm_clamp(fmaf(t, dy, oy), -p.bound, p.bound);
+        xyzs[s * 3 + 2] = rm_clamp(fmaf(t, dz, oz), -p.bound, p.bound);
+        dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz;
+        deltas[s * 2] = dt;
+        deltas[s * 2 + 1] = (t + dt) - last_t;
     }
 }
 
@@ -558,7 +563,9 @@ int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
     return FOC_OK;
 }
 
-uint64_t foc_march_rays_train_scratch_bytes(uint32_t N) { return ((uint64_t)N + 64) * sizeof(int32_t); }
+// counts [N] (+ pad), then the per-ray strips of sample positions [N, max_steps]
+static uint64_t rm_strip_offset(uint32_t N) { return (((uint64_t)N + 64) * sizeof(int32_t) + 255) & ~(uint64_t)255; }
+uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) { return rm_strip_offset(N) + (uint64_t)N * max_steps * sizeof(float); }
 
 int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -574,15 +581,16 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_train: C*H^3 exceeds 2^24");
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch);
+    float *tstrip = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + rm_strip_offset(N));
+    hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     FOC_CHECK_LAUNCH("march_rays_train(count)");
     // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, st, scratch, N, rays, counter);
     FOC_CHECK_LAUNCH("march_rays_train(scan)");
-    hipLaunchKernelGGL(k_march_write, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, N, M, nears, fars, noises,
-                       rays, xyzs, dirs, deltas);
-    FOC_CHECK_LAUNCH("march_rays_train(write)");
+    hipLaunchKernelGGL(k_march_emit, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs, dirs,
+                       deltas);
+    FOC_CHECK_LAUNCH("march_rays_train(emit)");
     return FOC_OK;
 }
 

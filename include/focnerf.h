@@ -77,7 +77,9 @@ int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
  * Order: the reference's slot order depends on atomicAdd arrival; this implementation
  * reserves slots by an exclusive scan in RAY ORDER (one of the reference's legal outcomes),
  * so the result is deterministic: rays[i] = (i, counter0_before + sum_{j<i} n_j, n_i).
- * scratch: device int32 [N + 64] (per-ray counts + scan carry), caller-owned.          */
+ * scratch: caller-owned device bytes (foc_march_rays_train_scratch_bytes): per-ray counts + scan carry, and one
+ * strip of max_steps sample positions per ray, so that the occupancy walk runs once (the reference walks every ray
+ * twice, raymarching.cu:357-399 and :415-479). */
 int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid,
                          float bound, float dt_gamma, uint32_t max_steps,
                          uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -85,8 +87,8 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises,
                          int32_t *scratch, void *stream);
-/* Bytes of `scratch` needed by foc_march_rays_train for N rays. */
-uint64_t foc_march_rays_train_scratch_bytes(uint32_t N);
+/* Bytes of `scratch` needed by foc_march_rays_train for N rays of at most max_steps samples. */
+uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
 
 /* raymarching.cu:500-588  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                      weights_sum, depth, image) */
