@@ -414,6 +414,35 @@ __device__ __forceinline__ void gb_cell_rows(const uint32_t (&pos_grid)[D], uint
         rows[idx] = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
     }
 }
+// The same 8 rows for D = 3 with the per-level decisions (which dimensions enter the dense index, dense or hashed, power-of-two
+// size) taken once on wave-uniform values and the per-axis terms shared between the corners: (p+1)*k = p*k + k in uint32, so every
+// row is two adds or two xors instead of ge_index's per-corner multiplies and branches. Bit-identical to gb_cell_rows<3>.
+__device__ __forceinline__ void gb_cell_rows3(const uint32_t (&pos_grid)[3], uint32_t hashmap_size, uint32_t resolution, uint32_t gridtype,
+                                              bool align_corners, uint32_t (&rows)[8]) {
+    const uint32_t r1 = align_corners ? resolution : resolution + 1u;
+    uint32_t stride = 1u, st[3];
+    bool part[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { part[d] = stride <= hashmap_size; st[d] = part[d] ? stride : 0u; if (part[d]) stride *= r1; }
+    const bool hashed = gridtype == 0u && stride > hashmap_size;
+    uint32_t t[3][2];
+    if (hashed) {
+        constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+#pragma unroll
+        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * primes[d]; t[d][1] = t[d][0] + primes[d]; }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * st[d]; t[d][1] = t[d][0] + st[d]; }
+    }
+    const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        const uint32_t a = t[0][idx & 1u], b = t[1][(idx >> 1) & 1u], c = t[2][(idx >> 2) & 1u];
+        uint32_t index = hashed ? (a ^ b ^ c) : (a + b + c);
+        if (index >= hashmap_size) index = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
+        rows[idx] = index;
+    }
+}
 template <uint32_t D>
 __device__ __forceinline__ void gb_cell_weights(const float (&pos)[D], float (&ws)[1u << D]) {
 #pragma unroll
@@ -535,7 +564,7 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
         if (emit) {
             const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
             uint32_t rows[8];
-            gb_cell_rows<3>(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+            gb_cell_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
 #pragma unroll
             for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
         }
@@ -565,9 +594,8 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     constexpr uint32_t NREC = GB_PM_TILE * 8u;
     __shared__ uint32_t cur[2][GB_MAX_SEGS];               // next free staging position per segment (double-buffered by level parity)
     __shared__ uint32_t pre[2][GB_MAX_SEGS + 1];           // first staging position per segment; [64] = records of this level
-    __shared__ uint32_t gb[2][GB_MAX_SEGS];                // this workgroup's first global record per segment
-    __shared__ uint32_t s_row[NREC];                       // local row | segment << 16
-    __shared__ uint32_t s_v0[NREC];
+    __shared__ uint32_t gb[2][GB_MAX_SEGS];                // this workgroup's first global record per segment MINUS its first staging position
+    __shared__ uint2 s_rec[NREC];                          // {local row | segment << 16, value word 0}: one 8-byte LDS access per record
     __shared__ uint32_t s_v1[sizeof(T) == 2 ? 1 : NREC];
     const uint32_t n_wg = gridDim.x;
     const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
@@ -620,7 +648,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             const uint32_t incl = (uint32_t)wave_incl_sum_i((int)hc, (int)threadIdx.x);
             pre[pb][threadIdx.x] = incl - hc;
             cur[pb][threadIdx.x] = incl - hc;
-            gb[pb][threadIdx.x] = nb0;
+            gb[pb][threadIdx.x] = nb0 - (incl - hc);
             if (threadIdx.x == GB_MAX_SEGS - 1) pre[pb][GB_MAX_SEGS] = incl;
             fetch_bases(level + 1);
         }
@@ -665,14 +693,13 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             if (emit) {
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
-                gb_cell_rows<3>(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+                gb_cell_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
                     const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
                     if (pos >= NREC) continue;             // cannot happen when count and scatter agree
-                    s_row[pos] = (rows[i] & (GB_SEG - 1u)) | (seg << 16);
-                    s_v0[pos] = pv0[i];
+                    s_rec[pos] = make_uint2((rows[i] & (GB_SEG - 1u)) | (seg << 16), pv0[i]);
                     if constexpr (sizeof(T) != 2) s_v1[pos] = pv1[i];
                 }
             }
@@ -680,17 +707,16 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         __syncthreads();
         const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
         for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
-            const uint32_t rw = s_row[j];
-            const uint32_t seg = rw >> 16;
-            const uint64_t at = (uint64_t)gb[pb][seg] + (j - pre[pb][seg]);
+            const uint2 rec = s_rec[j];
+            const uint32_t at = gb[pb][rec.x >> 16] + j;
             if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
             if constexpr (sizeof(T) == 2) {
-                reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rw & 0xFFFFu, s_v0[j]);
+                reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rec.x & 0xFFFFu, rec.y);
             } else {
                 uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
                 float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-                rr[at] = rw & 0xFFFFu;
-                vv[at] = make_float2(__uint_as_float(s_v0[j]), __uint_as_float(s_v1[j]));
+                rr[at] = rec.x & 0xFFFFu;
+                vv[at] = make_float2(__uint_as_float(rec.y), __uint_as_float(s_v1[j]));
             }
         }
         // no barrier here: the next level's setup writes the other parity of cur/pre/gb, and its staging writes come after
