@@ -728,6 +728,15 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
 // LDS accumulation is done in DOUBLE: on gfx950 ds_add_f32 on random addresses runs ~23x slower than
 // ds_add_u32 (measured 101 vs 2349 G records/s, tools/bench_lds_atomic.hip) while ds_add_f64 runs at
 // 1823 G/s — so the fp32-quality sum is kept in a 128 KiB f64 image (one workgroup per CU).
+// A finite fp16 value times 2^24 as a two's-complement 64-bit integer, straight from its bits: normal numbers are
+// (1024 | mantissa) << (exponent - 1), subnormals the mantissa itself (fp32 -> int64 conversion has no instruction on gfx950 and
+// expands to a dozen; this is a shift and a conditional negate).
+__device__ __forceinline__ unsigned long long gb_half_to_fixed(uint32_t h) {
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    const unsigned long long mag = e ? ((unsigned long long)(1024u | m) << (e - 1u)) : (unsigned long long)m;
+    return (h & 0x8000u) ? (0ull - mag) : mag;
+}
+
 #define GB_RTHREADS 1024u
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
@@ -772,13 +781,13 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
                 if (cur[u].x != 0xFFFFFFFFu) {
                     // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT
                     // (and order independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
-                    const float2 v = __half22float2(*reinterpret_cast<const __half2 *>(&cur[u].y));
-                    if (!(fabsf(v.x) <= 65504.0f) || !(fabsf(v.y) <= 65504.0f)) {      // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
+                    const uint32_t hv = cur[u].y;
+                    if ((hv & 0x7C00u) == 0x7C00u || (hv & 0x7C000000u) == 0x7C000000u) {   // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
                         atomicOr(&s_bad[cur[u].x >> 5], 1u << (cur[u].x & 31u));
                         continue;
                     }
-                    atomicAdd(&acci[cur[u].x * 2], (unsigned long long)(long long)(v.x * 16777216.0f));
-                    atomicAdd(&acci[cur[u].x * 2 + 1], (unsigned long long)(long long)(v.y * 16777216.0f));
+                    atomicAdd(&acci[cur[u].x * 2], gb_half_to_fixed(hv & 0xFFFFu));
+                    atomicAdd(&acci[cur[u].x * 2 + 1], gb_half_to_fixed(hv >> 16));
                 }
             }
 #pragma unroll
