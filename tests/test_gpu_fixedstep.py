@@ -105,3 +105,52 @@ def test_sample_positions_bit_exact_vs_torch():
         hit = (nears < 1e30).repeat_interleave(T)
         assert torch.equal(xyzs[hit], ref[hit])
         assert torch.equal(enc_in[hit], ((ref + bound) / (2 * bound))[hit])
+
+
+def test_fixed_step_training_fits_a_scene_fused_and_plain():
+    """End to end on FOC's default path: 120 Adam steps (GradScaler, fp16 autocast) on rays of an analytic scene — a red ball on a
+    white background — through the fully fused route (encoder->MLP node on [L,B,C] planes, activation re-evaluation, fused head and
+    composite, run-merged binned grid backward) and through the torch glue of NeRFRenderer.run with the plain per-op nodes. Both must
+    fit the scene; they see the same batches, so their loss curves must also stay close to each other."""
+    import os
+    from focnerf_amd import synthetic
+    from focnerf_amd.network import NeRFNetwork
+    bound, T, n_rays = 1, 128, 1024
+    gen = torch.Generator().manual_seed(0)
+    poses = synthetic.rand_poses(4, "cuda", radius=2.0, generator=gen)
+    intr = synthetic.intrinsics(96, 96)
+    ro, rd = synthetic.get_rays(poses, intr, 96, 96)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    # analytic target: ray hits the ball of radius 0.45 at the origin -> red, else white
+    bq = (ro * rd).sum(-1)
+    hit = (bq * bq - ((ro * ro).sum(-1) - 0.45 ** 2)) > 0
+    target = torch.ones(ro.shape[0], 3, device="cuda")
+    target[hit] = torch.tensor([0.9, 0.1, 0.1], device="cuda")
+    batches = [torch.randint(0, ro.shape[0], (n_rays,), generator=gen).cuda() for _ in range(120)]
+    curves = {}
+    for mode in ("fused", "plain"):
+        for k in ("FOC_FUSED_FIELD", "FOC_FUSED_HEAD", "FOC_MLP_RECOMPUTE"):
+            os.environ[k] = "1" if mode == "fused" else "0"
+        try:
+            torch.manual_seed(1)
+            m = NeRFNetwork(bound=bound).cuda().train()
+            opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+            scaler = torch.amp.GradScaler("cuda")
+            losses = []
+            for idx in batches:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    out = m.run(ro[idx][None], rd[idx][None], None, fused=(mode == "fused"), num_steps=T, upsample_steps=0, bg_color=1.0, perturb=True)
+                    loss = torch.nn.functional.mse_loss(out["image"], target[idx][None])
+                opt.zero_grad()
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+                losses.append(loss.item())
+            curves[mode] = np.array(losses)
+        finally:
+            for k in ("FOC_FUSED_FIELD", "FOC_FUSED_HEAD", "FOC_MLP_RECOMPUTE"):
+                os.environ.pop(k, None)
+    for mode, c in curves.items():
+        assert np.isfinite(c).all(), mode
+        assert c[-10:].mean() < 0.2 * c[:5].mean(), f"{mode}: loss {c[:5].mean():.4f} -> {c[-10:].mean():.4f}"
+    assert abs(curves["fused"][-10:].mean() - curves["plain"][-10:].mean()) < 0.5 * curves["plain"][-10:].mean() + 1e-3
