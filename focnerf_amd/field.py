@@ -28,6 +28,23 @@ def field_fusable(encoder, mlp):
             and mlp.padded_output_dim == 16 and os.environ.get("FOC_FUSED_FIELD", "1") != "0")
 
 
+_half_cache = {}
+
+
+def _half_of(param):
+    """fp16 copy of a parameter, reused while the parameter is unchanged (tensor version counter): a render evaluates the same table
+    and weights for every ray chunk, and the reference converts the 50 MB table on every call (grid.py:41-44)."""
+    if param.dtype == torch.half:
+        return param.contiguous()
+    key = id(param)
+    hit = _half_cache.get(key)
+    if hit is not None and hit[0] is param and hit[1] == param._version and hit[2].device == param.device:
+        return hit[2]
+    h = param.detach().to(torch.half).contiguous()
+    _half_cache[key] = (param, param._version, h)
+    return h
+
+
 class _hashgrid_mlp(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -38,8 +55,8 @@ class _hashgrid_mlp(Function):
         x = x.contiguous().float()
         B = x.shape[0]
         L = offsets.shape[0] - 1
-        emb = embeddings.to(torch.half).contiguous()            # grid.py:41-44: half table under autocast (C even)
-        w = weights.to(torch.half).contiguous()                 # ffmlp.py:23: custom_fwd(cast_inputs=half)
+        emb = _half_of(embeddings)                              # grid.py:41-44: half table under autocast (C even)
+        w = _half_of(weights)                                   # ffmlp.py:23: custom_fwd(cast_inputs=half)
         enc = torch.empty(L, B, 2, device=x.device, dtype=torch.half)
         _gridencoder.grid_encode_forward(x, emb, offsets, enc, B, 3, 2, L, S, H, None, gridtype, align_corners, interp)
         h = torch.empty(B, 16, device=x.device, dtype=torch.half)
