@@ -77,6 +77,8 @@ SIGNATURES = {
     "foc_sample_head_backward": (i32, [c_vp, c_vp, c_vp, u64, c_vp, u32, c_vp]),
     "foc_rgb_head_forward": (i32, [c_vp, u64, c_vp, c_vp]),
     "foc_rgb_head_backward": (i32, [c_vp, c_vp, u64, c_vp, c_vp]),
+    "foc_fixed_render_inference": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "foc_nerf_field_inference": (i32, [c_vp, i32, c_vp, u32, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_mark_untrained_grid": (i32, [c_vp, u32, f32, f32, f32, f32, f32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_grid_cells_xyz": (i32, [u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_grid_update_sample_workspace_bytes": (u64, [u32, u32]),

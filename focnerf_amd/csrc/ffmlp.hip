@@ -839,6 +839,194 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     }
 }
 
+// ---------------------------------------------------------------- inference: sigma network -> head -> colour network in one kernel
+// What NeRFNetwork.forward evaluates per sample (nerf/network_ff.py:51-75) without its intermediates ever leaving the registers:
+//   h = sigma_net(enc)            [16]   MFMA chain as in k_mlp_fwd; h is rounded to fp16 like the stored network output
+//   sigma = exp(h[0])                    fp32 (trunc_exp forward)
+//   cin = [SH4(dir) | h[1:16] | 0]       the 16 SH values are computed on the lane, the geometry features ARE the chained operand:
+//                                        element (h, j) of the sigma-net output fragment is neuron chain_k(0, h, j), so the colour net's
+//                                        layer-0 weights for k-chunk 1 are staged permuted (column 15 + neuron, none for neuron 0)
+//   rgb = sigmoid(color_net(cin)[0:3])   rounded to fp16 like the half sigmoid, stored as fp32
+// Per sample this reads 64 B of encoding + the direction and writes 16 B, instead of also writing and re-reading h (32 B), cin (64 B)
+// and the colour logits (32 B). Values are bit-identical to the separate kernels (same MFMA order, same roundings).
+__device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h8 &out) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float o[8];
+    if (h == 0) {
+        o[0] = 0.28209479177387814f; o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x;
+        o[4] = 1.0925484305920792f * xy; o[5] = -1.0925484305920792f * yz; o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+        o[7] = -1.0925484305920792f * xz;
+    } else {
+        o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+        o[2] = 2.8906114426405538f * xy * z; o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+        o[4] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f); o[5] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+        o[6] = 1.4453057213202769f * z * (x2 - y2); o[7] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = (_Float16)o[j];
+}
+
+template <int NLS, int NLC, bool PLANAR>
+__global__ void __launch_bounds__(MLP_BLOCK) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
+                                                          const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
+                                                          int relu, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
+    constexpr int HIDDEN = 64, MT = 2, KC = 4, NB = 2, IN = 32, KS0 = 2;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    // sigma net: the forward image of k_mlp_fwd; colour net behind it: layer 0 custom (see above), hidden and output as usual
+    constexpr uint32_t n_sigma = MT * KS0 + (NLS - 1) * MT * KC + KC;
+    _Float16 *ldsC = lds + (size_t)n_sigma * 512;
+    stage_weights_fwd<HIDDEN>(w_sigma, lds, IN, NLS);
+    {
+        constexpr uint32_t n0 = MT * KS0, nh = (NLC - 1) * MT * KC, total = n0 + nh + KC;
+        const _Float16 *Wh = w_color + (size_t)HIDDEN * IN;
+        const _Float16 *Wo = Wh + (size_t)(NLC - 1) * HIDDEN * HIDDEN;
+        for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
+            const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (f < n0) {
+                const uint32_t mt = f / KS0, kc = f % KS0, row = 32 * mt + r;
+                if (kc == 0) v = *reinterpret_cast<const h8 *>(w_color + (size_t)row * IN + 8 * h);          // SH chunk, natural order
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { const int n = chain_k(0, h, j); if (n >= 1) v[j] = w_color[(size_t)row * IN + 15 + n]; }
+                }
+            } else if (f < n0 + nh) {
+                const uint32_t g = f - n0, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, row = 32 * mt + r;
+                const _Float16 *p = Wh + (size_t)l * HIDDEN * HIDDEN + (size_t)row * HIDDEN + 16 * kc + 4 * h;
+                const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            } else {
+                const uint32_t kc = f - n0 - nh;
+                if (r < 16) {
+                    const _Float16 *p = Wo + (size_t)r * HIDDEN + 16 * kc + 4 * h;
+                    const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+                }
+            }
+            *reinterpret_cast<h8 *>(ldsC + (size_t)f * 512 + lane * 8) = v;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t n_tiles = (B + 32 * NB - 1) / (32 * NB);
+    auto zero = [](f16v &a) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) a[e] = 0.0f;
+    };
+    // one hidden stack: acc (pre-activation of layer 0) -> pre-activation of the output layer input; returns the B fragments of the last hidden layer
+    auto hidden_stack = [&](f16v (&acc)[MT][NB], h8 (&bf)[KC][NB], const _Float16 *img, uint32_t f_hidden, int nl) {
+        for (int l = 1; l <= nl; l++) {
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) bf[kc][nb] = relu ? acc_to_frag<true>(acc[kc >> 1][nb], kc & 1) : acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+            if (l < nl) {
+                const uint32_t fbase = f_hidden + (l - 1) * MT * KC;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const h8 a = ld_frag(img, fbase + mt * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                    }
+            }
+        }
+    };
+    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+        const uint64_t row0 = (uint64_t)tile * 32 * NB;
+        f16v acc[MT][NB];
+        h8 bf[KC][NB];
+        // ---- sigma net
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
+#pragma unroll
+        for (int kc = 0; kc < KS0; kc++) {
+            h8 b[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
+                b[nb] = PLANAR ? ld_planar8(enc, B, row, kc, h) : *reinterpret_cast<const h8 *>(enc + row * IN + 16 * kc + 8 * h);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[nb], acc[mt][nb]);
+            }
+        }
+        hidden_stack(acc, bf, lds, MT * KS0, NLS);
+        f16v o[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) zero(o[nb]);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            const h8 a = ld_frag(lds, MT * KS0 + (NLS - 1) * MT * KC + kc, lane);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
+        }
+        // ---- head: sigma from neuron 0 (lane half 0, element 0), SH on the lane, geometry features = the output fragment itself
+        h8 geo[NB], sh[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            geo[nb] = acc_to_frag<false>(o[nb], 0);
+            const uint64_t row = row0 + nb * 32 + c;
+            const uint64_t rl = min(row, (uint64_t)B - 1);
+            if (h == 0 && row < B && sigma_out) sigma_out[row] = expf((float)geo[nb][0]);
+            const float *dp = dirs + (rl / dir_div) * 3;
+            nf_sh16_half(dp[0], dp[1], dp[2], h, sh[nb]);
+        }
+        // ---- colour net
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const h8 a0 = ld_frag(ldsC, mt * KS0 + 0, lane);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], acc[mt][nb]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const h8 a1 = ld_frag(ldsC, mt * KS0 + 1, lane);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a1, geo[nb], acc[mt][nb]);
+        }
+        hidden_stack(acc, bf, ldsC, MT * KS0, NLC);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) zero(o[nb]);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            const h8 a = ld_frag(ldsC, MT * KS0 + (NLC - 1) * MT * KC + kc, lane);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            const uint64_t row = row0 + nb * 32 + c;
+            if (h == 0 && row < B) {
+                // torch.sigmoid on the half logits: fp32 math, one rounding to fp16 (network_ff.py:73)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float x = (float)(_Float16)o[nb][k];
+                    rgb_out[row * 3 + k] = (float)(_Float16)(1.0f / (1.0f + expf(-x)));
+                }
+            }
+        }
+    }
+}
+
 // ================================================================= host side
 static uint32_t g_num_cus = 0;
 static uint32_t mlp_num_cus() {
@@ -987,6 +1175,21 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     return FOC_OK;
 }
 
+template <int NLS, int NLC>
+static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
+                             float *sigma, float *rgb, hipStream_t st) {
+    const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024;
+    auto kern = planar ? k_nerf_infer<NLS, NLC, true> : k_nerf_infer<NLS, NLC, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    uint32_t grid = foc_div_up(foc_div_up(B, 64), MLP_WAVES);
+    const uint32_t cap = mlp_num_cus() * 4;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)enc, dirs, dir_div, (const _Float16 *)w_sigma, (const _Float16 *)w_color, B, relu,
+                       sigma, rgb);
+    FOC_CHECK_LAUNCH("nerf_field_inference");
+    return FOC_OK;
+}
+
 extern "C" {
 
 int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -1044,6 +1247,24 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
                               void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream) {
     return mlp_bwd_entry(grad, inputs_planar, weights, nullptr, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                          calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
+}
+
+int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, const void *sigma_weights, uint32_t sigma_layers,
+                             const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B, float *sigma,
+                             float *rgb, void *stream) {
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(enc && dirs && sigma_weights && color_weights && rgb, FOC_E_INVALID, "nerf_field_inference: null pointer");
+    FOC_REQUIRE(hidden_dim == 64 && dir_div >= 1, FOC_E_INVALID, "nerf_field_inference: hidden_dim must be 64 (got %u)", hidden_dim);
+    FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "nerf_field_inference: hidden activation must be relu(0) or none(6)");
+    const int relu = activation == 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t key = sigma_layers * 10 + color_layers;
+    switch (key) {
+        case 22: return nerf_infer_launch<2, 2>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 23: return nerf_infer_launch<2, 3>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        default: foc_set_error("nerf_field_inference: layer counts (%u, %u) are not built (2/2, 2/3, 3/3)", sigma_layers, color_layers); return FOC_E_INVALID;
+    }
 }
 
 int foc_allocate_splitk(uint64_t size) { (void)size; return FOC_OK; }

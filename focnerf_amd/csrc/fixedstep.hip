@@ -266,6 +266,54 @@ __global__ void __launch_bounds__(256) k_fs_composite_bwd(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------- inference tail: weights + mask + composite in one pass
+// sigma [M] fp32 and rgb [M,3] fp32 (foc_nerf_field_inference) -> image [N,3], depth [N], weights_sum [N]; one wave per ray, the
+// transmittance scan of k_fs_head_fwd and the masked sum of k_fs_composite_fwd without the weights / trans arrays in between.
+// rgb_masked (may be NULL): rgb * [w > thresh], the per-sample colour field the reference's run() returns (renderer.py:187).
+__global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict__ sigma_in, const float *__restrict__ rgb_in, const float *__restrict__ nears,
+                                                         const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
+                                                         float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
+                                                         float *__restrict__ image, float *__restrict__ depth, float *__restrict__ weights_sum,
+                                                         float *__restrict__ rgb_masked) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const FsGeom g = fs_geom(nears, fars, n, T);
+    float Tc = 1.0f, ws = 0, dp = 0, r = 0, gg = 0, b = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < T;
+        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const float sigma = sigma_in[s];
+        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float delta = g.sample_dist;
+        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
+        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float w = alpha * (Tc * Pex);
+        if (valid) {
+            float oz = (z - g.near) / g.span;
+            oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
+            ws += w; dp += w * oz;
+            const bool on = w > thresh;
+            const float c0 = rgb_in[s * 3], c1 = rgb_in[s * 3 + 1], c2 = rgb_in[s * 3 + 2];
+            if (on) { r += w * c0; gg += w * c1; b += w * c2; }
+            if (rgb_masked) { rgb_masked[s * 3] = on ? c0 : 0.0f; rgb_masked[s * 3 + 1] = on ? c1 : 0.0f; rgb_masked[s * 3 + 2] = on ? c2 : 0.0f; }
+        }
+        Tc *= __shfl(P, 63, 64);
+    }
+    ws = wave_sum(ws); dp = wave_sum(dp); r = wave_sum(r); gg = wave_sum(gg); b = wave_sum(b);
+    if (lane == 0) {
+        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+        image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
+        depth[n] = dp;
+        weights_sum[n] = ws;
+    }
+}
+
 // ================================================================= host entry points
 extern "C" {
 
@@ -324,6 +372,18 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
     hipLaunchKernelGGL(k_fs_composite_bwd, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, grad_image,
                        (const _Float16 *)c, weights, bg_ray, bg_scalar, N, T, thresh, (_Float16 *)grad_c, grad_w);
     FOC_CHECK_LAUNCH("fixed_composite_backward");
+    return FOC_OK;
+}
+
+int foc_fixed_render_inference(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
+                               float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
+                               float *rgb_masked, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(sigma && rgb && nears && fars && image && depth && weights_sum, FOC_E_INVALID, "fixed_render_inference: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_render_inference: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_render_infer, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
+                       density_scale, thresh, image, depth, weights_sum, rgb_masked);
+    FOC_CHECK_LAUNCH("fixed_render_inference");
     return FOC_OK;
 }
 

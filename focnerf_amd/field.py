@@ -80,6 +80,37 @@ class _hashgrid_mlp(Function):
         return None, g_emb, g_w, None, None, None, None
 
 
+def infer_fusable(model):
+    """Whole-field inference kernel (csrc/ffmlp.hip, k_nerf_infer): hash grid (D=3, C=2, 16 levels) -> 64-wide sigma net -> degree-4 SH
+    + 15 geometry features -> 64-wide colour net."""
+    from .shencoder import SHEncoder
+    enc, sn, cn = getattr(model, "encoder", None), getattr(model, "sigma_net", None), getattr(model, "color_net", None)
+    return (field_fusable(enc, sn) and isinstance(cn, FFMLP) and isinstance(getattr(model, "encoder_dir", None), SHEncoder)
+            and sn.input_dim == 32 and sn.hidden_dim == 64 and cn.hidden_dim == 64 and cn.input_dim == 32 and cn.padded_output_dim == 16
+            and getattr(model, "geo_feat_dim", 0) == 15 and (sn.num_layers, cn.num_layers) in ((2, 2), (2, 3), (3, 3))
+            and sn.activation == cn.activation and os.environ.get("FOC_FUSED_INFER", "1") != "0")
+
+
+@torch.no_grad()
+def field_infer(model, xn, dirs, dir_div=1):
+    """xn [M,3] fp32 in [0,1] (already normalised), dirs [M / dir_div, 3] -> sigma [M] fp32, rgb [M,3] fp32 (no autograd)."""
+    from ._lib import lib, ptr, stream_of, check
+    enc, sn, cn = model.encoder, model.sigma_net, model.color_net
+    xn = xn.contiguous().float()
+    dirs = dirs.contiguous().float()
+    M = xn.shape[0]
+    L = enc.offsets.shape[0] - 1
+    emb, ws, wc = _half_of(enc.embeddings), _half_of(sn.weights), _half_of(cn.weights)
+    planes = torch.empty(L, M, 2, device=xn.device, dtype=torch.half)
+    _gridencoder.grid_encode_forward(xn, emb, enc.offsets, planes, M, 3, 2, L, float(np.log2(enc.per_level_scale)), enc.base_resolution, None,
+                                     enc.gridtype_id, enc.align_corners, enc.interp_id)
+    sigma = torch.empty(M, dtype=torch.float32, device=xn.device)
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=xn.device)
+    check(lib.foc_nerf_field_inference(ptr(planes), 1, ptr(dirs), int(dir_div), ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, 64, sn.activation, M,
+                                       ptr(sigma), ptr(rgb), stream_of(xn)), "nerf_field_inference")
+    return sigma, rgb
+
+
 def hashgrid_mlp(encoder, mlp, x, bound=1):
     """x [...,3] in [-bound, bound] -> [..., 16] half: mlp.forward_padded(encoder(x, bound))."""
     prefix = list(x.shape[:-1])

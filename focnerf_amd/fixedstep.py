@@ -105,6 +105,17 @@ class _fixed_composite(Function):
         return grad_c, grad_w, None, None, None, None, None
 
 
+def _background(bg_color, N, dev):
+    """bg_color None / scalar / tensor -> (per-ray [N,3] tensor or None, scalar)."""
+    if bg_color is None:
+        return None, 1.0
+    if torch.is_tensor(bg_color):
+        if bg_color.numel() > 1:
+            return bg_color.to(dev, torch.float32).expand(N, 3).contiguous(), 0.0
+        return None, float(bg_color)
+    return None, float(bg_color)
+
+
 def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, bg_color=None, perturb=False, weight_thresh=1e-10,
                        return_fields=None, **kwargs):
     """Drop-in for NeRFRenderer.run(..., upsample_steps=0) on a focnerf_amd NeRFNetwork (fp16 autocast semantics); same result
@@ -122,6 +133,26 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
     nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
     noise = torch.rand(N * T, dtype=torch.float32, device=dev) if perturb else None
     enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound)
+
+    from .field import infer_fusable, field_infer
+    if not torch.is_grad_enabled() and infer_fusable(model) and not getattr(model, "uses_object_feature", False):
+        # inference: sample -> encoder planes -> whole-field kernel -> weights + mask + composite kernel
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T)
+        bg_ray, bg_scalar = _background(bg_color, N, dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        rgb_masked = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if return_fields else None
+        check(lib.foc_fixed_render_inference(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T,
+                                             float(model.density_scale), float(weight_thresh), ptr(image), ptr(depth), ptr(weights_sum), ptr(rgb_masked),
+                                             stream_of(sigma)), "fixed_render_inference")
+        t_mid = time.time()
+        results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum, 'criterion_outside_mask': None,
+                   'timing': [t_mid - t_start, time.time() - t_mid]}
+        if return_fields:
+            results['densities'] = sigma.view(N, T, 1)
+            results['rgbs'] = rgb_masked.view(N, T, 3)
+        return results
 
     enc = model.encoder
     from .field import field_fusable, _hashgrid_mlp
@@ -150,20 +181,14 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         c = model.color_net.forward_padded(cin)                            # [M,16] half, columns 0..2 = rgb logits
     t_mid = time.time()
 
-    bg_ray, bg_scalar = None, 1.0
-    if bg_color is None:
-        bg_scalar = 1.0
-    elif torch.is_tensor(bg_color):
-        bg_ray = bg_color.to(dev, torch.float32).expand(N, 3).contiguous() if bg_color.numel() > 1 else None
-        bg_scalar = float(bg_color) if bg_ray is None else 0.0
-    else:
-        bg_scalar = float(bg_color)
+    bg_ray, bg_scalar = _background(bg_color, N, dev)
     image = _fixed_composite.apply(c, weights, bg_ray, bg_scalar, N, T, weight_thresh)
 
     results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum,
                'criterion_outside_mask': criterion_outside_mask, 'timing': [t_mid - t_start, time.time() - t_mid]}
     if return_fields:
-        rgb = torch.sigmoid(c[:, :3]).float() * (weights > weight_thresh).unsqueeze(-1)
+        from .head import rgb_head
+        rgb = rgb_head(c.detach()) * (weights > weight_thresh).unsqueeze(-1)     # half-rounded sigmoid, fp32 tensor (the composite's values)
         results['densities'] = sigma.view(N, T, 1)
         results['rgbs'] = rgb.view(N, T, 3)
     return results

@@ -42,7 +42,10 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d):
         if self._fused_head_ok(x):
             from .head import sample_head, rgb_head
-            from .field import field_fusable, hashgrid_mlp
+            from .field import field_fusable, hashgrid_mlp, infer_fusable, field_infer
+            if not torch.is_grad_enabled() and infer_fusable(self):
+                # inference: encoder planes -> one kernel for both networks and the glue between them
+                return field_infer(self, (x + self.bound) / (2 * self.bound), d)
             if field_fusable(self.encoder, self.sigma_net):
                 h = hashgrid_mlp(self.encoder, self.sigma_net, x, self.bound)          # [M,16] half, encoding kept in [L,B,C]
             else:

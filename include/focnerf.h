@@ -264,6 +264,17 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
                               uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                               void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream);
 
+/* Inference of the whole NeRF field per sample in one kernel (nerf/network_ff.py:51-75): sigma network on the hash-grid
+ * encoding `enc` ([B,32] fp16 row-major, or the encoder's [16,B,2] planes when enc_planar), trunc_exp, degree-4 SH of the
+ * direction, colour network, sigmoid. dirs [B / dir_div, 3] fp32: sample s uses direction s / dir_div (dir_div = 1 for
+ * per-sample directions, = samples per ray when they are per ray). sigma [B] fp32 (may be NULL), rgb [B,3] fp32 (values
+ * rounded to fp16 like the half sigmoid). Same bits as foc_ffmlp_inference -> foc_sample_head_forward -> foc_ffmlp_inference
+ * -> foc_rgb_head_forward; hidden_dim 64, (sigma_layers, color_layers) in {(2,2), (2,3), (3,3)}. */
+int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div,
+                             const void *sigma_weights, uint32_t sigma_layers, const void *color_weights,
+                             uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B,
+                             float *sigma, float *rgb, void *stream);
+
 /* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
  * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the
  * backward launch sequence on the caller's stream, so both are no-ops kept for API parity. */
@@ -331,6 +342,15 @@ int foc_fixed_composite_forward(const void *c, const float *weights, const float
 int foc_fixed_composite_backward(const float *grad_image, const void *c, const float *weights,
                                  const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
                                  void *grad_c, float *grad_w, void *stream);
+
+/* Inference tail of the fixed-step renderer in one pass: sigma [M] fp32, rgb [M,3] fp32 (e.g. from
+ * foc_nerf_field_inference) -> weights (alpha * cumprod), image [N,3] = sum w rgb [w > thresh] + (1 - sum w) bg,
+ * depth [N], weights_sum [N]; rgb_masked [M,3] (may be NULL) = rgb where w > thresh else 0, the `rgbs` field of
+ * nerf/renderer.py:187. */
+int foc_fixed_render_inference(const float *sigma, const float *rgb, const float *nears, const float *fars,
+                               const float *noise, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T,
+                               float density_scale, float thresh, float *image, float *depth, float *weights_sum,
+                               float *rgb_masked, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Per-sample network glue for callers with arbitrary sample lists (the occupancy-grid paths): the torch

@@ -178,3 +178,44 @@ def test_fused_field_matches_separate_nodes(B, monkeypatch):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         h2 = hashgrid_mlp(m.encoder, m.sigma_net, x, m.bound)
     assert torch.equal(h2, res["fused"][0])
+
+
+@pytest.mark.parametrize("layers", [(2, 3), (2, 2), (3, 3)])
+@pytest.mark.parametrize("M", [5000, 64 * 7 + 1])
+def test_fused_inference_kernel_matches_separate_kernels(layers, M, monkeypatch):
+    """foc_nerf_field_inference (sigma net -> head -> colour net in one kernel) vs the separate kernels it replaces, per-sample and
+    per-ray directions. sigma: same bits. rgb: the geometry features enter the colour net's first MFMA in the chained k order instead
+    of the natural one, i.e. the same products summed in another association — at most one fp16 ulp on a handful of values."""
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(2)
+    m = NeRFNetwork(bound=1, num_layers=layers[0], num_layers_color=layers[1]).cuda().eval()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(M, 3, device="cuda", generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device="cuda", generator=gen), dim=-1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FOC_FUSED_INFER", mode)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out[mode] = m(x, d)
+    assert torch.equal(out["1"][0], out["0"][0]), "sigma"
+    dr = (out["1"][1].float() - out["0"][1].float()).abs()
+    assert dr.max().item() <= 4.9e-4 and (dr > 0).float().mean().item() < 1e-3, "rgb"
+    # fixed-step renderer in eval mode: whole-field kernel + one-pass tail vs the separate inference kernels
+    from focnerf_amd import synthetic
+    poses = synthetic.rand_poses(1, "cuda", radius=2.0, generator=torch.Generator().manual_seed(1))
+    ro, rd = synthetic.get_rays(poses, synthetic.intrinsics(32, 32), 32, 32)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FOC_FUSED_INFER", mode)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            res[mode] = m.run(ro, rd, None, fused=True, num_steps=96, upsample_steps=0, bg_color=1.0, perturb=False, return_fields=True)
+    for k in ("densities", "rgbs", "weights_sum", "depth", "image"):
+        a, b = res["1"][k].float(), res["0"][k].float()
+        assert a.shape == b.shape, k
+        if k == "densities":
+            assert torch.equal(a, b), (k, (a - b).abs().max())
+        elif k == "rgbs":
+            assert (a - b).abs().max().item() <= 4.9e-4 and ((a - b).abs() > 0).float().mean().item() < 1e-3
+        else:   # same weights, summed over the ray in a different association
+            assert torch.allclose(a, b, atol=2e-5, rtol=0, equal_nan=True), (k, (a - b).abs().max())
