@@ -128,6 +128,36 @@ __device__ __forceinline__ bool ge_load_point(const float *__restrict__ inputs, 
     return oob;
 }
 
+// The same 8 rows for D = 3 with the per-level decisions (which dimensions enter the dense index, dense or hashed, power-of-two
+// size) taken once on wave-uniform values and the per-axis terms shared between the corners: (p+1)*k = p*k + k in uint32, so every
+// row is two adds or two xors instead of ge_index's per-corner multiplies and branches. Bit-identical to ge_index per corner (corner idx: bit d set = +1 along axis d).
+__device__ __forceinline__ void ge_rows3(const uint32_t (&pos_grid)[3], uint32_t hashmap_size, uint32_t resolution, uint32_t gridtype,
+                                              bool align_corners, uint32_t (&rows)[8]) {
+    const uint32_t r1 = align_corners ? resolution : resolution + 1u;
+    uint32_t stride = 1u, st[3];
+    bool part[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { part[d] = stride <= hashmap_size; st[d] = part[d] ? stride : 0u; if (part[d]) stride *= r1; }
+    const bool hashed = gridtype == 0u && stride > hashmap_size;
+    uint32_t t[3][2];
+    if (hashed) {
+        constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+#pragma unroll
+        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * primes[d]; t[d][1] = t[d][0] + primes[d]; }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * st[d]; t[d][1] = t[d][0] + st[d]; }
+    }
+    const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        const uint32_t a = t[0][idx & 1u], b = t[1][(idx >> 1) & 1u], c = t[2][(idx >> 2) & 1u];
+        uint32_t index = hashed ? (a ^ b ^ c) : (a + b + c);
+        if (index >= hashmap_size) index = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
+        rows[idx] = index;
+    }
+}
+
 // ---- forward: one (point, level) ---------------------------------------------------------
 // out points at the C outputs of this (point, level); dy points at its [D,C] block or null.
 template <typename T, uint32_t D, uint32_t C>
@@ -162,6 +192,8 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     // issue all 2^D gathers before consuming them (latency-bound: keep them in flight)
     float vals[1u << D][C];
     float ws[1u << D];
+    uint32_t rows3[8];
+    if constexpr (D == 3) ge_rows3(pos_grid, hashmap_size, resolution, gridtype, align_corners, rows3);
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {             // :167-191
         float w = 1;
@@ -172,7 +204,9 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
             else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
         }
         ws[idx] = w;
-        const uint32_t row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+        uint32_t row;
+        if constexpr (D == 3) row = rows3[idx];
+        else row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
         GeVec<T, C>::ld(table + (uint64_t)row * C, vals[idx]);
     }
 #pragma unroll
@@ -414,35 +448,6 @@ __device__ __forceinline__ void gb_cell_rows(const uint32_t (&pos_grid)[D], uint
         rows[idx] = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
     }
 }
-// The same 8 rows for D = 3 with the per-level decisions (which dimensions enter the dense index, dense or hashed, power-of-two
-// size) taken once on wave-uniform values and the per-axis terms shared between the corners: (p+1)*k = p*k + k in uint32, so every
-// row is two adds or two xors instead of ge_index's per-corner multiplies and branches. Bit-identical to gb_cell_rows<3>.
-__device__ __forceinline__ void gb_cell_rows3(const uint32_t (&pos_grid)[3], uint32_t hashmap_size, uint32_t resolution, uint32_t gridtype,
-                                              bool align_corners, uint32_t (&rows)[8]) {
-    const uint32_t r1 = align_corners ? resolution : resolution + 1u;
-    uint32_t stride = 1u, st[3];
-    bool part[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) { part[d] = stride <= hashmap_size; st[d] = part[d] ? stride : 0u; if (part[d]) stride *= r1; }
-    const bool hashed = gridtype == 0u && stride > hashmap_size;
-    uint32_t t[3][2];
-    if (hashed) {
-        constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
-#pragma unroll
-        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * primes[d]; t[d][1] = t[d][0] + primes[d]; }
-    } else {
-#pragma unroll
-        for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * st[d]; t[d][1] = t[d][0] + st[d]; }
-    }
-    const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
-#pragma unroll
-    for (uint32_t idx = 0; idx < 8; idx++) {
-        const uint32_t a = t[0][idx & 1u], b = t[1][(idx >> 1) & 1u], c = t[2][(idx >> 2) & 1u];
-        uint32_t index = hashed ? (a ^ b ^ c) : (a + b + c);
-        if (index >= hashmap_size) index = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
-        rows[idx] = index;
-    }
-}
 template <uint32_t D>
 __device__ __forceinline__ void gb_cell_weights(const float (&pos)[D], float (&ws)[1u << D]) {
 #pragma unroll
@@ -564,7 +569,7 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
         if (emit) {
             const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
             uint32_t rows[8];
-            gb_cell_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+            ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
 #pragma unroll
             for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
         }
@@ -693,7 +698,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             if (emit) {
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
-                gb_cell_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
