@@ -148,13 +148,28 @@ __device__ __forceinline__ void ge_rows3(const uint32_t (&pos_grid)[3], uint32_t
 #pragma unroll
         for (int d = 0; d < 3; d++) { t[d][0] = pos_grid[d] * st[d]; t[d][1] = t[d][0] + st[d]; }
     }
+    // `index % hashmap_size` (gridencoder.cu:83), decided once per level: a dense level that takes all three axes has index < size
+    // already; a power-of-two size (every hashed level: 2^log2_hashmap_size) is a mask; the division is left for tiled grids with odd sizes
+    const bool need_mod = hashed || stride > hashmap_size || !part[2];
     const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+    if (!need_mod) {
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; idx++) {
-        const uint32_t a = t[0][idx & 1u], b = t[1][(idx >> 1) & 1u], c = t[2][(idx >> 2) & 1u];
-        uint32_t index = hashed ? (a ^ b ^ c) : (a + b + c);
-        if (index >= hashmap_size) index = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
-        rows[idx] = index;
+        for (uint32_t idx = 0; idx < 8; idx++) rows[idx] = t[0][idx & 1u] + t[1][(idx >> 1) & 1u] + t[2][(idx >> 2) & 1u];
+    } else if (pow2) {
+        const uint32_t mask = hashmap_size - 1u;
+        if (hashed) {
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) rows[idx] = (t[0][idx & 1u] ^ t[1][(idx >> 1) & 1u] ^ t[2][(idx >> 2) & 1u]) & mask;
+        } else {
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) rows[idx] = (t[0][idx & 1u] + t[1][(idx >> 1) & 1u] + t[2][(idx >> 2) & 1u]) & mask;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            const uint32_t a = t[0][idx & 1u], b = t[1][(idx >> 1) & 1u], c = t[2][(idx >> 2) & 1u];
+            rows[idx] = (hashed ? (a ^ b ^ c) : (a + b + c)) % hashmap_size;
+        }
     }
 }
 
