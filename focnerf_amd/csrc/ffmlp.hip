@@ -1084,10 +1084,10 @@ template <bool TRAIN>
 static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                    uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *buffer, void *outputs, void *stream, int planar = 0) {
     const char *who = TRAIN ? "ffmlp_forward" : "ffmlp_inference";
-    FOC_REQUIRE(inputs && weights && outputs && (!TRAIN || buffer), FOC_E_INVALID, "%s: null pointer", who);
     int rc = mlp_check(who, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc) return rc;
-    if (B == 0) return FOC_OK;
+    if (B == 0) return FOC_OK;                      // empty tensors carry null data pointers
+    FOC_REQUIRE(inputs && weights && outputs && (!TRAIN || buffer), FOC_E_INVALID, "%s: null pointer", who);
     const int relu = activation == 0;
     hipStream_t st = (hipStream_t)stream;
     switch (hidden_dim) {
@@ -1213,11 +1213,16 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
                          int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, int planar, void *stream) {
     // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip; forward_buffer may be NULL: the fused kernel
     // then re-evaluates the activations from the inputs (the two-kernel path checks both again)
-    FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
-    FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
     int rc = mlp_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
     if (rc) return rc;
-    if (B == 0) return FOC_OK;
+    if (B == 0) {                                   // empty batch (null data pointers): the weight gradient is all zeros
+        FOC_REQUIRE(grad_weights, FOC_E_INVALID, "ffmlp_backward: null pointer");
+        const size_t n_w = (size_t)hidden_dim * (input_dim + (size_t)hidden_dim * (num_layers - 1) + 16);
+        if (hipMemsetAsync(grad_weights, 0, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("ffmlp_backward: memset failed"); return FOC_E_LAUNCH; }
+        return FOC_OK;
+    }
+    FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
+    FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
     const int relu = activation == 0;
     hipStream_t st = (hipStream_t)stream;
     void *gi = calc_grad_inputs ? grad_inputs : nullptr;

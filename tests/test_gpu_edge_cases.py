@@ -1,0 +1,113 @@
+"""GPU: degenerate sizes through the Python operator API — empty batches, single elements, rays that all miss, a masked colour
+query with an empty mask, error behaviour on bad arguments (RuntimeError with the library's message, like TORCH_CHECK)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(bound=1, cuda_ray=False):
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    return NeRFNetwork(bound=bound, cuda_ray=cuda_ray).cuda()
+
+
+def test_empty_batches_everywhere():
+    from focnerf_amd import raymarching
+    from focnerf_amd.gridencoder import GridEncoder
+    from focnerf_amd.freqencoder import FreqEncoder
+    from focnerf_amd.ffmlp import FFMLP
+    dev = "cuda"
+    z3 = torch.zeros(0, 3, device=dev)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device=dev)
+    n, f = raymarching.near_far_from_aabb(z3, z3, aabb, 0.2)
+    assert n.shape == (0,) and f.shape == (0,)
+    assert raymarching.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
+    assert raymarching.morton3D_invert(torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 3)
+    enc = GridEncoder(desired_resolution=2048).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        e = enc(z3, bound=1)
+        assert e.shape == (0, 32)
+        mlp = FFMLP(32, 16, 64, 2).cuda().train()
+        xin = torch.zeros(0, 32, device=dev, requires_grad=True)
+        y = mlp(xin)
+        assert y.shape == (0, 16)
+        y.sum().backward()                       # empty backward: zero weight gradient, no launch on zero rows
+        assert torch.all(mlp.weights.grad == 0)
+    fe = FreqEncoder(input_dim=3, degree=4).cuda()
+    assert fe(z3).shape == (0, 27)
+    m = _net().eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s, c = m(z3, z3)
+        assert s.shape == (0,) and c.shape == (0, 3)
+        out = m.run(z3[None], z3[None], None, fused=True, num_steps=16, upsample_steps=0)
+        assert out["image"].shape == (1, 0, 3)
+
+
+def test_single_sample_and_single_ray():
+    m = _net().eval()
+    x = torch.tensor([[0.1, -0.2, 0.3]], device="cuda")
+    d = torch.tensor([[0.0, 0.0, 1.0]], device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s1, c1 = m(x, d)
+        s2, c2 = m(x.repeat(65, 1), d.repeat(65, 1))
+    assert s1.shape == (1,) and torch.isfinite(s1).all() and torch.equal(s2, s1.expand(65)) and torch.equal(c2, c1.expand(65, 3))
+    ro = torch.tensor([[[0.0, 0.0, -2.0]]], device="cuda")
+    rd = torch.tensor([[[0.0, 0.0, 1.0]]], device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = m.run(ro, rd, None, fused=True, num_steps=8, upsample_steps=0, bg_color=1.0)
+        b = m.run(ro, rd, None, fused=False, num_steps=8, upsample_steps=0, bg_color=1.0)
+    assert torch.allclose(a["image"], b["image"], atol=2e-3) and torch.allclose(a["depth"], b["depth"], atol=2e-3)
+
+
+def test_rays_that_miss_the_box():
+    """near = far = FLT_MAX from near_far_from_aabb (raymarching.cu:139-142): the fixed-step renderer then produces the background
+    and a NaN depth exactly like the torch code does ((z - near) / (far - near) = 0/0), the occupancy path no samples."""
+    m = _net(2, cuda_ray=True).train()
+    from focnerf_amd import synthetic
+    m.set_density_grid(synthetic.analytic_density_grid(2, device="cuda"))
+    ro = torch.tensor([[[10.0, 10.0, 10.0], [8.0, 9.0, 10.0]]], device="cuda")
+    rd = torch.nn.functional.normalize(torch.tensor([[[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], device="cuda"), dim=-1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        out = m.render(ro, rd, None, staged=False, perturb=False, force_all_rays=True, dt_gamma=1 / 128, max_steps=64, bg_color=1.0)
+    assert torch.allclose(out["image"], torch.ones_like(out["image"]))
+    assert int(m.step_counter[(m.local_step - 1) % 16, 0].item()) == 0
+    f = _net(1).eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = f.run(ro, rd, None, fused=True, num_steps=8, upsample_steps=0, bg_color=1.0)
+        b = f.run(ro, rd, None, fused=False, num_steps=8, upsample_steps=0, bg_color=1.0)
+    assert torch.equal(torch.isnan(a["depth"]), torch.isnan(b["depth"]))
+
+
+def test_colour_query_with_empty_mask_and_full_mask():
+    m = _net().eval()
+    x = torch.rand(10, 3, device="cuda") * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(10, 3, device="cuda"), dim=-1)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        dens = m.density(x)
+        none = m.color(x, d, mask=torch.zeros(10, dtype=torch.bool, device="cuda"), **dens)
+        full = m.color(x, d, mask=torch.ones(10, dtype=torch.bool, device="cuda"), **dens)
+        plain = m.color(x, d, **dens)
+    assert torch.all(none == 0) and torch.allclose(full.float(), plain.float())
+
+
+def test_bad_arguments_raise_runtime_error():
+    from focnerf_amd.backend import _gridencoder, _ffmlp
+    from focnerf_amd.ffmlp import FFMLP
+    x = torch.rand(4, 3, device="cuda")
+    emb = torch.rand(64, 2, device="cuda")
+    off = torch.tensor([0, 64], dtype=torch.int32, device="cuda")
+    out = torch.empty(1, 4, 2, device="cuda")
+    with pytest.raises(RuntimeError, match="D must be 2 or 3"):
+        _gridencoder.grid_encode_forward(torch.rand(4, 4, device="cuda"), emb, off, out, 4, 4, 2, 1, 0.0, 8, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        _gridencoder.grid_encode_forward(x, torch.rand(64, 3, device="cuda"), off, torch.empty(1, 4, 3, device="cuda"), 4, 3, 3, 1, 0.0, 8, None, 0, False, 0)
+    with pytest.raises(RuntimeError):
+        _gridencoder.grid_encode_forward(x.cpu(), emb, off, out, 4, 3, 2, 1, 0.0, 8, None, 0, False, 0)        # CPU tensor: no CPU implementation
+    with pytest.raises(AssertionError):
+        FFMLP(30, 3, 64, 2)                                                                                     # ffmlp.py:84
+    w = torch.zeros(64 * (32 + 64 + 16), dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="hidden_dim"):
+        _ffmlp.ffmlp_inference(torch.zeros(4, 32, dtype=torch.float16, device="cuda"), w, 4, 32, 16, 256, 2, 0, 6, None,
+                               torch.empty(4, 16, dtype=torch.float16, device="cuda"))
