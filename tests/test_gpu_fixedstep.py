@@ -154,3 +154,47 @@ def test_fixed_step_training_fits_a_scene_fused_and_plain():
         assert np.isfinite(c).all(), mode
         assert c[-10:].mean() < 0.2 * c[:5].mean(), f"{mode}: loss {c[:5].mean():.4f} -> {c[-10:].mean():.4f}"
     assert abs(curves["fused"][-10:].mean() - curves["plain"][-10:].mean()) < 0.5 * curves["plain"][-10:].mean() + 1e-3
+
+
+def test_whole_step_replays_as_a_hip_graph():
+    """focnerf_amd.graph.GraphedStep: forward, backward, GradScaler and fused Adam of the fixed-step path captured once and replayed;
+    the kernels of the C ABI run on torch's capturing stream and the scratch buffers are persistent, so the replayed steps follow
+    the eager ones."""
+    from focnerf_amd import synthetic
+    from focnerf_amd.graph import GraphedStep
+    from focnerf_amd.network import NeRFNetwork
+    gen = torch.Generator().manual_seed(0)
+    poses = synthetic.rand_poses(2, "cuda", radius=2.0, generator=gen)
+    ro, rd = synthetic.get_rays(poses, synthetic.intrinsics(48, 48), 48, 48)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    target = torch.rand(ro.shape[0], 3, generator=gen).cuda()
+    batches = [torch.randint(0, ro.shape[0], (512,), generator=gen).cuda() for _ in range(6)]
+
+    def make():
+        torch.manual_seed(3)
+        m = NeRFNetwork(bound=1).cuda().train()
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+        sc = torch.amp.GradScaler("cuda", init_scale=1024.0)
+
+        def step(o, d, t):
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = m.run(o[None], d[None], None, fused=True, num_steps=64, upsample_steps=0, bg_color=1.0, perturb=False)
+                loss = torch.nn.functional.mse_loss(out["image"], t[None])
+            opt.zero_grad(set_to_none=False)
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+            return loss.detach()
+        return m, step
+
+    m_e, step_e = make()
+    m_g, step_g = make()
+    eager = [float(step_e(ro[i], rd[i], target[i])) for i in batches]
+    # first step eagerly on the second model too (creates the scratch buffers and the cached host copy of the level offsets: neither
+    # may happen inside a capture); the capture itself executes nothing, the remaining five batches are replays
+    got = [float(step_g(ro[batches[0]], rd[batches[0]], target[batches[0]]))]
+    graphed = GraphedStep(step_g, (ro[batches[1]], rd[batches[1]], target[batches[1]]), warmup=0)
+    got += [float(graphed(ro[i], rd[i], target[i])) for i in batches[1:]]
+    assert np.allclose(got, eager, rtol=2e-2, atol=1e-4), (got, eager)
+    assert torch.allclose(m_g.sigma_net.weights, m_e.sigma_net.weights, atol=2e-3)
+    assert not torch.equal(m_g.sigma_net.weights, make()[0].sigma_net.weights), "the replayed steps did update the parameters"
