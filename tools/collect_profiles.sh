@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence bench.py's `roofline` refers to (run on the GPU box via gpurun):
 #   1. --kernel-trace --stats of the default bench command (kernel durations),
-#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) — never combined with a trace domain,
+#   2. separate --pmc passes (FETCH_SIZE; WRITE_SIZE; MFMA busy cycles) — never combined with a trace domain,
 # and summarises them into profiles/<tag>_bench_kernel_stats.csv and profiles/<tag>_bench_pmc_hbm.csv
 # (written under gpurun_out/profiles/, copy them into profiles/ afterwards).
 # usage: tools/collect_profiles.sh r01
@@ -15,4 +15,5 @@ BENCH_ARGS="--steps 8 --warmup 4 --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" $BENCH_ARGS > "$OUT/stats.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" $BENCH_ARGS > "$OUT/pmc_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 "$R/bench.py" $BENCH_ARGS > "$OUT/pmc_mfma.log" 2>&1
 python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG"

@@ -49,6 +49,23 @@ def main():
         w = csv.writer(fh)
         w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_raw_avg", "fetch_bytes_corrected_x2", "write_bytes", "hbm_bytes_per_launch"])
         w.writerows(rows)
+    # matrix-core utilisation of the kernels that use it: SQ_VALU_MFMA_BUSY_CYCLES counts pipe cycles summed over the SIMDs
+    # (32 per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE the busy cycles summed over the 8 XCDs (observed: 8 x duration x
+    # clock); utilisation = busy / (gui_active / 8 * 1024 SIMDs)
+    mdir = os.path.join(out, "pmc_mfma")
+    if os.path.isdir(mdir):
+        busy = counter_avg(mdir, "SQ_VALU_MFMA_BUSY_CYCLES")
+        mops = counter_avg(mdir, "SQ_INSTS_VALU_MFMA_MOPS_F16")
+        act = counter_avg(mdir, "GRBM_GUI_ACTIVE")
+        with open(os.path.join(out, f"{tag}_bench_pmc_mfma.csv"), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["kernel", "dispatches", "mfma_busy_cycles_avg", "mfma_mops_f16_avg", "gui_active_cycles_avg", "mfma_pipe_utilisation"])
+            for k in sorted(busy, key=lambda k: -busy[k][0]):
+                b, n = busy[k]
+                if b <= 0:
+                    continue
+                a = act.get(k, (0.0, 0))[0]
+                w.writerow([k, n, round(b), round(mops.get(k, (0.0, 0))[0]), round(a), round(b / (a / 8.0 * 1024.0), 4) if a else ""])
     print("wrote", out, tag)
 
 
