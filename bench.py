@@ -175,44 +175,62 @@ def cuda_ray_train_step(model, opt, scaler, rays_o, rays_d, target):
     return loss
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=10.0, one_core_s=4.0):
     """The CPU oracle port of the same step's kernels (G1 -> M1 sigma -> M1 colour -> fixed-step composite, forward and backward)
-    on a bounded sample: as many 512-sample rays as fit in ~budget_s seconds of one host core."""
+    on a bounded sample: as many 512-sample rays as the host cores available to this process get through in ~budget_s seconds
+    (one worker thread per core, up to 16; the C calls release the GIL), after a short single-core run for reference."""
     import numpy as np
     import oracle
+    from concurrent.futures import ThreadPoolExecutor
     from focnerf_amd.gridencoder import level_offsets
-    rng = np.random.default_rng(0)
     pls = np.exp2(np.log2(2048 / 16) / 15)
     S = float(np.log2(pls))
     off = level_offsets(3, 16, pls, 16, 19)
-    table = rng.uniform(-1, 1, (int(off[-1]), 2)).astype(np.float16)
-    Ws = (rng.uniform(-1, 1, 64 * (32 + 64 + 16)) * 0.2).astype(np.float16)
-    Wc = (rng.uniform(-1, 1, 64 * (32 + 128 + 16)) * 0.2).astype(np.float16)
+    rng0 = np.random.default_rng(0)
+    table = rng0.uniform(-1, 1, (int(off[-1]), 2)).astype(np.float16)
+    Ws = (rng0.uniform(-1, 1, 64 * (32 + 64 + 16)) * 0.2).astype(np.float16)
+    Wc = (rng0.uniform(-1, 1, 64 * (32 + 128 + 16)) * 0.2).astype(np.float16)
     rays_per_chunk = 8
     B = rays_per_chunk * NUM_STEPS            # 4096 samples, a multiple of 128
-    done, t0 = 0, time.perf_counter()
-    while True:
-        x = rng.random((B, 3)).astype(np.float32)
-        enc = oracle.grid_encode_forward(x, table, off, 3, 2, 16, S, 16)
-        enc_bl = np.ascontiguousarray(np.transpose(enc, (1, 0, 2)).reshape(B, 32))
-        h, fb_s = oracle.ffmlp_forward(enc_bl, Ws, 32, 64, 2, 0)
-        sigma = np.exp(h[:, 0].astype(np.float32))
-        c, fb_c = oracle.ffmlp_forward(np.concatenate([h, h], 1).astype(np.float16), Wc, 32, 64, 3, 0)
-        rgb = 1 / (1 + np.exp(-c[:, :3].astype(np.float32)))
-        nears = np.full(rays_per_chunk, 0.5, np.float32); fars = np.full(rays_per_chunk, 2.5, np.float32)
-        oracle.composite_fixed_steps(sigma.reshape(rays_per_chunk, NUM_STEPS), rgb.reshape(rays_per_chunk, NUM_STEPS, 3), nears, fars, 1.0)
-        g = (rng.standard_normal((B, 16)) * 0.01).astype(np.float16)
-        gw_c, gi_c, _ = oracle.ffmlp_backward(g, np.concatenate([h, h], 1).astype(np.float16), Wc, fb_c, 32, 64, 3, 0, True)
-        gw_s, gi_s, _ = oracle.ffmlp_backward(gi_c[:, :16].copy(), enc_bl, Ws, fb_s, 32, 64, 2, 0, True)
-        genc = np.ascontiguousarray(np.transpose(gi_s.reshape(B, 16, 2), (1, 0, 2)))
-        oracle.grid_encode_backward(genc, x, off, int(off[-1]), 3, 2, 16, S, 16)
-        done += B
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return {"value": done / el, "unit": "samples/s", "cores": 1, "kind": "port",
+    oracle.lib()                              # build / load once, before the threads start
+
+    def worker(seed, seconds):
+        rng = np.random.default_rng(seed)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            x = rng.random((B, 3)).astype(np.float32)
+            enc = oracle.grid_encode_forward(x, table, off, 3, 2, 16, S, 16)
+            enc_bl = np.ascontiguousarray(np.transpose(enc, (1, 0, 2)).reshape(B, 32))
+            h, fb_s = oracle.ffmlp_forward(enc_bl, Ws, 32, 64, 2, 0)
+            sigma = np.exp(h[:, 0].astype(np.float32))
+            cin = np.concatenate([h, h], 1).astype(np.float16)
+            c, fb_c = oracle.ffmlp_forward(cin, Wc, 32, 64, 3, 0)
+            rgb = 1 / (1 + np.exp(-c[:, :3].astype(np.float32)))
+            nears = np.full(rays_per_chunk, 0.5, np.float32); fars = np.full(rays_per_chunk, 2.5, np.float32)
+            oracle.composite_fixed_steps(sigma.reshape(rays_per_chunk, NUM_STEPS), rgb.reshape(rays_per_chunk, NUM_STEPS, 3), nears, fars, 1.0)
+            g = (rng.standard_normal((B, 16)) * 0.01).astype(np.float16)
+            gw_c, gi_c, _ = oracle.ffmlp_backward(g, cin, Wc, fb_c, 32, 64, 3, 0, True)
+            gw_s, gi_s, _ = oracle.ffmlp_backward(gi_c[:, :16].copy(), enc_bl, Ws, fb_s, 32, 64, 2, 0, True)
+            genc = np.ascontiguousarray(np.transpose(gi_s.reshape(B, 16, 2), (1, 0, 2)))
+            oracle.grid_encode_backward(genc, x, off, int(off[-1]), 3, 2, 16, S, 16)
+            done += B
+        return done, time.perf_counter() - t0
+
+    d1, e1 = worker(1, one_core_s)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        res = list(pool.map(lambda sd: worker(sd, budget_s), range(100, 100 + cores)))
+    el = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    return {"value": done / el, "unit": "samples/s", "cores": cores, "kind": "port", "one_core_value": d1 / e1,
             "sample": f"{done} samples ({done // NUM_STEPS} rays x {NUM_STEPS}) of the same step's kernels "
-                      f"(hash-grid fwd/bwd, both fused MLPs fwd/bwd, fixed-step composite), scalar C oracle, {el:.1f} s"}
+                      f"(hash-grid fwd/bwd, both fused MLPs fwd/bwd, fixed-step composite), scalar C oracle on {cores} threads, {el:.1f} s "
+                      f"(+ {e1:.1f} s single-core run)"}
 
 
 def main():
