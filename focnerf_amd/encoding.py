@@ -1,7 +1,6 @@
 """encoding.get_encoder — the module the reference's networks import (nerf/network_ff.py:5,
 nerf/network.py:5) but the reference tree does not contain. Signature follows
 torch-ngp's: returns (encoder module, output_dim)."""
-import torch.nn as nn
 
 from .gridencoder import GridEncoder
 from .freqencoder import FreqEncoder

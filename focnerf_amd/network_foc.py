@@ -14,7 +14,6 @@ torch expressions and to `network.NeRFNetwork` with a zero object feature.
 """
 import os
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -8,7 +8,6 @@ cascaded 128^3 grid at cell centres exactly where `update_extra_state` would sam
 """
 import math
 
-import numpy as np
 import torch
 
 
