@@ -270,6 +270,41 @@ def test_full_batch_properties():
         assert torch.allclose(got, want, atol=2e-3), f"level {l}"
 
 
+def test_beyond_baseline_size_and_render_view_size():
+    """Sizes past the training batch: B = 6 M + 37 ray-ordered points in fp16 (1.6 G record slots: the 32-bit record indices of the
+    binned backward are still in range, the ragged tail exercises the partial last workgroup), through the encoder -> MLP node."""
+    from focnerf_amd.network import NeRFNetwork
+    from focnerf_amd.field import hashgrid_mlp
+    torch.manual_seed(5)
+    m = NeRFNetwork(bound=1).cuda().train()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    n_rays, T = 11719, 512
+    B = n_rays * T + 37                                              # 6 000 165
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    o = torch.rand(n_rays + 1, 1, 3, device="cuda", generator=gen) * 0.4 - 0.2
+    d = torch.nn.functional.normalize(torch.randn(n_rays + 1, 1, 3, device="cuda", generator=gen), dim=-1)
+    t = torch.linspace(-1.0, 1.0, T, device="cuda")[None, :, None]
+    x = (o + d * t).clamp(-1, 1).reshape(-1, 3)[:B].contiguous()
+    with torch.autocast("cuda", dtype=torch.float16):
+        h = hashgrid_mlp(m.encoder, m.sigma_net, x, 1)
+        sel = torch.randint(0, B, (2048,), device="cuda", generator=gen)
+        h_small = hashgrid_mlp(m.encoder, m.sigma_net, x[sel], 1)
+    assert torch.equal(h[sel], h_small), "rows are independent of the batch they are evaluated in"
+    g = (torch.randn(B, 16, device="cuda", generator=gen) * 1e-2).half()
+    h.backward(g)
+    ge = m.encoder.embeddings.grad
+    assert torch.isfinite(ge).all() and ge.abs().max() > 0
+    # same gradient from three slices of the batch (fixed-point sums per slice, added in fp32): linear in the batch
+    ge_full = ge.clone()
+    m.zero_grad(set_to_none=True)
+    cuts = [0, 2_000_000, 4_100_000 + 11, B]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with torch.autocast("cuda", dtype=torch.float16):
+            hashgrid_mlp(m.encoder, m.sigma_net, x[a:b], 1).backward(g[a:b])
+    scale = ge_full.abs().max().item()
+    assert (m.encoder.embeddings.grad - ge_full).abs().max().item() <= 4e-3 * scale
+
+
 def test_freq_encoder():
     from focnerf_amd.freqencoder import FreqEncoder
     torch.manual_seed(0)
