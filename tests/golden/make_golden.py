@@ -6,6 +6,7 @@ Run ONLY in the build container (needs /root/reference); the GPU box never runs 
 What is imported from the reference (nothing is copied into this repo; the fixtures hold data only):
   * activation.trunc_exp                      -> trunc_exp.npz   (forward + backward values)
   * nerf.renderer.NeRFRenderer.run            -> run_foc.npz     (FOC fixed-step compositing, mask w > 1e-10)
+  * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
   (legacy/nerf/renderer.py is not importable here: its `from .utils import custom_meshgrid` pulls in
    imageio, cv2, tensorboardX, mcubes, lpips, torchmetrics, torch_ema ... none of which are installed.)
 `raymarching` (a CUDA extension that would JIT-build on import) and `trimesh`
@@ -122,6 +123,94 @@ def run_reference(mod, foc, bound, N, T, seed):
     return out
 
 
+def poly_sigma(x):
+    """Analytic density of the grid-maintenance fixture: add / multiply / max only, so that every IEEE-754 machine gets the same bits
+    (torch's CPU exp differs in the last place between vector ISAs)."""
+    c = torch.tensor([0.1, -0.05, 0.2])
+    r2 = ((x - c) * (x - c)).sum(-1)
+    a = torch.clamp(1.0 - r2 * 2.5, min=0.0)
+    q = ((x + 0.4) * (x + 0.4)).sum(-1)
+    b = torch.clamp(1.0 - q * 16.0, min=0.0)
+    return a * a * 40.0 + b * 3.0
+
+
+def grid_maintenance(H=32, bound=2):
+    """NeRFRenderer.mark_untrained_grid and update_extra_state (nerf/renderer.py:356-508) run on the CPU at grid size H (the reference
+    hard-codes 128; the attribute and the two buffers are replaced after construction, every use goes through self.grid_size).
+    morton3D / morton3D_invert / packbits are this repo's oracle (the reference's are CUDA); torch.rand_like is pinned to 0.5 (cell
+    centres) and the torch.randint draws of the steady-state branch are recorded, so the call can be replayed exactly."""
+    # nerf/renderer.py calls custom_meshgrid without importing it (the reference's FOC renderer cannot run its own occupancy path,
+    # SURVEY.md H4); the helper is torch.meshgrid(..., indexing='ij') in the reference's utils.py
+    foc_renderer.custom_meshgrid = lambda *a: torch.meshgrid(*a, indexing='ij')
+    rm.morton3D = lambda c: torch.from_numpy(oracle.morton3D(c.numpy()))
+    rm.morton3D_invert = lambda i: torch.from_numpy(oracle.morton3D_invert(i.numpy().astype(np.int32)))
+    rm.packbits = lambda grid, thresh, bitfield=None: torch.from_numpy(oracle.packbits(grid.contiguous().numpy(), thresh))
+
+    class Toy(foc_renderer.NeRFRenderer):
+        def density(self, x):
+            return {'sigma': poly_sigma(x)}
+
+    m = Toy(bound=bound, cuda_ray=True, density_thresh=0.01)
+    C = m.cascade
+    m.grid_size = H
+    m.density_grid = torch.zeros(C, H ** 3)
+    m.density_bitfield = torch.zeros(C * H ** 3 // 8, dtype=torch.uint8)
+    out = dict(H=np.int32(H), bound=np.float32(bound), cascade=np.int32(C), decay=np.float32(0.95), density_thresh=np.float32(m.density_thresh),
+               density_scale=np.float32(m.density_scale))
+    # ---- mark_untrained_grid
+    g = torch.Generator().manual_seed(7)
+    th = torch.rand(5, generator=g) * (np.pi / 3) + np.pi / 3
+    ph = torch.rand(5, generator=g) * 2 * np.pi
+    centers = torch.stack([torch.sin(th) * torch.sin(ph), torch.cos(th), torch.sin(th) * torch.cos(ph)], -1) * 2.2
+    fw = -centers / centers.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, -1.0, 0.0]).expand(5, 3)
+    rt = torch.cross(fw, up, dim=-1); rt = rt / rt.norm(dim=-1, keepdim=True)
+    up2 = torch.cross(rt, fw, dim=-1); up2 = up2 / up2.norm(dim=-1, keepdim=True)
+    poses = torch.eye(4).repeat(5, 1, 1)
+    poses[:, :3, 0], poses[:, :3, 1], poses[:, :3, 2], poses[:, :3, 3] = rt, up2, fw, centers
+    intr = (700.0, 650.0, 200.0, 180.0)                     # a narrow frustum, so that some cells are seen by nobody
+    m.density_grid.fill_(1.0)
+    out.update(mark_poses=poses.numpy(), mark_intrinsics=np.array(intr, np.float32), mark_grid_before=m.density_grid.numpy().copy())
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.mark_untrained_grid(poses, intr)
+    out['mark_grid_after'] = m.density_grid.numpy().copy()
+    # ---- two full sweeps (iter_density < 16), jitter pinned to the cell centre
+    m.density_grid.zero_()
+    m.density_grid[0, ::9] = -1.0                           # some untrained cells, as mark_untrained_grid leaves them
+    out['sweep_grid_before'] = m.density_grid.numpy().copy()
+    orig_rand_like, orig_randint = torch.rand_like, torch.randint
+    torch.rand_like = lambda t, **k: torch.full_like(t, 0.5)
+    try:
+        for it in range(2):
+            m.update_extra_state()
+            out[f'sweep{it}_grid'] = m.density_grid.numpy().copy()
+            out[f'sweep{it}_mean'] = np.float32(m.mean_density)
+            out[f'sweep{it}_bits'] = m.density_bitfield.numpy().copy()
+        # ---- one steady-state update (iter_density >= 16), its torch.randint draws recorded
+        m.iter_density = 16
+        drawn = []
+
+        def recording_randint(*a, **k):
+            t = orig_randint(*a, **k)
+            drawn.append(t.clone())
+            return t
+        torch.randint = recording_randint
+        torch.manual_seed(11)
+        n_occ = [int((m.density_grid[c] > 0).sum()) for c in range(C)]
+        m.update_extra_state()
+    finally:
+        torch.rand_like, torch.randint = orig_rand_like, orig_randint
+    assert len(drawn) == 2 * C
+    out['steady_n_occ'] = np.array(n_occ, np.int32)
+    out['steady_coords'] = np.stack([drawn[2 * c].numpy() for c in range(C)]).astype(np.uint8)          # [C, N, 3]
+    out['steady_pick'] = np.stack([drawn[2 * c + 1].numpy() for c in range(C)]).astype(np.int32)      # [C, N] index into the occupied list
+    out['steady_grid'] = m.density_grid.numpy().copy()
+    out['steady_mean'] = np.float32(m.mean_density)
+    out['steady_bits'] = m.density_bitfield.numpy().copy()
+    return out
+
+
 def main():
     # trunc_exp
     g = torch.Generator().manual_seed(0)
@@ -133,6 +222,7 @@ def main():
 
     np.savez_compressed(os.path.join(HERE, "run_foc.npz"), **run_reference(foc_renderer, True, bound=1, N=96, T=128, seed=1))
     np.savez_compressed(os.path.join(HERE, "run_foc_b2.npz"), **run_reference(foc_renderer, True, bound=2, N=64, T=512, seed=2))
+    np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -308,3 +308,52 @@ def test_grid_update_known_answers():
     assert list(idx2[1]) == [511, 1, 511, 1]                         # cascade 1 has no occupied cell: the random cells are repeated
     c = oracle.morton3D_invert(np.array([100], np.int32))[0].astype(np.float32)
     assert np.array_equal(xyz[2], (2 * c / (H - 1) - 1) * np.float32(1 - 1 / H))     # jitter 0.5 -> centre of the cell, cascade 0 scale
+
+
+# ---------------------------------------------------------------- density-grid maintenance against the REFERENCE's own torch code
+def _golden_sigma(x):
+    """The analytic density of the grid-maintenance fixture (tests/golden/make_golden.py, poly_sigma): add / multiply / max only, the
+    same bits on every IEEE-754 machine."""
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(x))
+    c = torch.tensor([0.1, -0.05, 0.2])
+    r2 = ((x - c) * (x - c)).sum(-1)
+    a = torch.clamp(1.0 - r2 * 2.5, min=0.0)
+    q = ((x + 0.4) * (x + 0.4)).sum(-1)
+    b = torch.clamp(1.0 - q * 16.0, min=0.0)
+    return (a * a * 40.0 + b * 3.0).numpy()
+
+
+def test_grid_maintenance_against_reference_fixture(golden_dir):
+    """tests/golden/grid_maintenance.npz = NeRFRenderer.mark_untrained_grid / update_extra_state of the reference (nerf/renderer.py:356-508)
+    executed on the CPU at grid size 32 with the jitter pinned to the cell centres and the randint draws recorded. The oracle's
+    restatement replays the same calls: this pins the restatement (and through the GPU parity tests the kernels) to the reference."""
+    g = np.load(os.path.join(golden_dir, "grid_maintenance.npz"))
+    H, C, bound = int(g["H"]), int(g["cascade"]), float(g["bound"])
+    H3 = H ** 3
+    # mark_untrained_grid: torch's CPU matmul may associate the 3-term dot product differently -> cells exactly on a frustum plane
+    got, cnt = oracle.mark_untrained_grid(g["mark_poses"], tuple(float(v) for v in g["mark_intrinsics"]), bound, C, H, g["mark_grid_before"])
+    ref = g["mark_grid_after"]
+    assert ((got == -1) != (ref == -1)).mean() < 1e-4
+    assert 0.02 < (ref == -1).mean() < 0.98
+    # two full sweeps
+    grid = g["sweep_grid_before"].copy()
+    half = np.full((C * H3, 3), 0.5, np.float32)
+    for it in range(2):
+        xyz = oracle.grid_cells_xyz(C, H, bound, half)
+        grid, bits, mean = oracle.grid_update_apply(grid, C, H, _golden_sigma(xyz), None, float(g["density_scale"]), float(g["decay"]), float(g["density_thresh"]))
+        assert np.array_equal(grid, g[f"sweep{it}_grid"]), f"sweep {it}: density_grid"
+        assert abs(mean - float(g[f"sweep{it}_mean"])) <= 2e-6 * max(1.0, abs(mean))
+        assert np.array_equal(bits, g[f"sweep{it}_bits"]), f"sweep {it}: bitfield"
+    assert (grid[0, ::9] == -1).all()
+    # steady-state update: recorded random cells, picks k into the ascending occupied list expressed as u = (k + 0.5) / n_occ
+    coords = g["steady_coords"].astype(np.int32)
+    n_occ = g["steady_n_occ"].astype(np.float64)
+    assert (n_occ > 0).all()
+    u = ((g["steady_pick"].astype(np.float64) + 0.5) / n_occ[:, None]).astype(np.float32)
+    N = coords.shape[1]
+    idx, xyz = oracle.grid_update_sample(grid, C, H, bound, coords, u, np.full((C * 2 * N, 3), 0.5, np.float32))
+    grid2, bits2, mean2 = oracle.grid_update_apply(grid, C, H, _golden_sigma(xyz), idx, float(g["density_scale"]), float(g["decay"]), float(g["density_thresh"]))
+    assert np.array_equal(grid2, g["steady_grid"])
+    assert abs(mean2 - float(g["steady_mean"])) <= 2e-6 * max(1.0, abs(mean2))
+    assert np.array_equal(bits2, g["steady_bits"])
