@@ -7,6 +7,7 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * activation.trunc_exp                      -> trunc_exp.npz   (forward + backward values)
   * nerf.renderer.NeRFRenderer.run            -> run_foc.npz     (FOC fixed-step compositing, mask w > 1e-10)
   * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
+  * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
   (legacy/nerf/renderer.py is not importable here: its `from .utils import custom_meshgrid` pulls in
    imageio, cv2, tensorboardX, mcubes, lpips, torchmetrics, torch_ema ... none of which are installed.)
 `raymarching` (a CUDA extension that would JIT-build on import) and `trimesh`
@@ -211,6 +212,51 @@ def grid_maintenance(H=32, bound=2):
     return out
 
 
+def combined_fixture(K=4, N=40, T=64):
+    """COMBINED.py keeps its logic in methods of a class defined inside its `__main__` block and imports ultralytics, lpips, cv2, ...
+    at the top, so the file cannot be imported. The two methods on the path — best_densities_and_colors_v3 (:247-251) and
+    image_depth_generation (:141-200) — are located with `ast`, compiled from the reference file where it lies and run here with the
+    objects they reach for: `raymarching` (near_far_from_aabb = this repo's oracle), `opt.num_steps`, `self.model`. The object loop is
+    the one of :592-618 (first object initialises, later ones go through the select)."""
+    import ast
+    import textwrap
+    path = os.path.join(REF, "COMBINED.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    wanted = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("best_densities_and_colors_v3", "image_depth_generation"):
+            wanted[node.name] = textwrap.dedent(ast.get_source_segment(src, node))
+    assert len(wanted) == 2
+    ns = {"torch": torch, "raymarching": rm, "opt": types.SimpleNamespace(num_steps=T)}
+    for code in wanted.values():
+        exec(compile(code, path, "exec"), ns)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    me = types.SimpleNamespace(model=types.SimpleNamespace(aabb_train=aabb, aabb_infer=aabb, training=False, min_near=0.2))
+    g = torch.Generator().manual_seed(5)
+    o, d = make_rays(N, 9, 1)
+    dens = torch.rand(K, 1, N, T, generator=g) * 3
+    dens[dens < 0.6] = 0.0                                     # empty space, and therefore ties at zero between objects
+    dens[2, 0, :, ::5] = dens[0, 0, :, ::5]                    # exact ties between objects 0 and 2: the first one must win
+    rgbs = torch.rand(K, 1, N, T, 3, generator=g)
+    max_d, max_rgb = None, None
+    for k in range(K):                                         # COMBINED.py:592-618
+        if max_d is None:
+            max_d, max_rgb = dens[k], rgbs[k]
+        else:
+            max_d, max_rgb = ns["best_densities_and_colors_v3"](me, dens[k], max_d, rgbs[k], max_rgb)
+    data = {"rays_o": o, "rays_d": d}
+    out = dict(rays_o=o.numpy(), rays_d=d.numpy(), aabb=aabb.numpy(), min_near=np.float32(0.2), densities=dens.numpy(), rgbs=rgbs.numpy(),
+               max_densities=max_d.numpy(), max_rgbs=max_rgb.numpy())
+    for bg in ("white", "black"):
+        img, dep = ns["image_depth_generation"](me, data, max_d.clone(), max_rgb.clone(), bg)
+        out[f"image_{bg}"] = img.numpy()
+        out[f"depth_{bg}"] = dep.numpy()
+    nears, fars = _near_far(o, d, aabb, 0.2)
+    out["nears"], out["fars"] = nears.numpy(), fars.numpy()
+    return out
+
+
 def main():
     # trunc_exp
     g = torch.Generator().manual_seed(0)
@@ -223,6 +269,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "run_foc.npz"), **run_reference(foc_renderer, True, bound=1, N=96, T=128, seed=1))
     np.savez_compressed(os.path.join(HERE, "run_foc_b2.npz"), **run_reference(foc_renderer, True, bound=2, N=64, T=512, seed=2))
     np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
+    np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -69,3 +69,29 @@ def test_key_pack_unpack_and_single_rank_combiner():
     i_ref, d_ref = oracle.composite_fixed_steps(dens[0], rgb[0], nears, fars, 1.0, clamp01=True)
     np.testing.assert_allclose(to_np(img), i_ref, atol=1e-4)
     np.testing.assert_allclose(to_np(dep), d_ref, atol=1e-4)
+
+
+def test_combine_kernels_replay_the_reference_fixture():
+    """tests/golden/combined.npz (COMBINED.py's own best_densities_and_colors_v3 loop + image_depth_generation) through the HIP path:
+    the serial select, the key form used across ranks (simulated here: K packs, elementwise max, unpack per rank, sum), the composite."""
+    import os
+    from focnerf_amd.combine import combine_serial, composite_fixed_steps, HipCombineOps
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "combined.npz"))
+    dens, rgbs = g["densities"][:, 0], g["rgbs"][:, 0]          # [K,N,T], [K,N,T,3]
+    K, N, T = dens.shape
+    fields = [(torch.from_numpy(dens[k]).cuda(), torch.from_numpy(rgbs[k]).cuda()) for k in range(K)]
+    md, best = combine_serial(fields)
+    assert np.array_equal(to_np(md), g["max_densities"][0]) and np.array_equal(to_np(best), g["max_rgbs"][0])
+    # what ObjectCombiner.select does with K ranks: all-reduce(MAX) of the keys, all-reduce(SUM) of the winner-masked colours
+    keys = torch.stack([HipCombineOps.pack_keys(fields[k][0], k) for k in range(K)]).max(dim=0).values
+    md2, summed = None, 0
+    for k in range(K):
+        md2, masked = HipCombineOps.unpack(keys, k, fields[k][1])
+        summed = summed + masked
+    assert np.array_equal(to_np(md2), g["max_densities"][0]) and np.array_equal(to_np(summed), g["max_rgbs"][0])
+    nears, fars = torch.from_numpy(g["nears"]).cuda(), torch.from_numpy(g["fars"]).cuda()
+    for bg, val in (("white", 1.0), ("black", 0.0)):
+        img4, depth = composite_fixed_steps(md, best, nears, fars, val)
+        ok = np.isfinite(g[f"depth_{bg}"])
+        np.testing.assert_allclose(to_np(img4), g[f"image_{bg}"], atol=1e-4, rtol=0)       # RGB / alpha within the 1e-4 target
+        np.testing.assert_allclose(to_np(depth)[ok], g[f"depth_{bg}"][ok], atol=1e-4, rtol=0)

@@ -357,3 +357,33 @@ def test_grid_maintenance_against_reference_fixture(golden_dir):
     assert np.array_equal(grid2, g["steady_grid"])
     assert abs(mean2 - float(g["steady_mean"])) <= 2e-6 * max(1.0, abs(mean2))
     assert np.array_equal(bits2, g["steady_bits"])
+
+
+# ---------------------------------------------------------------- multi-object combine against COMBINED.py's own methods
+def test_combine_matches_reference_fixture(golden_dir):
+    """tests/golden/combined.npz = COMBINED.py's best_densities_and_colors_v3 looped over 4 objects (:592-618, ties at zero and exact ties
+    between objects) followed by image_depth_generation for both backgrounds, run from the reference file. The oracle's select is
+    bit-exact (first object wins ties), its composite agrees to 2e-6 (torch.cumprod vs a running product)."""
+    g = np.load(os.path.join(golden_dir, "combined.npz"))
+    dens, rgbs = g["densities"], g["rgbs"]                     # [K,1,N,T], [K,1,N,T,3]
+    K, _, N, T = dens.shape
+    max_d, best = dens[0, 0].copy(), rgbs[0, 0].copy()
+    for k in range(1, K):
+        max_d, best = oracle.combine_select(dens[k, 0], rgbs[k, 0], max_d, best)
+    assert np.array_equal(max_d, g["max_densities"][0]) and np.array_equal(best.reshape(N, T, 3), g["max_rgbs"][0])
+    # the serial select written as one pass over objects (what one all-reduce(MAX) of (sigma, -rank) keys computes): same winner
+    winner = np.zeros((N, T), np.int64)
+    cur = dens[0, 0].copy()
+    for k in range(1, K):
+        take = dens[k, 0] > cur
+        winner[take] = k
+        cur = np.maximum(cur, dens[k, 0])
+    assert np.array_equal(np.take_along_axis(rgbs[:, 0], winner[None, ..., None].repeat(3, -1), 0)[0], g["max_rgbs"][0])
+    n2, f2 = oracle.near_far_from_aabb(g["rays_o"], g["rays_d"], g["aabb"], float(g["min_near"]))
+    assert np.array_equal(n2, g["nears"]) and np.array_equal(f2, g["fars"])
+    for bg, val in (("white", 1.0), ("black", 0.0)):
+        img, dep = oracle.composite_fixed_steps(max_d, best.reshape(N, T, 3), g["nears"], g["fars"], val)
+        ok = np.isfinite(g[f"depth_{bg}"])
+        np.testing.assert_allclose(img, g[f"image_{bg}"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(dep[ok], g[f"depth_{bg}"][ok], atol=2e-6, rtol=0)
+        assert np.array_equal(np.isnan(dep), np.isnan(g[f"depth_{bg}"]))
