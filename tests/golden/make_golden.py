@@ -8,6 +8,7 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * nerf.renderer.NeRFRenderer.run            -> run_foc.npz     (FOC fixed-step compositing, mask w > 1e-10)
   * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
   * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
+  * gridencoder.GridEncoder / grid_encode and ffmlp.FFMLP / ffmlp_forward (the Python wrappers, on oracle-backed stub backends) -> wrappers.npz
   (legacy/nerf/renderer.py is not importable here: its `from .utils import custom_meshgrid` pulls in
    imageio, cv2, tensorboardX, mcubes, lpips, torchmetrics, torch_ema ... none of which are installed.)
 `raymarching` (a CUDA extension that would JIT-build on import) and `trimesh`
@@ -257,6 +258,105 @@ def combined_fixture(K=4, N=40, T=64):
     return out
 
 
+def wrapper_fixture():
+    """The reference's Python operator wrappers (gridencoder/grid.py GridEncoder + grid_encode, ffmlp/ffmlp.py FFMLP + ffmlp_forward)
+    driven on the CPU with their pybind11 backends replaced by stubs of the same names that call this repo's oracle. What the fixture
+    pins is the WRAPPER layer a drop-in has to reproduce: the level-offset table and per_level_scale of GridEncoder.__init__, the
+    (x + bound) / (2 bound) normalisation, the [L,B,C] <-> [B,L*C] permutes, FFMLP's weight-blob size and seed-42 initialisation, its
+    padding of the batch to a multiple of 128 and the slicing of the padded output. `_gridencoder` / `_ffmlp` are put into sys.modules
+    BEFORE the packages are imported, so their JIT-building backend.py is never reached; `turtle` (ffmlp.py:2, a stray
+    import that needs tkinter) is stubbed too."""
+    ge = types.ModuleType("_gridencoder")
+
+    def ge_fwd(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
+        res = oracle.grid_encode_forward(inputs.detach().numpy(), embeddings.detach().numpy(), offsets.numpy(), D, C, L, float(S), H,
+                                         dy_dx is not None, gridtype, align_corners, interp)
+        if dy_dx is not None:
+            outputs.copy_(torch.from_numpy(res[0])); dy_dx.copy_(torch.from_numpy(res[1]).reshape(dy_dx.shape))
+        else:
+            outputs.copy_(torch.from_numpy(res))
+
+    def ge_bwd(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
+        res = oracle.grid_encode_backward(grad.numpy(), inputs.detach().numpy(), offsets.numpy(), embeddings.shape[0], D, C, L, float(S), H,
+                                          dy_dx.numpy().reshape(B, L, D, C) if dy_dx is not None else None, gridtype, align_corners, interp)
+        if dy_dx is not None:
+            grad_embeddings.copy_(torch.from_numpy(res[0])); grad_inputs.copy_(torch.from_numpy(res[1]))
+        else:
+            grad_embeddings.copy_(torch.from_numpy(res))
+    ge.grid_encode_forward, ge.grid_encode_backward = ge_fwd, ge_bwd
+    sys.modules["_gridencoder"] = ge
+
+    ff = types.ModuleType("_ffmlp")
+    calls = {"allocate_splitk": [], "forward_B": [], "inference_B": []}
+
+    def ff_fwd(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs):
+        calls["forward_B"].append(int(B))
+        out, fb = oracle.ffmlp_forward(inputs.detach().numpy(), weights.detach().half().numpy(), input_dim, hidden_dim, num_layers, activation)
+        outputs.copy_(torch.from_numpy(out)); forward_buffer.copy_(torch.from_numpy(fb))
+
+    def ff_inf(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference_buffer, outputs):
+        calls["inference_B"].append(int(B))
+        outputs.copy_(torch.from_numpy(oracle.ffmlp_forward(inputs.detach().numpy(), weights.detach().half().numpy(), input_dim, hidden_dim, num_layers,
+                                                             activation, training=False)))
+
+    def ff_bwd(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs,
+               backward_buffer, grad_inputs, grad_weights):
+        gw, gi, bb = oracle.ffmlp_backward(grad.numpy(), inputs.detach().numpy(), weights.detach().half().numpy(), forward_buffer.numpy(), input_dim, hidden_dim,
+                                           num_layers, activation, bool(calc_grad_inputs))
+        grad_weights.copy_(torch.from_numpy(gw).to(grad_weights.dtype)); backward_buffer.copy_(torch.from_numpy(bb))
+        if calc_grad_inputs:
+            grad_inputs.copy_(torch.from_numpy(gi))
+    ff.ffmlp_forward, ff.ffmlp_inference, ff.ffmlp_backward = ff_fwd, ff_inf, ff_bwd
+    ff.allocate_splitk = lambda n: calls["allocate_splitk"].append(int(n))
+    ff.free_splitk = lambda: None
+    sys.modules["_ffmlp"] = ff
+    sys.modules.setdefault("turtle", types.SimpleNamespace(backward=None, forward=None))
+
+    import gridencoder as ref_ge            # /root/reference/gridencoder (sys.path), backend = the stub above
+    import ffmlp as ref_ff
+    assert ref_ge.__file__.startswith(REF) and ref_ff.__file__.startswith(REF)
+    out = {}
+    # ---- GridEncoder: default FOC table (offsets only: 6.1 M rows are not stored) and a small one driven end to end
+    big = ref_ge.GridEncoder(desired_resolution=2048)
+    out["big_offsets"] = big.offsets.numpy()
+    out["big_per_level_scale"] = np.float64(big.per_level_scale)
+    torch.manual_seed(3)
+    cfg = dict(input_dim=3, num_levels=8, level_dim=2, base_resolution=4, log2_hashmap_size=12, desired_resolution=96)
+    enc = ref_ge.GridEncoder(**cfg)
+    enc.embeddings.data.uniform_(-1, 1)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(77, 3, generator=g) * 2 - 1) * 2.0            # bound 2
+    x[5] = 2.0; x[6] = -2.0                                        # the faces of the box
+    xg = x.clone().requires_grad_(True)
+    y = enc(xg, bound=2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update(ge_offsets=enc.offsets.numpy(), ge_per_level_scale=np.float64(enc.per_level_scale), ge_embeddings=enc.embeddings.detach().numpy(),
+               ge_x=x.numpy(), ge_y=y.detach().numpy(), ge_gy=gy.numpy(), ge_grad_embeddings=enc.embeddings.grad.numpy(), ge_grad_x=xg.grad.numpy(),
+               ge_output_dim=np.int32(enc.output_dim))
+    # ---- FFMLP
+    mlp = ref_ff.FFMLP(input_dim=32, output_dim=3, hidden_dim=64, num_layers=2)
+    out["ff_weights"] = mlp.weights.detach().numpy()
+    out["ff_allocate_splitk"] = np.array(calls["allocate_splitk"], np.int32)
+    xin = (torch.randn(200, 32, generator=g) * 0.5).half()
+    mlp.eval()
+    with torch.no_grad():
+        out["ff_y_eval"] = mlp(xin).numpy()
+    mlp.train()
+    xt = xin.clone().requires_grad_(True)
+    yt = mlp(xt)
+    gyt = (torch.randn(200, 3, generator=g) * 0.1).half()
+    yt.backward(gyt)
+    out.update(ff_x=xin.numpy(), ff_y_train=yt.detach().numpy(), ff_gy=gyt.numpy(), ff_grad_x=xt.grad.numpy(), ff_grad_w=mlp.weights.grad.numpy(),
+               ff_forward_B=np.array(calls["forward_B"], np.int32), ff_inference_B=np.array(calls["inference_B"], np.int32))
+    # a batch that is already a multiple of 128 still gets one more block of padding (ffmlp.py:157-159)
+    mlp.eval()
+    with torch.no_grad():
+        mlp(xin[:128])
+    out["ff_inference_B_aligned"] = np.int32(calls["inference_B"][-1])
+    return out
+
+
 def main():
     # trunc_exp
     g = torch.Generator().manual_seed(0)
@@ -270,6 +370,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "run_foc_b2.npz"), **run_reference(foc_renderer, True, bound=2, N=64, T=512, seed=2))
     np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
     np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
+    np.savez_compressed(os.path.join(HERE, "wrappers.npz"), **wrapper_fixture())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
