@@ -9,6 +9,7 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
   * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
   * gridencoder.GridEncoder / grid_encode and ffmlp.FFMLP / ffmlp_forward (the Python wrappers, on oracle-backed stub backends) -> wrappers.npz
+  * raymarching/raymarching.py wrappers (same arrangement; Tensor.cuda patched to the identity for the run) -> raymarching_wrappers.npz
   (legacy/nerf/renderer.py is not importable here: its `from .utils import custom_meshgrid` pulls in
    imageio, cv2, tensorboardX, mcubes, lpips, torchmetrics, torch_ema ... none of which are installed.)
 `raymarching` (a CUDA extension that would JIT-build on import) and `trimesh`
@@ -357,6 +358,119 @@ def wrapper_fixture():
     return out
 
 
+def raymarching_wrapper_fixture(H=32, bound=2.0):
+    """The reference's raymarching/raymarching.py wrappers (output allocation, the mean_count / align / force_all_rays sizing and
+    slicing of march_rays_train, the padding of march_rays, the autograd plumbing of composite_rays_train) on an oracle-backed
+    `_raymarching` stub. The wrappers move their inputs with `.cuda()`; for this CPU run Tensor.cuda is the identity and
+    torch.cuda.empty_cache a no-op. perturb=False throughout (the noise comes from torch's generator). The package contains a
+    prebuilt _raymarching*.so; it is never loaded: the name is already in sys.modules when the package is imported."""
+    C = 2
+    st = types.ModuleType("_raymarching")
+
+    def t2n(t):
+        return t.detach().numpy()
+
+    def s_near_far(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        n, f = oracle.near_far_from_aabb(t2n(rays_o), t2n(rays_d), t2n(aabb), min_near)
+        nears.copy_(torch.from_numpy(n)); fars.copy_(torch.from_numpy(f))
+
+    def s_morton(coords, N, indices):
+        indices.copy_(torch.from_numpy(oracle.morton3D(t2n(coords))))
+
+    def s_morton_inv(indices, N, coords):
+        coords.copy_(torch.from_numpy(oracle.morton3D_invert(t2n(indices))))
+
+    def s_packbits(grid, N, thresh, bitfield):
+        bitfield.copy_(torch.from_numpy(oracle.packbits(t2n(grid.contiguous()), thresh)))
+
+    def s_march_train(rays_o, rays_d, grid, bnd, dt_gamma, max_steps, N, Cc, Hh, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises):
+        x, d, dl, r, c = oracle.march_rays_train(t2n(rays_o), t2n(rays_d), t2n(grid), bnd, dt_gamma, max_steps, Cc, Hh, M, t2n(nears), t2n(fars), t2n(noises), t2n(counter))
+        xyzs.copy_(torch.from_numpy(x)); dirs.copy_(torch.from_numpy(d)); deltas.copy_(torch.from_numpy(dl)); rays.copy_(torch.from_numpy(r))
+        counter.copy_(torch.from_numpy(c))
+
+    def s_comp_fwd(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+        w, dp, im = oracle.composite_rays_train_forward(t2n(sigmas), t2n(rgbs), t2n(deltas), t2n(rays), N, T_thresh)
+        weights_sum.copy_(torch.from_numpy(w)); depth.copy_(torch.from_numpy(dp)); image.copy_(torch.from_numpy(im))
+
+    def s_comp_bwd(gws, gim, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs):
+        gs, gc = oracle.composite_rays_train_backward(t2n(gws), t2n(gim), t2n(sigmas), t2n(rgbs), t2n(deltas), t2n(rays), t2n(weights_sum), t2n(image), T_thresh)
+        grad_sigmas.copy_(torch.from_numpy(gs)); grad_rgbs.copy_(torch.from_numpy(gc))
+
+    def s_march(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bnd, dt_gamma, max_steps, Cc, Hh, grid, nears, fars, xyzs, dirs, deltas, noises):
+        x, d, dl = oracle.march_rays(n_alive, n_step, t2n(rays_alive), t2n(rays_t), t2n(rays_o), t2n(rays_d), bnd, dt_gamma, max_steps, Cc, Hh, t2n(grid),
+                                     t2n(nears), t2n(fars), t2n(noises), M=xyzs.shape[0])
+        xyzs.copy_(torch.from_numpy(x)); dirs.copy_(torch.from_numpy(d)); deltas.copy_(torch.from_numpy(dl))
+
+    def s_comp(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        ra, rt, w, dp, im = oracle.composite_rays(n_alive, n_step, T_thresh, t2n(rays_alive), t2n(rays_t), t2n(sigmas), t2n(rgbs), t2n(deltas), t2n(weights_sum),
+                                                  t2n(depth), t2n(image))
+        rays_alive.copy_(torch.from_numpy(ra)); rays_t.copy_(torch.from_numpy(rt)); weights_sum.copy_(torch.from_numpy(w))
+        depth.copy_(torch.from_numpy(dp)); image.copy_(torch.from_numpy(im))
+
+    st.near_far_from_aabb, st.morton3D, st.morton3D_invert, st.packbits = s_near_far, s_morton, s_morton_inv, s_packbits
+    st.march_rays_train, st.composite_rays_train_forward, st.composite_rays_train_backward = s_march_train, s_comp_fwd, s_comp_bwd
+    st.march_rays, st.composite_rays = s_march, s_comp
+    sys.modules["_raymarching"] = st
+    saved = sys.modules.pop("raymarching")
+    orig_cuda, orig_empty = torch.Tensor.cuda, torch.cuda.empty_cache
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.empty_cache = lambda: None
+    try:
+        import raymarching as ref_rm
+        assert ref_rm.__file__.startswith(REF)
+        out = dict(H=np.int32(H), C=np.int32(C), bound=np.float32(bound))
+        # occupancy: a ball of radius 0.7 in both cascades
+        idx = torch.arange(H ** 3, dtype=torch.int32)
+        coords = ref_rm.morton3D_invert(idx)
+        out["morton_roundtrip_ok"] = np.bool_(torch.equal(ref_rm.morton3D(coords), idx))
+        grid = torch.zeros(C, H ** 3)
+        for cas in range(C):
+            b = min(2 ** cas, bound)
+            xyz = (2 * coords.float() / (H - 1) - 1) * (b - b / H)
+            grid[cas] = (xyz.norm(dim=-1) < 0.7).float() * 5.0
+        bitfield = ref_rm.packbits(grid, 0.5)
+        out["grid"], out["bitfield"] = grid.numpy(), bitfield.numpy()
+        o, d = make_rays(96, 21, bound * 0.9)
+        aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound])
+        nears, fars = ref_rm.near_far_from_aabb(o, d, aabb, 0.2)
+        out.update(rays_o=o.numpy(), rays_d=d.numpy(), aabb=aabb.numpy(), nears=nears.numpy(), fars=fars.numpy())
+        # march_rays_train: first epochs (mean_count <= 0: slice to the used count rounded up to 128), steady state (M = mean_count rounded
+        # up, here too small so that rays are dropped), force_all_rays
+        for name, kw in (("first", dict(mean_count=-1, align=128)), ("steady", dict(mean_count=700, align=128)), ("force", dict(mean_count=700, align=128, force_all_rays=True)),
+                         ("noalign", dict(mean_count=-1, align=-1))):
+            counter = torch.zeros(2, dtype=torch.int32)
+            xyzs, dirs, deltas, rays = ref_rm.march_rays_train(o, d, bound, bitfield, C, H, nears, fars, counter, kw.get("mean_count", -1), False, kw.get("align", -1),
+                                                               kw.get("force_all_rays", False), 1 / 128, 256)
+            out.update({f"mt_{name}_xyzs": xyzs.numpy(), f"mt_{name}_dirs": dirs.numpy(), f"mt_{name}_deltas": deltas.numpy(), f"mt_{name}_rays": rays.numpy(),
+                        f"mt_{name}_counter": counter.numpy()})
+        # composite_rays_train with autograd through the wrapper
+        xyzs, deltas, rays = torch.from_numpy(out["mt_first_xyzs"]), torch.from_numpy(out["mt_first_deltas"]), torch.from_numpy(out["mt_first_rays"])
+        g = torch.Generator().manual_seed(8)
+        sig = (torch.rand(xyzs.shape[0], generator=g) * 8).requires_grad_(True)
+        rgb = torch.rand(xyzs.shape[0], 3, generator=g).requires_grad_(True)
+        ws, dep, img = ref_rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+        gws, gimg = torch.rand(ws.shape, generator=g), torch.rand(img.shape, generator=g)
+        (ws * gws).sum().add((img * gimg).sum()).backward()
+        out.update(ct_sigmas=sig.detach().numpy(), ct_rgbs=rgb.detach().numpy(), ct_ws=ws.detach().numpy(), ct_depth=dep.detach().numpy(), ct_image=img.detach().numpy(),
+                   ct_gws=gws.numpy(), ct_gimg=gimg.numpy(), ct_grad_sigmas=sig.grad.numpy(), ct_grad_rgbs=rgb.grad.numpy())
+        # one inference iteration: march_rays (padded to 128) + composite_rays (in place)
+        N = o.shape[0]
+        n_alive, n_step = N, 3
+        rays_alive = torch.arange(N, dtype=torch.int32)
+        rays_t = nears.clone()
+        x2, d2, dl2 = ref_rm.march_rays(n_alive, n_step, rays_alive, rays_t, o, d, bound, bitfield, C, H, nears, fars, 128, False, 1 / 128, 256)
+        sig2 = torch.rand(x2.shape[0], generator=g) * 6
+        rgb2 = torch.rand(x2.shape[0], 3, generator=g)
+        wsum, dpt, im = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+        ref_rm.composite_rays(n_alive, n_step, rays_alive, rays_t, sig2, rgb2, dl2, wsum, dpt, im, 1e-2)
+        out.update(mi_xyzs=x2.numpy(), mi_dirs=d2.numpy(), mi_deltas=dl2.numpy(), mi_sigmas=sig2.numpy(), mi_rgbs=rgb2.numpy(), mi_rays_alive=rays_alive.numpy(),
+                   mi_rays_t=rays_t.numpy(), mi_ws=wsum.numpy(), mi_depth=dpt.numpy(), mi_image=im.numpy())
+    finally:
+        torch.Tensor.cuda, torch.cuda.empty_cache = orig_cuda, orig_empty
+        sys.modules["raymarching"] = saved
+    return out
+
+
 def main():
     # trunc_exp
     g = torch.Generator().manual_seed(0)
@@ -371,6 +485,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
     np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
     np.savez_compressed(os.path.join(HERE, "wrappers.npz"), **wrapper_fixture())
+    np.savez_compressed(os.path.join(HERE, "raymarching_wrappers.npz"), **raymarching_wrapper_fixture())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

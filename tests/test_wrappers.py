@@ -75,3 +75,57 @@ def test_ffmlp_module_matches_reference_wrapper():
     gw, gw_ref = to_np(mlp.weights.grad).astype(np.float32), g["ff_grad_w"].astype(np.float32)
     assert gw.shape == gw_ref.shape
     assert np.abs(gw - gw_ref).max() <= 2e-2 * np.abs(gw_ref).max() + 1e-3
+
+
+@pytest.mark.gpu
+def test_raymarching_wrappers_match_reference_wrappers():
+    """tests/golden/raymarching_wrappers.npz: the reference's raymarching.py wrappers on an oracle-backed `_raymarching` stub. Same calls
+    through focnerf_amd.raymarching on the device: shapes after the mean_count / align / force_all_rays sizing and slicing, sample
+    positions and ray tables bit for bit, composites within 1e-4 (`__expf`)."""
+    from focnerf_amd import raymarching as rm
+    g = np.load(os.path.join(HERE, "golden", "raymarching_wrappers.npz"))
+    H, C, bound = int(g["H"]), int(g["C"]), float(g["bound"])
+    dev = "cuda"
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    idx = torch.arange(H ** 3, dtype=torch.int32, device=dev)
+    coords = rm.morton3D_invert(idx)
+    assert torch.equal(rm.morton3D(coords), idx) and bool(g["morton_roundtrip_ok"])
+    bitfield = rm.packbits(t("grid"), 0.5)
+    assert np.array_equal(to_np(bitfield), g["bitfield"])
+    o, d, aabb = t("rays_o"), t("rays_d"), t("aabb")
+    nears, fars = rm.near_far_from_aabb(o, d, aabb, 0.2)
+    assert np.array_equal(to_np(nears), g["nears"]) and np.array_equal(to_np(fars), g["fars"])
+    cases = (("first", dict(mean_count=-1, align=128)), ("steady", dict(mean_count=700, align=128)), ("force", dict(mean_count=700, align=128, force_all_rays=True)),
+             ("noalign", dict(mean_count=-1, align=-1)))
+    for name, kw in cases:
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        xyzs, dirs, deltas, rays = rm.march_rays_train(o, d, bound, bitfield, C, H, nears, fars, counter, kw.get("mean_count", -1), False, kw.get("align", -1),
+                                                       kw.get("force_all_rays", False), 1 / 128, 256)
+        assert xyzs.shape == g[f"mt_{name}_xyzs"].shape, name
+        assert np.array_equal(to_np(counter), g[f"mt_{name}_counter"]), name
+        assert np.array_equal(to_np(rays), g[f"mt_{name}_rays"]), name
+        for a, k in ((xyzs, "xyzs"), (dirs, "dirs"), (deltas, "deltas")):
+            assert np.array_equal(to_np(a).view(np.uint32), g[f"mt_{name}_{k}"].view(np.uint32)), (name, k)
+    # composite_rays_train, forward and through autograd
+    sig, rgb = t("ct_sigmas").requires_grad_(True), t("ct_rgbs").requires_grad_(True)
+    ws, dep, img = rm.composite_rays_train(sig, rgb, t("mt_first_deltas"), t("mt_first_rays"), 1e-4)
+    np.testing.assert_allclose(to_np(ws), g["ct_ws"], atol=1e-4)
+    np.testing.assert_allclose(to_np(dep), g["ct_depth"], atol=1e-4)
+    np.testing.assert_allclose(to_np(img), g["ct_image"], atol=1e-4)
+    (ws * t("ct_gws")).sum().add((img * t("ct_gimg")).sum()).backward()
+    np.testing.assert_allclose(to_np(sig.grad), g["ct_grad_sigmas"], atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(to_np(rgb.grad), g["ct_grad_rgbs"], atol=1e-4)
+    # one inference iteration
+    N = o.shape[0]
+    rays_alive = torch.arange(N, dtype=torch.int32, device=dev)
+    rays_t = nears.clone()
+    x2, d2, dl2 = rm.march_rays(N, 3, rays_alive, rays_t, o, d, bound, bitfield, C, H, nears, fars, 128, False, 1 / 128, 256)
+    assert x2.shape == g["mi_xyzs"].shape
+    assert np.array_equal(to_np(x2).view(np.uint32), g["mi_xyzs"].view(np.uint32)) and np.array_equal(to_np(dl2).view(np.uint32), g["mi_deltas"].view(np.uint32))
+    wsum, dpt, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+    rm.composite_rays(N, 3, rays_alive, rays_t, t("mi_sigmas"), t("mi_rgbs"), dl2, wsum, dpt, im, 1e-2)
+    assert np.array_equal(to_np(rays_alive), g["mi_rays_alive"])
+    np.testing.assert_allclose(to_np(rays_t), g["mi_rays_t"], atol=1e-6)
+    np.testing.assert_allclose(to_np(wsum), g["mi_ws"], atol=1e-4)
+    np.testing.assert_allclose(to_np(dpt), g["mi_depth"], atol=1e-4)
+    np.testing.assert_allclose(to_np(im), g["mi_image"], atol=1e-4)
