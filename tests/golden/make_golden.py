@@ -465,6 +465,33 @@ def raymarching_wrapper_fixture(H=32, bound=2.0):
         ref_rm.composite_rays(n_alive, n_step, rays_alive, rays_t, sig2, rgb2, dl2, wsum, dpt, im, 1e-2)
         out.update(mi_xyzs=x2.numpy(), mi_dirs=d2.numpy(), mi_deltas=dl2.numpy(), mi_sigmas=sig2.numpy(), mi_rgbs=rgb2.numpy(), mi_rays_alive=rays_alive.numpy(),
                    mi_rays_t=rays_t.numpy(), mi_ws=wsum.numpy(), mi_depth=dpt.numpy(), mi_image=im.numpy())
+        # ---- NeRFRenderer.run_cuda (nerf/renderer.py:243-352) on top of these wrappers: the training branch (march_rays_train ->
+        # network -> composite_rays_train) and the inference loop (n_step schedule, alive-ray filtering), analytic network, perturb off
+        class ToyField(foc_renderer.NeRFRenderer):
+            def forward(self, x, d):
+                return poly_sigma(x), 0.5 + 0.25 * (x[..., :3] * 0.5 + d)
+
+        old_rm = foc_renderer.raymarching
+        foc_renderer.raymarching = ref_rm
+        try:
+            m = ToyField(bound=bound, cuda_ray=True)
+            m.grid_size = H
+            m.density_grid = grid.clone()
+            m.density_bitfield = bitfield.clone()
+            o2, d2r = make_rays(80, 33, bound * 0.9)
+            m.train()
+            tr0 = m.run_cuda(o2[None], d2r[None], dt_gamma=1 / 128, bg_color=None, perturb=False, force_all_rays=False, max_steps=256, T_thresh=1e-4)
+            m.mean_count = 640                                       # what update_extra_state would set; rays beyond M are dropped
+            tr1 = m.run_cuda(o2[None], d2r[None], dt_gamma=1 / 128, bg_color=0.25, perturb=False, force_all_rays=False, max_steps=256, T_thresh=1e-4)
+            m.eval()
+            with torch.no_grad():
+                ev = m.run_cuda(o2[None], d2r[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4)
+            out.update(rc_rays_o=o2.numpy(), rc_rays_d=d2r.numpy(), rc_step_counter=m.step_counter.numpy().copy(),
+                       rc_train0_image=tr0["image"][0].detach().numpy(), rc_train0_depth=tr0["depth"][0].detach().numpy(), rc_train0_ws=tr0["weights_sum"].detach().numpy(),
+                       rc_train1_image=tr1["image"][0].detach().numpy(), rc_train1_depth=tr1["depth"][0].detach().numpy(),
+                       rc_eval_image=ev["image"][0].numpy(), rc_eval_depth=ev["depth"][0].numpy())
+        finally:
+            foc_renderer.raymarching = old_rm
     finally:
         torch.Tensor.cuda, torch.cuda.empty_cache = orig_cuda, orig_empty
         sys.modules["raymarching"] = saved

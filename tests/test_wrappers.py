@@ -129,3 +129,46 @@ def test_raymarching_wrappers_match_reference_wrappers():
     np.testing.assert_allclose(to_np(wsum), g["mi_ws"], atol=1e-4)
     np.testing.assert_allclose(to_np(dpt), g["mi_depth"], atol=1e-4)
     np.testing.assert_allclose(to_np(im), g["mi_image"], atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_run_cuda_matches_reference_renderer():
+    """The reference's NeRFRenderer.run_cuda (nerf/renderer.py:243-352) was run on top of its own raymarching wrappers (oracle backends)
+    with an analytic field — two training calls (first epochs; a too small mean_count that drops rays) and the inference loop.
+    focnerf_amd.renderer.NeRFRenderer.run_cuda with the same field on the GPU must give the same images, depths and step counters."""
+    from focnerf_amd.renderer import NeRFRenderer
+    from test_oracle import _golden_sigma
+    g = np.load(os.path.join(HERE, "golden", "raymarching_wrappers.npz"))
+    H, bound = int(g["H"]), float(g["bound"])
+
+    class ToyField(NeRFRenderer):
+        def forward(self, x, d):
+            c = torch.tensor([0.1, -0.05, 0.2], device=x.device)
+            r2 = ((x - c) * (x - c)).sum(-1)
+            a = torch.clamp(1.0 - r2 * 2.5, min=0.0)
+            q = ((x + 0.4) * (x + 0.4)).sum(-1)
+            b = torch.clamp(1.0 - q * 16.0, min=0.0)
+            return a * a * 40.0 + b * 3.0, 0.5 + 0.25 * (x[..., :3] * 0.5 + d)
+
+    m = ToyField(bound=bound, cuda_ray=True).cuda()
+    m.grid_size = H
+    m.density_grid = torch.from_numpy(g["grid"]).cuda()
+    m.density_bitfield = torch.from_numpy(g["bitfield"]).cuda()
+    o, d = torch.from_numpy(g["rc_rays_o"]).cuda(), torch.from_numpy(g["rc_rays_d"]).cuda()
+    m.train()
+    tr0 = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, force_all_rays=False, max_steps=256, T_thresh=1e-4)
+    m.mean_count = 640
+    tr1 = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=0.25, perturb=False, force_all_rays=False, max_steps=256, T_thresh=1e-4)
+    m.eval()
+    with torch.no_grad():
+        ev = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4)
+        ev2 = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4, device_compaction=True)
+    assert np.array_equal(to_np(m.step_counter), g["rc_step_counter"])
+    for got, img, dep in ((tr0, "rc_train0_image", "rc_train0_depth"), (tr1, "rc_train1_image", "rc_train1_depth"), (ev, "rc_eval_image", "rc_eval_depth"),
+                          (ev2, "rc_eval_image", "rc_eval_depth")):
+        np.testing.assert_allclose(to_np(got["image"][0]), g[img], atol=1e-4, err_msg=img)
+        ok = np.isfinite(g[dep])
+        assert np.array_equal(np.isfinite(to_np(got["depth"][0])), ok), dep
+        np.testing.assert_allclose(to_np(got["depth"][0])[ok], g[dep][ok], atol=1e-4, err_msg=dep)
+    np.testing.assert_allclose(to_np(tr0["weights_sum"]), g["rc_train0_ws"], atol=1e-4)
+    assert (g["rc_train1_image"] != g["rc_train0_image"]).any(), "the second call used another background and dropped rays"
