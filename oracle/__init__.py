@@ -9,6 +9,7 @@ composite and trunc_exp are pinned by tests/golden/.
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -19,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 def build(force=False):
     src = os.path.join(_HERE, "oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=sys.stderr)       # never onto stdout: bench.py prints exactly one JSON line there
     return LIB_PATH
 
 
