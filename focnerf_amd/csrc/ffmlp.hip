@@ -179,7 +179,7 @@ __device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t 
 
 // ---------------------------------------------------------------- M1: fused forward / inference
 template <int HIDDEN, int NB, bool TRAIN, bool PLANAR>
-__global__ void __launch_bounds__(MLP_BLOCK) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
+__global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
                                                        _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
                                                        uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
