@@ -11,6 +11,7 @@ write them (`foc_ffmlp_forward_planar`, `foc_ffmlp_backward_planar`), so neither
 Used by NeRFNetwork (fused head) and render_fixed_steps; FOC_FUSED_FIELD=0 restores the two separate nodes.
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -33,15 +34,18 @@ _half_cache = {}
 
 def _half_of(param):
     """fp16 copy of a parameter, reused while the parameter is unchanged (tensor version counter): a render evaluates the same table
-    and weights for every ray chunk, and the reference converts the 50 MB table on every call (grid.py:41-44)."""
+    and weights for every ray chunk, and the reference converts the 50 MB table on every call (grid.py:41-44). Entries die with
+    their parameter (weak references)."""
     if param.dtype == torch.half:
         return param.contiguous()
     key = id(param)
     hit = _half_cache.get(key)
-    if hit is not None and hit[0] is param and hit[1] == param._version and hit[2].device == param.device:
+    if hit is not None and hit[0]() is param and hit[1] == param._version and hit[2].device == param.device:
         return hit[2]
+    for k in [k for k, v in _half_cache.items() if v[0]() is None]:
+        del _half_cache[k]
     h = param.detach().to(torch.half).contiguous()
-    _half_cache[key] = (param, param._version, h)
+    _half_cache[key] = (weakref.ref(param), param._version, h)
     return h
 
 
