@@ -50,6 +50,7 @@ SIGNATURES = {
     "foc_grid_encode_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
                                        u32, i32, u32, i32, i32, c_vp, c_vp]),
     "foc_grid_encode_backward_workspace_bytes": (u64, [u32, u32, u32, u32, i32]),
+    "foc_grid_planes_to_rows": (i32, [c_vp, c_vp, u32, u32, u32, c_vp]),
     "foc_grid_encode_backward_binned": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
                                               u32, i32, u32, i32, i32, c_vp, c_vp, u64, c_vp]),
     "foc_grad_total_variation": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, c_vp]),

@@ -145,6 +145,11 @@ class _gridencoder:
         check(fn(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype, int(bool(align_corners)),
                  interp, dt, None, stream_of(inputs)), "grid_encode_forward")
 
+    @staticmethod
+    def planes_to_rows(planes, rows, B, L, unit_bytes):
+        require_cuda(planes, rows); _contig(planes, rows)
+        check(lib.foc_grid_planes_to_rows(ptr(planes), ptr(rows), B, L, unit_bytes, stream_of(planes)), "grid_planes_to_rows")
+
     _offsets_host = {}
 
     @staticmethod

@@ -934,6 +934,19 @@ __global__ void __launch_bounds__(256) k_grad_tv(const T *__restrict__ inputs, c
 }
 
 // ================================================================= host side
+// [L, B] units -> [B, L] units (a unit = the C features of one (point, level): 4 or 8 bytes). Thread = point: L coalesced plane reads,
+// one contiguous row store. Lets the public [B, L*C] op use the level-major forward kernel (0.39 vs 0.74 ms per 2 M random points).
+template <typename U>
+__global__ void __launch_bounds__(256) k_planes_to_rows(const U *__restrict__ planes, U *__restrict__ rows, uint32_t B, uint32_t L) {
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        U v[GE_MAX_LEVELS];
+#pragma unroll
+        for (uint32_t l = 0; l < GE_MAX_LEVELS; l++) if (l < L) v[l] = planes[(uint64_t)l * B + b];
+#pragma unroll
+        for (uint32_t l = 0; l < GE_MAX_LEVELS; l++) if (l < L) rows[(uint64_t)b * L + l] = v[l];
+    }
+}
+
 static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
     if (L > GE_MAX_LEVELS) return 1;
     for (uint32_t l = 0; l < L; l++) {
@@ -1112,6 +1125,17 @@ int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, cons
                                uint32_t interp, int dtype, const int32_t *offsets_host, void *stream) {
     (void)offsets_host;
     return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, true, stream);
+}
+
+int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream) {
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(planes && rows, FOC_E_INVALID, "grid_planes_to_rows: null pointer");
+    FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && (unit_bytes == 4 || unit_bytes == 8), FOC_E_INVALID, "grid_planes_to_rows: L in [1,%d], 4- or 8-byte units", GE_MAX_LEVELS);
+    hipStream_t st = (hipStream_t)stream;
+    if (unit_bytes == 4) hipLaunchKernelGGL((k_planes_to_rows<uint32_t>), dim3(foc_grid_1d(B, 256)), dim3(256), 0, st, (const uint32_t *)planes, (uint32_t *)rows, B, L);
+    else hipLaunchKernelGGL((k_planes_to_rows<uint2>), dim3(foc_grid_1d(B, 256)), dim3(256), 0, st, (const uint2 *)planes, (uint2 *)rows, B, L);
+    FOC_CHECK_LAUNCH("grid_planes_to_rows");
+    return FOC_OK;
 }
 
 int foc_grid_encode_backward(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,

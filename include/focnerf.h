@@ -158,6 +158,9 @@ int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, cons
                                float S, uint32_t H, void *dy_dx, uint32_t gridtype,
                                int align_corners, uint32_t interp, int dtype,
                                const int32_t *offsets_host, void *stream);
+/* [L,B,C] -> [B,L*C] for C * sizeof(element) = unit_bytes in {4, 8}: the permute + copy of grid.py:57 as one kernel, so that
+ * the [B,L*C] result can come from the level-major forward kernel (faster than the point-major one on incoherent points). */
+int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream);
 
 /* gridencoder.cu:473-503  grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings,
  *       B, D, C, L, S, H, dy_dx?, grad_inputs?, gridtype, align_corners, interp)
