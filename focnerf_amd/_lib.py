@@ -76,6 +76,7 @@ SIGNATURES = {
     "foc_fixed_composite_backward": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_sample_head_forward": (i32, [c_vp, c_vp, u64, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_sample_head_backward": (i32, [c_vp, c_vp, c_vp, u64, c_vp, u32, c_vp]),
+    "foc_sh_encode": (i32, [c_vp, u64, c_vp, c_vp]),
     "foc_rgb_head_forward": (i32, [c_vp, u64, c_vp, c_vp]),
     "foc_rgb_head_backward": (i32, [c_vp, c_vp, u64, c_vp, c_vp]),
     "foc_fixed_render_inference": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp]),

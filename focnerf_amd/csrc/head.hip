@@ -116,7 +116,26 @@ __global__ void __launch_bounds__(256) k_rgb_bwd(const _Float16 *__restrict__ c,
     }
 }
 
+// dirs [M,3] fp32 -> SH degree 4 [M,16] fp32 (the module encoding.get_encoder('sphere_harmonics') returns; 17 torch kernels as an expression)
+__global__ void __launch_bounds__(256) k_sh_encode(const float *__restrict__ dirs, uint64_t M, float *__restrict__ out) {
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < M; s += (uint64_t)gridDim.x * 256) {
+        float sh[16];
+        hd_sh16(dirs[s * 3], dirs[s * 3 + 1], dirs[s * 3 + 2], sh);
+        float4 *dst = reinterpret_cast<float4 *>(out + s * 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[k] = make_float4(sh[4 * k], sh[4 * k + 1], sh[4 * k + 2], sh[4 * k + 3]);
+    }
+}
+
 extern "C" {
+
+int foc_sh_encode(const float *dirs, uint64_t M, float *out, void *stream) {
+    if (M == 0) return FOC_OK;
+    FOC_REQUIRE(dirs && out, FOC_E_INVALID, "sh_encode: null pointer");
+    hipLaunchKernelGGL(k_sh_encode, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, dirs, M, out);
+    FOC_CHECK_LAUNCH("sh_encode");
+    return FOC_OK;
+}
 
 int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, const void *obj_feat, uint32_t cin_width, void *stream) {
     if (M == 0) return FOC_OK;

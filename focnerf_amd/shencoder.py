@@ -46,4 +46,12 @@ class SHEncoder(nn.Module):
         return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
 
     def forward(self, inputs, **kwargs):
-        return sh_encode_deg4(inputs.float())
+        inputs = inputs.float()
+        if inputs.is_cuda and not (inputs.requires_grad and torch.is_grad_enabled()):
+            # one kernel (csrc/head.hip, same expressions) instead of 17; directions carry no gradient in the NeRF networks
+            from ._lib import lib, ptr, stream_of, check
+            flat = inputs.contiguous().view(-1, 3)
+            out = torch.empty(flat.shape[0], 16, dtype=torch.float32, device=inputs.device)
+            check(lib.foc_sh_encode(ptr(flat), flat.shape[0], ptr(out), stream_of(flat)), "sh_encode")
+            return out.view(*inputs.shape[:-1], 16)
+        return sh_encode_deg4(inputs)

@@ -370,6 +370,9 @@ int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float 
  * (column 0: grad_sigma * exp(clamp(h0,-15,15)), activation.py:16-18; columns 1..15: grad_cin[:,16:31]). */
 int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M,
                              void *grad_h, uint32_t cin_width, void *stream);
+/* Degree-4 real spherical harmonics of dirs [M,3] fp32 -> out [M,16] fp32: the direction encoder the reference imports as
+ * encoding.get_encoder('sphere_harmonics') (network_ff.py:43) but does not ship. */
+int foc_sh_encode(const float *dirs, uint64_t M, float *out, void *stream);
 /* c [M,16] fp16 = colour-net output -> rgb [M,3] fp32 = sigmoid(c[:, :3]) rounded to fp16 (network_ff.py:73). */
 int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream);
 /* grad_rgb [M,3] fp32 -> grad_c [M,16] fp16 (columns 3..15 zero). */

@@ -219,3 +219,15 @@ def test_fused_inference_kernel_matches_separate_kernels(layers, M, monkeypatch)
             assert (a - b).abs().max().item() <= 4.9e-4 and ((a - b).abs() > 0).float().mean().item() < 1e-3
         else:   # same weights, summed over the ray in a different association
             assert torch.allclose(a, b, atol=2e-5, rtol=0, equal_nan=True), (k, (a - b).abs().max())
+
+
+def test_sh_encoder_kernel_matches_expression():
+    from focnerf_amd.shencoder import SHEncoder, sh_encode_deg4
+    enc = SHEncoder()
+    d = torch.nn.functional.normalize(torch.randn(7, 333, 3, device="cuda"), dim=-1)
+    got = enc(d)
+    assert got.shape == (7, 333, 16) and got.dtype == torch.float32
+    assert torch.allclose(got, sh_encode_deg4(d), rtol=2e-6, atol=1e-7)
+    dg = d.clone().requires_grad_(True)
+    enc(dg).sum().backward()                                   # differentiable form still available
+    assert dg.grad is not None and torch.isfinite(dg.grad).all()
