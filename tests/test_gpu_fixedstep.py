@@ -198,3 +198,40 @@ def test_whole_step_replays_as_a_hip_graph():
     assert np.allclose(got, eager, rtol=2e-2, atol=1e-4), (got, eager)
     assert torch.allclose(m_g.sigma_net.weights, m_e.sigma_net.weights, atol=2e-3)
     assert not torch.equal(m_g.sigma_net.weights, make()[0].sigma_net.weights), "the replayed steps did update the parameters"
+
+
+def test_amp_overflow_steps_are_detected_and_skipped():
+    """A GradScaler that starts far too high overflows the fp16 gradients of the first steps. The inf/NaN must reach the parameter
+    gradients (the binned grid backward has no encoding for them in its fixed-point sums and poisons the rows instead), so that the
+    scaler skips those steps and backs off; the parameters stay finite and training proceeds once the scale is sane."""
+    from focnerf_amd import synthetic
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    m = NeRFNetwork(bound=1).cuda().train()
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, backoff_factor=1.0 / 65536.0, growth_interval=10 ** 6)
+    gen = torch.Generator().manual_seed(0)
+    poses = synthetic.rand_poses(1, "cuda", radius=2.0, generator=gen)
+    ro, rd = synthetic.get_rays(poses, synthetic.intrinsics(32, 32), 32, 32)
+    target = torch.rand(1, ro.shape[1], 3, generator=gen).cuda()
+    before = [p.detach().clone() for p in m.parameters()]
+    scales, losses = [], []
+    for it in range(6):
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = m.run(ro, rd, None, fused=True, num_steps=64, upsample_steps=0, bg_color=1.0, perturb=False)
+            loss = torch.nn.functional.mse_loss(out["image"], target)
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        if it == 0:
+            assert not all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None), "the overflow must be visible in the gradients"
+            assert not torch.isfinite(m.encoder.embeddings.grad).all(), "in the hash-table gradient too"
+        scaler.step(opt)
+        scaler.update()
+        scales.append(scaler.get_scale())
+        losses.append(loss.item())
+        if it == 0:
+            assert all(torch.equal(a, b) for a, b in zip(before, m.parameters())), "an overflowed step must not touch the parameters"
+    assert scales[0] < 2.0 ** 40 and scales[-1] <= scales[0]
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(before, m.parameters())), "later steps did train"
+    assert np.isfinite(losses).all()
