@@ -72,6 +72,34 @@ __device__ __forceinline__ h8 ld_planar8(const _Float16 *__restrict__ base, uint
     return __builtin_bit_cast(h8, v);
 }
 
+// Colour-network inputs taken from where they already are (input mode 2, in_dim = 32): the row [SH16(ray) | h[1:16] | 0] the
+// reference concatenates per sample (network_ff.py:104-108) is never materialised. k-chunk 0 = the ray's 16 SH values (one 32-byte
+// row per ray, shared by its samples); k-chunk 1 = columns 1..16 of the sigma network's output row h [B,16], i.e. the row shifted by
+// one half with a zero shifted in at the end — every value sits at the k position it has in the concatenated row, so the
+// products and their summation order are those of the materialised form.
+struct MlpHead {
+    const _Float16 *ray_sh;        // [B / samples_per_ray, 16]
+    const _Float16 *grad_h0;       // backward: [B], gradient of h[:,0] (the density path), merged into grad_h column 0
+    uint32_t samples_per_ray;
+};
+// the loads and the shift are separate so that a prefetching caller can keep the raw dwords in flight
+__device__ __forceinline__ void ld_head_raw(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(hrows + row * 16) + 4 * h;
+    v = *reinterpret_cast<const u32x4 *>(p);
+    nxt = h == 0 ? p[4] : 0u;
+}
+__device__ __forceinline__ h8 head_shift(const u32x4 v, uint32_t nxt) {
+    const u32x4 r = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16), __builtin_amdgcn_alignbit(v.w, v.z, 16),
+                     __builtin_amdgcn_alignbit(nxt, v.w, 16)};
+    return __builtin_bit_cast(h8, r);
+}
+__device__ __forceinline__ h8 ld_head8(const _Float16 *__restrict__ hrows, const MlpHead &hd, uint64_t row, uint32_t kc, int h) {
+    if (kc == 0) return *reinterpret_cast<const h8 *>(hd.ray_sh + (uint64_t)((uint32_t)row / hd.samples_per_ray) * 16 + 8 * h);
+    u32x4 v; uint32_t nxt;
+    ld_head_raw(hrows, row, h, v, nxt);
+    return head_shift(v, nxt);
+}
+
 // ---------------------------------------------------------------- weight staging
 // Forward image. Fragment f holds, for lane (r = lane&31, h = lane>>5), the 8 halfs
 //   layer 0      : W0[32*mt + r][16*kc + 8*h + j]                       (natural k: B comes from global inputs)
@@ -120,7 +148,7 @@ __device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds,
 //   dX          [mt0][kc]   : W0[chain_k(kc,h,j)][32*mt0 + r]  (i < in_dim, else 0)
 // Fragment order: out [mt] | hidden [l][mt][kc] | dX [mt0][kc].
 template <int HIDDEN>
-__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx, bool head = false) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t no = MT, nh = (num_layers - 1) * MT * KC, nx = with_dx ? MT0 * KC : 0, total = no + nh + nx;
@@ -145,7 +173,13 @@ __device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds,
             }
         } else {
             const uint32_t g = f - no - nh, mt0 = g / KC, kc = g % KC, i = 32 * mt0 + r;
-            if (i < in_dim) {
+            if (head) {
+                // input mode 2: result row 16 + k is the gradient of h column k = input column 15 + k (k = 1..15); rows 0..16 are not used
+                if (i >= 17 && i < 32) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * in_dim + (i - 1)];
+                }
+            } else if (i < in_dim) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * in_dim + i];
             }
@@ -178,12 +212,12 @@ __device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t 
 }
 
 // ---------------------------------------------------------------- M1: fused forward / inference
-template <int HIDDEN, int NB, bool TRAIN, bool PLANAR>
+template <int HIDDEN, int NB, bool TRAIN, int IMODE>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
                                                        _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
-                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu) {
+                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu, MlpHead hd) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
-    constexpr bool planar = PLANAR;
+    constexpr bool planar = IMODE == 1;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
     __syncthreads();
@@ -211,7 +245,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
                 const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
-                b[nb] = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
+                if constexpr (IMODE == 2) b[nb] = ld_head8(inputs, hd, row, kc, h);
+                else b[nb] = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -504,17 +539,18 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
 // where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
 // and input rows are fetched while the current group is processed.
-template <int HIDDEN, int NL, int NB, bool RECOMP, bool PLANAR>
+template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
-                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs) {
+                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs, MlpHead hd) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
-    constexpr bool planar = PLANAR;
+    constexpr bool planar = IMODE == 1;
+    static_assert(IMODE != 2 || RECOMP, "input mode 2 has no stored-activation form");
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const bool with_dx = grad_inputs != nullptr;
-    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx);
+    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx, IMODE == 2);
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
     _Float16 *sD = lds + lds_w_halfs;                    // [4][RW][WD]
     _Float16 *sA = sD + 4 * RW * WD;                     // [4][RW][WA]
@@ -542,8 +578,17 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     // RECOMP: this wave's grad rows (D_0 tile order) and input rows (layer-0 B operand order) of the group about to be processed
     h8 g_nxt[(RW * 2 + 63) / 64];
     h8 x_nxt[KS0M][NB];
+    _Float16 h0_nxt[NB];                                 // input mode 2: the density path's gradient of h[:,0] for this lane's rows
+    uint32_t hx_nxt[NB];                                 // input mode 2: the dword after the lane's 16 bytes of its h row
     auto fetch_group = [&](uint32_t grp) {
         const uint64_t r0 = (uint64_t)grp * rows_per_group + wave * RW;
+        if constexpr (IMODE == 2) {
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const uint64_t row = r0 + nb * 32 + c;
+                h0_nxt[nb] = (hd.grad_h0 && row < B) ? hd.grad_h0[row] : (_Float16)0;
+            }
+        }
 #pragma unroll
         for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
             const uint32_t idx = lane + 64 * it, rr = idx >> 1, cc = (idx & 1) * 8;
@@ -558,7 +603,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                 h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if ((uint32_t)kc < KS0) {
                     const uint64_t row = min(r0 + nb * 32 + c, (uint64_t)B - 1);
-                    v = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
+                    if constexpr (IMODE == 2) {
+                        if (kc == 0) v = ld_head8(inputs, hd, row, 0, h);
+                        else { u32x4 raw; ld_head_raw(inputs, row, h, raw, hx_nxt[nb]); v = __builtin_bit_cast(h8, raw); }   // shifted when it becomes x_cur
+                    } else v = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
                 }
                 x_nxt[kc][nb] = v;
             }
@@ -571,6 +619,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
         h8 fa[RECOMP ? NL : 1][KC][NB];                  // RECOMP: post-activation of forward layer l, chained layout
         h8 g_cur[(RW * 2 + 63) / 64];
         h8 x_cur[KS0M][NB];
+        _Float16 h0_cur[NB];
+        if constexpr (IMODE == 2) {
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) h0_cur[nb] = h0_nxt[nb];
+        }
         if constexpr (RECOMP) {
 #pragma unroll
             for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) g_cur[it] = g_nxt[it];
@@ -578,6 +631,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             for (int kc = 0; kc < KS0M; kc++)
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) x_cur[kc][nb] = x_nxt[kc][nb];
+            if constexpr (IMODE == 2) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) x_cur[1][nb] = head_shift(__builtin_bit_cast(u32x4, x_nxt[1][nb]), hx_nxt[nb]);
+            }
             if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
 #pragma unroll
@@ -772,7 +829,17 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        if constexpr (RECOMP && PLANAR) {
+                        if constexpr (IMODE == 2) {
+                            // rows 16..31 of the tile = gradient of h columns 0..15 (staged shifted); column 0 comes from the density path
+                            const uint64_t row = row0 + nb * 32 + c;
+                            if (row < B) {
+                                h4 lo = {(_Float16)x[nb][8], (_Float16)x[nb][9], (_Float16)x[nb][10], (_Float16)x[nb][11]};
+                                const h4 hi = {(_Float16)x[nb][12], (_Float16)x[nb][13], (_Float16)x[nb][14], (_Float16)x[nb][15]};
+                                if (h == 0) lo[0] = h0_cur[nb];
+                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 4 * h) = lo;
+                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 8 + 4 * h) = hi;
+                            }
+                        } else if constexpr (RECOMP && IMODE == 1) {
                             // [in_dim/2][B] half2 planes (the encoder's [L,B,C] gradient layout): register quad q = features 32mt0 + 8q + 4h .. +3
                             const uint64_t row = row0 + nb * 32 + c;
                             if (row < B) {
@@ -1063,19 +1130,21 @@ static size_t mlp_bwd_lds(uint32_t in_dim, uint32_t num_layers, bool dx) {
 
 template <int HIDDEN, bool TRAIN>
 static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
-                          void *fwd_buf, void *outputs, int planar, hipStream_t st) {
+                          void *fwd_buf, void *outputs, int planar, hipStream_t st, const MlpHead *head = nullptr) {
     constexpr int NB = 2;
     const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     FOC_REQUIRE(!(planar && TRAIN), FOC_E_INVALID, "ffmlp_forward: planar inputs go with the activation-free forward");
-    auto kern = planar ? k_mlp_fwd<HIDDEN, NB, false, true> : k_mlp_fwd<HIDDEN, NB, TRAIN, false>;
+    auto kern = planar ? k_mlp_fwd<HIDDEN, NB, false, 1> : k_mlp_fwd<HIDDEN, NB, TRAIN, 0>;
+    if constexpr (HIDDEN == 64 && !TRAIN) { if (head) kern = k_mlp_fwd<HIDDEN, NB, false, 2>; }
+    else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_tiles = foc_div_up(B, 32 * NB);
     uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu);
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u});
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
@@ -1101,7 +1170,7 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
 
 template <int HIDDEN, int NL>
 static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, int relu,
-                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
+                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st, const MlpHead *head = nullptr) {
     FOC_REQUIRE(!planar || fwd_buf == nullptr, FOC_E_INVALID, "ffmlp_backward: planar inputs need the re-evaluating form (forward_buffer NULL)");
     constexpr int NB = 1, RW = 32 * NB, WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     const bool dx = grad_inputs != nullptr;
@@ -1111,8 +1180,10 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
-    auto kern = recomp ? (planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, false>)
-                       : k_mlp_bwd_fused<HIDDEN, NL, NB, false, false>;
+    auto kern = recomp ? (planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0>)
+                       : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0>;
+    if constexpr (HIDDEN == 64 && NL <= 3) { if (head) kern = k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2>; }
+    else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
     if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
@@ -1120,7 +1191,8 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const uint32_t cap = mlp_num_cus() * 2;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)));
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
+                       head ? *head : MlpHead{nullptr, nullptr, 1u});
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
     hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
     FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
@@ -1270,6 +1342,38 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
         case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
         default: foc_set_error("nerf_field_inference: layer counts (%u, %u) are not built (2/2, 2/3, 3/3)", sigma_layers, color_layers); return FOC_E_INVALID;
     }
+}
+
+// The colour network of the fixed-step training path, fed from the sigma network's output rows and a per-ray SH table (input mode 2).
+int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights, uint32_t B, uint32_t hidden_dim,
+                           uint32_t num_layers, uint32_t activation, void *outputs, void *stream) {
+    int rc = mlp_check("color_head_forward", B, 32, 16, hidden_dim, num_layers, activation, 6);
+    if (rc) return rc;
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(h && ray_sh && weights && outputs, FOC_E_INVALID, "color_head_forward: null pointer");
+    FOC_REQUIRE(hidden_dim == 64 && samples_per_ray >= 1, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64 (got %u), samples_per_ray >= 1", hidden_dim);
+    const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray};
+    return mlp_fwd_launch<64, false>(h, weights, B, 32, num_layers, activation == 0, nullptr, outputs, 0, (hipStream_t)stream, &hd);
+}
+
+int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
+                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
+                            void *stream) {
+    int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
+    if (rc) return rc;
+    FOC_REQUIRE(hidden_dim == 64 && (num_layers == 2 || num_layers == 3) && samples_per_ray >= 1, FOC_E_INVALID,
+                "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3 (got %u, %u)", hidden_dim, num_layers);
+    if (B == 0) {
+        FOC_REQUIRE(grad_weights, FOC_E_INVALID, "color_head_backward: null pointer");
+        const size_t n_w = (size_t)64 * (32 + (size_t)64 * (num_layers - 1) + 16);
+        if (hipMemsetAsync(grad_weights, 0, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("color_head_backward: memset failed"); return FOC_E_LAUNCH; }
+        return FOC_OK;
+    }
+    FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");
+    const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray};
+    const int relu = activation == 0;
+    if (num_layers == 2) return mlp_bwd_fused_launch<64, 2>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);
+    return mlp_bwd_fused_launch<64, 3>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);
 }
 
 int foc_allocate_splitk(uint64_t size) { (void)size; return FOC_OK; }

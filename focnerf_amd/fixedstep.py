@@ -50,7 +50,7 @@ class _density_head(Function):
             assert obj_feat.numel() == 16
         cin = torch.empty(M, width, dtype=torch.float16, device=dev)
         check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
-                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), ptr(obj_feat), width, stream_of(h)), "fixed_head_forward")
+                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), ptr(obj_feat), width, None, stream_of(h)), "fixed_head_forward")
         ctx.save_for_backward(h, sigma, trans, nears, fars, noise if noise is not None else torch.empty(0, device=dev))
         ctx.has_noise = noise is not None
         ctx.dims = (N, T, float(density_scale))
@@ -69,7 +69,7 @@ class _density_head(Function):
         g_cin = g_cin.contiguous().half() if g_cin is not None else None
         grad_h = torch.empty_like(h)
         check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(g_weights), ptr(g_ws), ptr(g_depth),
-                                          ptr(g_cin), N, T, ds, ptr(grad_h), ctx.width, stream_of(h)), "fixed_head_backward")
+                                          ptr(g_cin), N, T, ds, ptr(grad_h), ctx.width, None, stream_of(h)), "fixed_head_backward")
         g_obj = None
         if ctx.width == 48 and ctx.needs_input_grad[8] and g_cin is not None:
             g_obj = g_cin[:, 31:47].float().sum(0)                 # one feature vector feeds every sample
@@ -103,6 +103,83 @@ class _fixed_composite(Function):
         check(lib.foc_fixed_composite_backward(ptr(g_image), ptr(c), ptr(weights), ptr(bg_ray), bg_scalar, N, T, thresh, ptr(grad_c), ptr(grad_w),
                                                stream_of(c)), "fixed_composite_backward")
         return grad_c, grad_w, None, None, None, None, None
+
+
+def tail_fusable(model):
+    """Shapes `_render_tail` serves: 16-wide sigma head, degree-4 SH, 64-wide colour network of 2 or 3 layers, no object feature."""
+    import os
+    from .ffmlp import FFMLP
+    from .shencoder import SHEncoder
+    cn = getattr(model, "color_net", None)
+    return (isinstance(cn, FFMLP) and cn.input_dim == 32 and cn.hidden_dim == 64 and cn.num_layers in (2, 3) and cn.padded_output_dim == 16
+            and isinstance(getattr(model, "encoder_dir", None), SHEncoder) and getattr(model, "geo_feat_dim", 0) == 15
+            and not getattr(model, "uses_object_feature", False) and os.environ.get("FOC_FUSED_TAIL", "1") != "0")
+
+
+class _render_tail(Function):
+    """Density head -> colour network -> composite as ONE node: h [M,16] half + the colour network's weight blob ->
+    image [N,3], weights_sum [N], depth [N] (+ sigma [M], weights [M], c [M,16], not differentiable).
+
+    Same values and gradients as `_density_head` -> `FFMLP.forward_padded` -> `_fixed_composite`, bit for bit, without the colour
+    network's input: its kernels read h and one SH row per ray (foc_color_head_forward), and in the backward pass the colour
+    network writes grad_h itself — its input gradient for columns 1..15 merged with the density path's column 0 — so neither
+    cin [M,32] nor grad_cin [M,32] exists (0.5 GB of traffic per 2 M-sample step)."""
+
+    @staticmethod
+    def forward(ctx, h, cweights, rays_d, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation):
+        from .field import _half_of
+        h = h.contiguous()
+        assert h.dtype == torch.float16 and h.shape == (N * T, 16)
+        dev, M = h.device, N * T
+        st = stream_of(h)
+        w16 = _half_of(cweights)
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        trans = torch.empty(M, dtype=torch.float32, device=dev)
+        weights = torch.empty(M, dtype=torch.float32, device=dev)
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        ray_sh = torch.empty(N, 16, dtype=torch.float16, device=dev)
+        check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
+                                         ptr(weights), ptr(ws), ptr(depth), None, None, 32, ptr(ray_sh), st), "fixed_head_forward")
+        c = torch.empty(M, 16, dtype=torch.float16, device=dev)
+        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), st), "color_head_forward")
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        check(lib.foc_fixed_composite_forward(ptr(c), ptr(weights), ptr(bg_ray), float(bg_scalar), N, T, float(thresh), ptr(image), st),
+              "fixed_composite_forward")
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise if noise is not None else empty,
+                              bg_ray if bg_ray is not None else empty)
+        ctx.flags = (noise is not None, bg_ray is not None)
+        ctx.dims = (N, T, float(density_scale), float(thresh), float(bg_scalar), int(num_layers), int(activation))
+        ctx.mark_non_differentiable(sigma, weights, c)
+        return image, ws, depth, sigma, weights, c
+
+    @staticmethod
+    def backward(ctx, g_image, g_ws, g_depth, _g_sigma, _g_weights, _g_c):
+        from .backend import _scratch
+        h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise, bg_ray = ctx.saved_tensors
+        has_noise, has_bg = ctx.flags
+        N, T, ds, thresh, bg_scalar, num_layers, activation = ctx.dims
+        noise = noise if has_noise else None
+        bg_ray = bg_ray if has_bg else None
+        dev, M = h.device, N * T
+        st = stream_of(h)
+        g_image = g_image.contiguous().float() if g_image is not None else torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        g_ws = g_ws.contiguous().float() if g_ws is not None else None
+        g_depth = g_depth.contiguous().float() if g_depth is not None else None
+        grad_c = torch.empty_like(c)
+        grad_w = torch.empty_like(weights)
+        check(lib.foc_fixed_composite_backward(ptr(g_image), ptr(c), ptr(weights), ptr(bg_ray), bg_scalar, N, T, thresh, ptr(grad_c), ptr(grad_w), st),
+              "fixed_composite_backward")
+        grad_h0 = torch.empty(M, dtype=torch.float16, device=dev)
+        check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(grad_w), ptr(g_ws), ptr(g_depth),
+                                          None, N, T, ds, None, 32, ptr(grad_h0), st), "fixed_head_backward")
+        grad_h = torch.empty_like(h)
+        g_w = torch.empty_like(w16)
+        wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(32, 64, num_layers), dev)
+        check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
+                                          ptr(g_w), ptr(wsb), st), "color_head_backward")
+        return (grad_h, g_w) + (None,) * 12
 
 
 def _background(bg_color, N, dev):
@@ -173,16 +250,25 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         obj_feat = None
         if getattr(model, "uses_object_feature", False):                  # FOC network (network_foc.py): encoded YOLO feature in the colour input
             obj_feat = model.encode_object_feature(yolo_details, dev)
-        weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale, obj_feat)
+        fused_tail = tail_fusable(model) and obj_feat is None and model.training and torch.is_grad_enabled()
+        if fused_tail:
+            cn = model.color_net
+            bg_ray, bg_scalar = _background(bg_color, N, dev)
+            image, weights_sum, depth, sigma, weights, c = _render_tail.apply(h, cn.weights, rays_d, nears, fars, noise, bg_ray, bg_scalar, N, T,
+                                                                              model.density_scale, weight_thresh, cn.num_layers, cn.activation)
+        else:
+            weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale, obj_feat)
         criterion_outside_mask = None
         if model.training and yolo_details is not None:                   # nerf/renderer.py:163-165
             from .activation import trunc_exp
             criterion_outside_mask = torch.norm(trunc_exp(h[:, 0]).view(N, T)[~yolo_details[0].squeeze(0)] - 0)
-        c = model.color_net.forward_padded(cin)                            # [M,16] half, columns 0..2 = rgb logits
+        if not fused_tail:
+            c = model.color_net.forward_padded(cin)                        # [M,16] half, columns 0..2 = rgb logits
     t_mid = time.time()
 
-    bg_ray, bg_scalar = _background(bg_color, N, dev)
-    image = _fixed_composite.apply(c, weights, bg_ray, bg_scalar, N, T, weight_thresh)
+    if not fused_tail:
+        bg_ray, bg_scalar = _background(bg_color, N, dev)
+        image = _fixed_composite.apply(c, weights, bg_ray, bg_scalar, N, T, weight_thresh)
 
     results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum,
                'criterion_outside_mask': criterion_outside_mask, 'timing': [t_mid - t_start, time.time() - t_mid]}
