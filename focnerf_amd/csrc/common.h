@@ -42,6 +42,11 @@ static inline uint32_t foc_grid_1d(uint64_t n, uint32_t block, uint32_t max_bloc
     return (uint32_t)g;
 }
 
+// fp32 -> fp16 of a value that was ROUNDED TO fp32 first, as a torch `.half()` of an fp32 tensor is. Without the barrier the
+// compiler folds a preceding multiply into v_fma_mixlo_f16 (one rounding of the exact product, even with -ffp-contract=off),
+// which differs from the two-step rounding in about one value in 2^13.
+__device__ __forceinline__ _Float16 foc_f2h(float v) { asm volatile("" : "+v"(v)); return (_Float16)v; }
+
 // wave64 reductions / scans via DPP-backed shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -62,7 +62,8 @@ __device__ __forceinline__ void fs_sh16(float x, float y, float z, float (&o)[16
 // ---------------------------------------------------------------- sample generation
 __global__ void __launch_bounds__(256) k_fs_sample(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
                                                    const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
-                                                   uint32_t N, uint32_t T, float bound, float *__restrict__ xyzs, float *__restrict__ enc_in) {
+                                                   uint32_t N, uint32_t T, float bound, float *__restrict__ xyzs, float *__restrict__ enc_in,
+                                                   _Float16 *__restrict__ ray_sh) {
     const uint64_t total = (uint64_t)N * T;
     const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
     const float two_b = 2 * bound;
@@ -75,6 +76,15 @@ __global__ void __launch_bounds__(256) k_fs_sample(const float *__restrict__ ray
         x = fminf(fmaxf(x, a0), a3); y = fminf(fmaxf(y, a1), a4); w = fminf(fmaxf(w, a2), a5);
         if (xyzs) { xyzs[s * 3] = x; xyzs[s * 3 + 1] = y; xyzs[s * 3 + 2] = w; }
         if (enc_in) { enc_in[s * 3] = (x + bound) / two_b; enc_in[s * 3 + 1] = (y + bound) / two_b; enc_in[s * 3 + 2] = (w + bound) / two_b; }
+        if (ray_sh && i == 0) {                            // the ray's SH row as it stands in the colour-net input (fp16), once per ray
+            float sh[16];
+            fs_sh16(rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], sh);
+            h8 lo, hi;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { lo[k] = foc_f2h(sh[k]); hi[k] = foc_f2h(sh[8 + k]); }
+            h8 *dst = reinterpret_cast<h8 *>(ray_sh + (uint64_t)n * 16);
+            dst[0] = lo; dst[1] = hi;
+        }
     }
 }
 
@@ -98,7 +108,7 @@ __global__ void __launch_bounds__(256) k_fs_head_fwd(const _Float16 *__restrict_
         float sh[16];
         fs_sh16(rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], sh);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { shlo[k] = (_Float16)sh[k]; shhi[k] = (_Float16)sh[8 + k]; }
+        for (int k = 0; k < 8; k++) { shlo[k] = foc_f2h(sh[k]); shhi[k] = foc_f2h(sh[8 + k]); }
         if (ray_sh && lane == 0) { h8 *dst = reinterpret_cast<h8 *>(ray_sh + (uint64_t)n * 16); dst[0] = shlo; dst[1] = shhi; }
         if (obj) {
             ob0 = obj[0];
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(256) k_fs_head_bwd(const _Float16 *__restrict_
         const float dsigma = dalpha * (delta * density_scale) * ex;
         const _Float16 h0 = h[s * 16];
         const float dh0 = dsigma * expf(fminf(fmaxf((float)h0, -15.0f), 15.0f));   // trunc_exp backward (activation.py:15)
-        if (valid && grad_h0) grad_h0[s] = (_Float16)dh0;          // column 0 only: the colour network's backward writes the row (foc_color_head_backward)
+        if (valid && grad_h0) grad_h0[s] = foc_f2h(dh0);          // column 0 only: the colour network's backward writes the row (foc_color_head_backward)
         else if (valid) {
             h8 o0, o1;
             if (grad_cin) {
@@ -207,7 +217,7 @@ __global__ void __launch_bounds__(256) k_fs_head_bwd(const _Float16 *__restrict_
 #pragma unroll
                 for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
             }
-            o0[0] = (_Float16)dh0;
+            o0[0] = foc_f2h(dh0);
             h8 *dst = reinterpret_cast<h8 *>(grad_h + s * 16);
             dst[0] = o0; dst[1] = o1;
         }
@@ -263,11 +273,121 @@ __global__ void __launch_bounds__(256) k_fs_composite_bwd(const float *__restric
             const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
             const float y0 = fs_sigmoid_h((float)cc[0]), y1 = fs_sigmoid_h((float)cc[1]), y2 = fs_sigmoid_h((float)cc[2]);
             gw += g0 * y0 + g1 * y1 + g2 * y2;
-            o0[0] = (_Float16)(g0 * w * y0 * (1 - y0)); o0[1] = (_Float16)(g1 * w * y1 * (1 - y1)); o0[2] = (_Float16)(g2 * w * y2 * (1 - y2));
+            o0[0] = foc_f2h(g0 * w * y0 * (1 - y0)); o0[1] = foc_f2h(g1 * w * y1 * (1 - y1)); o0[2] = foc_f2h(g2 * w * y2 * (1 - y2));
         }
         grad_w[s] = gw;
         h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16);
         dst[0] = o0; dst[1] = o1;
+    }
+}
+
+// ---------------------------------------------------------------- training tail: density head + composite in one pass per direction
+// What k_fs_head_fwd (without the colour-net input) and k_fs_composite_fwd compute, one wave per ray, with the same per-lane
+// accumulation order, so the results are the same bits; the weights are not re-read. c [M,16] fp16 = colour-net output.
+__global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict__ h, const _Float16 *__restrict__ c, const float *__restrict__ nears,
+                                                     const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
+                                                     float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
+                                                     float *__restrict__ sigma_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
+                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const FsGeom g = fs_geom(nears, fars, n, T);
+    float Tc = 1.0f, ws = 0, dp = 0, r = 0, gg = 0, b = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < T;
+        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const float sigma = expf((float)h[s * 16]);                             // trunc_exp forward (activation.py:9)
+        const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float delta = g.sample_dist;
+        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
+        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float Tb = Tc * Pex;
+        const float w = alpha * Tb;
+        if (valid) {
+            sigma_out[s] = sigma; trans_out[s] = Tb; weights_out[s] = w;
+            float oz = (z - g.near) / g.span;
+            oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
+            ws += w; dp += w * oz;
+            if (w > thresh) {
+                const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
+                r += w * fs_sigmoid_h((float)cc[0]); gg += w * fs_sigmoid_h((float)cc[1]); b += w * fs_sigmoid_h((float)cc[2]);
+            }
+        }
+        Tc *= __shfl(P, 63, 64);
+    }
+    ws = wave_sum(ws); dp = wave_sum(dp); r = wave_sum(r); gg = wave_sum(gg); b = wave_sum(b);
+    if (lane == 0) {
+        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+        image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
+        weights_sum[n] = ws; depth[n] = dp;
+    }
+}
+
+// a value the compiler cannot fold: exp(+-15) below must come out of the device's expf like every other exp of this file
+__device__ __forceinline__ float fs_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+
+// k_fs_composite_bwd and k_fs_head_bwd (column 0 only) in one pass: grad_image [N,3], grad_ws / grad_depth [N] (may be null)
+// -> grad_c [M,16] fp16 and grad_h0 [M] fp16. The gradient of the weights never leaves the lane. trunc_exp's backward factor
+// exp(clamp(h0, -15, 15)) is taken as clamp(sigma, exp(-15), exp(15)) — the same bits, expf being monotonic — so h is not read.
+__global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ grad_image, const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
+                                                     const _Float16 *__restrict__ c, const float *__restrict__ sigma_in, const float *__restrict__ trans_in,
+                                                     const float *__restrict__ weights, const float *__restrict__ nears, const float *__restrict__ fars,
+                                                     const float *__restrict__ noise, const float *__restrict__ bg_ray, float bg_scalar, uint32_t N, uint32_t T,
+                                                     float density_scale, float thresh, _Float16 *__restrict__ grad_c, _Float16 *__restrict__ grad_h0) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const FsGeom g = fs_geom(nears, fars, n, T);
+    const float gws = grad_ws ? grad_ws[n] : 0.0f, gdp = grad_depth ? grad_depth[n] : 0.0f;
+    const float g0 = grad_image[n * 3], g1 = grad_image[n * 3 + 1], g2 = grad_image[n * 3 + 2];
+    const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+    const float e_lo = expf(fs_opaque(-15.0f)), e_hi = expf(fs_opaque(15.0f));
+    float S_carry = 0.0f;
+    const uint32_t n_chunks = (T + 63) / 64;
+    for (uint32_t cidx = n_chunks; cidx-- > 0;) {
+        const uint32_t i = cidx * 64 + lane;
+        const bool valid = i < T;
+        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const float sigma = sigma_in[s], Tb = trans_in[s], w = weights[s];
+        // ---- composite backward (k_fs_composite_bwd)
+        float gw = -(g0 * b0 + g1 * b1 + g2 * b2);
+        h8 o0, o1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
+        if (w > thresh) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+            const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
+            const float y0 = fs_sigmoid_h((float)cc[0]), y1 = fs_sigmoid_h((float)cc[1]), y2 = fs_sigmoid_h((float)cc[2]);
+            gw += g0 * y0 + g1 * y1 + g2 * y2;
+            o0[0] = foc_f2h(g0 * w * y0 * (1 - y0)); o0[1] = foc_f2h(g1 * w * y1 * (1 - y1)); o0[2] = foc_f2h(g2 * w * y2 * (1 - y2));
+        }
+        if (valid) { h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16); dst[0] = o0; dst[1] = o1; }
+        // ---- density head backward (k_fs_head_bwd)
+        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float delta = g.sample_dist;
+        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        const float ex = expf((-delta * density_scale) * sigma);
+        const float alpha = 1 - ex;
+        const float om = 1 - alpha + 1e-15f;
+        float oz = (z - g.near) / g.span;
+        oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
+        float gi = gw + gws;
+        if (gdp != 0.0f) gi += gdp * oz;
+        const float gw_i = valid ? gi * (alpha * Tb) : 0.0f;
+        const float incl = wave_suffix_incl_sum(gw_i, (int)lane);
+        const float S_i = S_carry + (incl - gw_i);
+        const float dalpha = gi * Tb - S_i / om;
+        const float dsigma = dalpha * (delta * density_scale) * ex;
+        const float dh0 = dsigma * fminf(fmaxf(sigma, e_lo), e_hi);
+        if (valid) grad_h0[s] = foc_f2h(dh0);
+        S_carry += __shfl(incl, 0, 64);
     }
 }
 
@@ -323,12 +443,12 @@ __global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict
 extern "C" {
 
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
-                     uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *stream) {
+                     uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *ray_sh, void *stream) {
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && nears && fars && aabb && (xyzs || enc_in), FOC_E_INVALID, "fixed_sample: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_sample: T must be >= 2");
     hipLaunchKernelGGL(k_fs_sample, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars, aabb,
-                       noise, N, T, bound, xyzs, enc_in);
+                       noise, N, T, bound, xyzs, enc_in, (_Float16 *)ray_sh);
     FOC_CHECK_LAUNCH("fixed_sample");
     return FOC_OK;
 }
@@ -377,6 +497,30 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
     hipLaunchKernelGGL(k_fs_composite_bwd, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, grad_image,
                        (const _Float16 *)c, weights, bg_ray, bg_scalar, N, T, thresh, (_Float16 *)grad_c, grad_w);
     FOC_CHECK_LAUNCH("fixed_composite_backward");
+    return FOC_OK;
+}
+
+int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
+                           uint32_t N, uint32_t T, float density_scale, float thresh, float *sigma, float *trans, float *weights, float *weights_sum,
+                           float *depth, float *image, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(h && c && nears && fars && sigma && trans && weights && weights_sum && depth && image, FOC_E_INVALID, "fixed_tail_forward: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_forward: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_tail_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, (const _Float16 *)c, nears, fars, noise,
+                       bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image);
+    FOC_CHECK_LAUNCH("fixed_tail_forward");
+    return FOC_OK;
+}
+
+int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c, const float *sigma, const float *trans,
+                            const float *weights, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
+                            uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, void *stream) {
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(grad_image && c && sigma && trans && weights && nears && fars && grad_c && grad_h0, FOC_E_INVALID, "fixed_tail_backward: null pointer");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_backward: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_tail_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, grad_image, grad_ws, grad_depth, (const _Float16 *)c, sigma,
+                       trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0);
+    FOC_CHECK_LAUNCH("fixed_tail_backward");
     return FOC_OK;
 }
 

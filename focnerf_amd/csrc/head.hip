@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_head_fwd(const _Float16 *__restrict__ h
             hd_sh16(dirs[s * 3], dirs[s * 3 + 1], dirs[s * 3 + 2], sh);
             h8 c0, c1, c2, c3;
 #pragma unroll
-            for (int k = 0; k < 8; k++) { c0[k] = (_Float16)sh[k]; c1[k] = (_Float16)sh[8 + k]; }
+            for (int k = 0; k < 8; k++) { c0[k] = foc_f2h(sh[k]); c1[k] = foc_f2h(sh[8 + k]); }
 #pragma unroll
             for (int k = 0; k < 7; k++) { c2[k] = r0[k + 1]; c3[k] = r1[k + 1]; }
             c2[7] = r1[0]; c3[7] = ob0;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_head_bwd(const _Float16 *__restrict__ h
             g0 = grad_sigma[s] * expf(x);
         }
         h8 o0, o1;
-        o0[0] = (_Float16)g0;
+        o0[0] = foc_f2h(g0);
 #pragma unroll
         for (int k = 0; k < 7; k++) { o0[k + 1] = g2[k]; o1[k + 1] = g3[k]; }
         o1[0] = g2[7];
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_rgb_bwd(const _Float16 *__restrict__ c,
         for (int k = 0; k < 3; k++) {
             const float y = hd_sigmoid_h((float)c[s * 16 + k]);
             const float g = (float)(_Float16)grad_rgb[s * 3 + k];
-            o0[k] = (_Float16)(g * (1.0f - y) * y);
+            o0[k] = foc_f2h(g * (1.0f - y) * y);
         }
         *reinterpret_cast<h8 *>(grad_c + s * 16) = o0;
         *reinterpret_cast<h8 *>(grad_c + s * 16 + 8) = z;

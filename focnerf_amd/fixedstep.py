@@ -19,14 +19,26 @@ from ._lib import lib, ptr, stream_of, check
 from .gridencoder import grid_encode
 
 
-def fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, bound, want_xyzs=False):
+def fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, bound, want_xyzs=False, want_ray_sh=False):
     N = rays_o.shape[0]
     dev = rays_o.device
     enc_in = torch.empty(N * T, 3, dtype=torch.float32, device=dev)
     xyzs = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if want_xyzs else None
+    ray_sh = torch.empty(N, 16, dtype=torch.float16, device=dev) if want_ray_sh else None
     check(lib.foc_fixed_sample(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, T, float(bound), ptr(xyzs), ptr(enc_in),
-                               stream_of(rays_o)), "fixed_sample")
+                               ptr(ray_sh), stream_of(rays_o)), "fixed_sample")
+    if want_ray_sh:
+        return enc_in, xyzs, ray_sh
     return enc_in, xyzs
+
+
+def ray_sh_rows(rays_d):
+    """[N,3] directions -> [N,16] half: each ray's degree-4 SH values as they stand in the colour-net input."""
+    rays_d = rays_d.contiguous().float()
+    N, dev = rays_d.shape[0], rays_d.device
+    zeros, ones = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    aabb = torch.tensor([-1., -1., -1., 1., 1., 1.], device=dev)
+    return fixed_sample(torch.zeros_like(rays_d), rays_d, zeros, ones, aabb, None, 2, 1.0, want_ray_sh=True)[2]
 
 
 class _density_head(Function):
@@ -123,29 +135,28 @@ class _render_tail(Function):
     Same values and gradients as `_density_head` -> `FFMLP.forward_padded` -> `_fixed_composite`, bit for bit, without the colour
     network's input: its kernels read h and one SH row per ray (foc_color_head_forward), and in the backward pass the colour
     network writes grad_h itself — its input gradient for columns 1..15 merged with the density path's column 0 — so neither
-    cin [M,32] nor grad_cin [M,32] exists (0.5 GB of traffic per 2 M-sample step)."""
+    cin [M,32] nor grad_cin [M,32] exists (0.5 GB of traffic per 2 M-sample step). Head and composite are one kernel per
+    direction (foc_fixed_tail_forward / _backward). ray_sh [N,16] half: `fixed_sample(..., want_ray_sh=True)` or `ray_sh_rows`."""
 
     @staticmethod
-    def forward(ctx, h, cweights, rays_d, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation):
+    def forward(ctx, h, cweights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation):
         from .field import _half_of
         h = h.contiguous()
         assert h.dtype == torch.float16 and h.shape == (N * T, 16)
+        assert ray_sh.dtype == torch.float16 and ray_sh.shape == (N, 16) and ray_sh.is_contiguous()
         dev, M = h.device, N * T
         st = stream_of(h)
         w16 = _half_of(cweights)
+        c = torch.empty(M, 16, dtype=torch.float16, device=dev)
+        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), st), "color_head_forward")
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         trans = torch.empty(M, dtype=torch.float32, device=dev)
         weights = torch.empty(M, dtype=torch.float32, device=dev)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
-        ray_sh = torch.empty(N, 16, dtype=torch.float16, device=dev)
-        check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
-                                         ptr(weights), ptr(ws), ptr(depth), None, None, 32, ptr(ray_sh), st), "fixed_head_forward")
-        c = torch.empty(M, 16, dtype=torch.float16, device=dev)
-        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), st), "color_head_forward")
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        check(lib.foc_fixed_composite_forward(ptr(c), ptr(weights), ptr(bg_ray), float(bg_scalar), N, T, float(thresh), ptr(image), st),
-              "fixed_composite_forward")
+        check(lib.foc_fixed_tail_forward(ptr(h), ptr(c), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T, float(density_scale),
+                                         float(thresh), ptr(sigma), ptr(trans), ptr(weights), ptr(ws), ptr(depth), ptr(image), st), "fixed_tail_forward")
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise if noise is not None else empty,
                               bg_ray if bg_ray is not None else empty)
@@ -168,12 +179,9 @@ class _render_tail(Function):
         g_ws = g_ws.contiguous().float() if g_ws is not None else None
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         grad_c = torch.empty_like(c)
-        grad_w = torch.empty_like(weights)
-        check(lib.foc_fixed_composite_backward(ptr(g_image), ptr(c), ptr(weights), ptr(bg_ray), bg_scalar, N, T, thresh, ptr(grad_c), ptr(grad_w), st),
-              "fixed_composite_backward")
         grad_h0 = torch.empty(M, dtype=torch.float16, device=dev)
-        check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(grad_w), ptr(g_ws), ptr(g_depth),
-                                          None, N, T, ds, None, 32, ptr(grad_h0), st), "fixed_head_backward")
+        check(lib.foc_fixed_tail_backward(ptr(g_image), ptr(g_ws), ptr(g_depth), ptr(c), ptr(sigma), ptr(trans), ptr(weights), ptr(nears), ptr(fars),
+                                          ptr(noise), ptr(bg_ray), bg_scalar, N, T, ds, thresh, ptr(grad_c), ptr(grad_h0), st), "fixed_tail_backward")
         grad_h = torch.empty_like(h)
         g_w = torch.empty_like(w16)
         wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(32, 64, num_layers), dev)
@@ -209,7 +217,9 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
     aabb = model.aabb_train if model.training else model.aabb_infer
     nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
     noise = torch.rand(N * T, dtype=torch.float32, device=dev) if perturb else None
-    enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound)
+    want_tail = (tail_fusable(model) and model.training and torch.is_grad_enabled())
+    enc_in, _, ray_sh = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, want_ray_sh=True) if want_tail else \
+        fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound) + (None,)
 
     from .field import infer_fusable, field_infer
     if not torch.is_grad_enabled() and infer_fusable(model) and not getattr(model, "uses_object_feature", False):
@@ -250,11 +260,11 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         obj_feat = None
         if getattr(model, "uses_object_feature", False):                  # FOC network (network_foc.py): encoded YOLO feature in the colour input
             obj_feat = model.encode_object_feature(yolo_details, dev)
-        fused_tail = tail_fusable(model) and obj_feat is None and model.training and torch.is_grad_enabled()
+        fused_tail = want_tail and obj_feat is None
         if fused_tail:
             cn = model.color_net
             bg_ray, bg_scalar = _background(bg_color, N, dev)
-            image, weights_sum, depth, sigma, weights, c = _render_tail.apply(h, cn.weights, rays_d, nears, fars, noise, bg_ray, bg_scalar, N, T,
+            image, weights_sum, depth, sigma, weights, c = _render_tail.apply(h, cn.weights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T,
                                                                               model.density_scale, weight_thresh, cn.num_layers, cn.activation)
         else:
             weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale, obj_feat)

@@ -335,7 +335,9 @@ int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const floa
  * and/or enc_in [M,3] = (xyz + bound)/(2 bound), the GridEncoder's normalised input (grid.py:149). */
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
                      const float *aabb, const float *noise, uint32_t N, uint32_t T, float bound,
-                     float *xyzs, float *enc_in, void *stream);
+                     float *xyzs, float *enc_in, void *ray_sh, void *stream);
+/* ray_sh [N,16] fp16 or NULL: the degree-4 SH values of each ray's direction, rounded to fp16 as they stand in columns 0..15 of
+ * the colour-net input (for foc_color_head_forward). */
 
 /* h [M,16] fp16 = sigma-net output. sigma = exp(h[:,0]); weights = alpha * cumprod(1-alpha+1e-15);
  * trans [M] = transmittance before each sample; weights_sum/depth [N]; cin [M,cin_width] fp16 or NULL:
@@ -356,6 +358,18 @@ int foc_fixed_head_backward(const void *h, const float *sigma, const float *tran
                             const float *fars, const float *noise, const float *grad_w, const float *grad_ws,
                             const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
                             float density_scale, void *grad_h, uint32_t cin_width, void *grad_h0, void *stream);
+
+/* Training tail in one pass per direction (one wave per ray): foc_fixed_head_forward (cin NULL) + foc_fixed_composite_forward,
+ * and foc_fixed_composite_backward + foc_fixed_head_backward (grad_h0 form) — the same bits as the pairs; the weights are not
+ * re-read, their gradient never leaves the lane, and the backward does not read h (exp(clamp(h0,-15,15)) = clamp(sigma, ...)). */
+int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise,
+                           const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
+                           float *sigma, float *trans, float *weights, float *weights_sum, float *depth, float *image,
+                           void *stream);
+int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c,
+                            const float *sigma, const float *trans, const float *weights, const float *nears,
+                            const float *fars, const float *noise, const float *bg_ray, float bg_scalar, uint32_t N,
+                            uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, void *stream);
 
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL

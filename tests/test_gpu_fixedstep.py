@@ -244,7 +244,7 @@ def test_render_tail_node_is_bitwise_the_three_node_chain(N, T, layers, perturb,
     image, weights_sum, depth, sigma, weights, colour logits and grad_h must be the SAME BITS (every value of the colour input sits at
     the k position it has in the materialised row); the weight gradient differs only by the order of its fp32 atomics."""
     from focnerf_amd.ffmlp import FFMLP
-    from focnerf_amd.fixedstep import _density_head, _fixed_composite, _render_tail
+    from focnerf_amd.fixedstep import _density_head, _fixed_composite, _render_tail, ray_sh_rows
     g = torch.Generator(device="cuda").manual_seed(N * 1000 + T)
     M = N * T
     h0 = (torch.randn(M, 16, generator=g, device="cuda") * 0.7).half()
@@ -266,7 +266,7 @@ def test_render_tail_node_is_bitwise_the_three_node_chain(N, T, layers, perturb,
         net.weights.grad = None
         with torch.autocast("cuda", dtype=torch.float16):
             if fused:
-                image, ws, depth, sigma, weights, c = _render_tail.apply(h, net.weights, rays_d, nears, fars, noise, bg_ray, bg_scalar, N, T, 1.0, 1e-4,
+                image, ws, depth, sigma, weights, c = _render_tail.apply(h, net.weights, ray_sh_rows(rays_d), nears, fars, noise, bg_ray, bg_scalar, N, T, 1.0, 1e-4,
                                                                          net.num_layers, net.activation)
             else:
                 weights, ws, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, 1.0, None)
