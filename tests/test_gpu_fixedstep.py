@@ -305,3 +305,32 @@ def test_render_tail_is_the_path_render_fixed_steps_trains_through(monkeypatch):
     for ga, gb in zip(a[2:], b[2:]):
         scale = ga.abs().max().item()
         assert scale > 0 and (ga - gb).abs().max().item() <= 5e-3 * scale
+
+
+def test_outside_mask_criterion_trains_through_the_fused_tail():
+    """nerf/renderer.py:163-165: in training with YOLO details the renderer also returns the norm of the densities outside the object
+    mask. On the fused path h feeds both that criterion (torch) and the fused tail node; the two gradients must add up as in run()."""
+    from focnerf_amd.fixedstep import render_fixed_steps
+    m = _model(1, 4).train()
+    o, d = _rays(1, 12, 6)
+    N, T = o.shape[1], 64
+    mask = (torch.rand(1, N, T, device="cuda") > 0.5)
+    yolo = (mask, None, None)
+    target = torch.rand(1, N, 3, device="cuda")
+    outs = {}
+    for fused in (False, True):
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            res = render_fixed_steps(m, o, d, yolo, num_steps=T, bg_color=1.0, perturb=False) if fused else \
+                m.run(o, d, yolo, num_steps=T, upsample_steps=0, bg_color=1.0, perturb=False, fused=False)
+            crit = res["criterion_outside_mask"]
+            loss = ((res["image"] - target) ** 2).mean() + 1e-3 * crit
+        (loss * 256.0).backward()
+        outs[fused] = (res["image"].detach().clone(), crit.detach().clone(), m.encoder.embeddings.grad.clone(), m.sigma_net.weights.grad.clone(),
+                       m.color_net.weights.grad.clone())
+    a, b = outs[False], outs[True]
+    assert torch.allclose(a[0], b[0], atol=2e-4)
+    assert torch.allclose(a[1].float(), b[1].float(), rtol=1e-3)
+    for ga, gb in zip(a[2:], b[2:]):
+        scale = ga.abs().max().item()
+        assert scale > 0 and (ga.float() - gb.float()).abs().max().item() <= 3e-2 * scale
