@@ -175,7 +175,7 @@ __device__ __forceinline__ void ge_rows3(const uint32_t (&pos_grid)[3], uint32_t
 
 // ---- forward: one (point, level) ---------------------------------------------------------
 // out points at the C outputs of this (point, level); dy points at its [D,C] block or null.
-template <typename T, uint32_t D, uint32_t C>
+template <typename T, uint32_t D, uint32_t C, bool PAIRS = false>
 __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, const T *__restrict__ table, uint32_t hashmap_size,
                                                float scale, uint32_t resolution, T *__restrict__ out, T *__restrict__ dy,
                                                uint32_t gridtype, bool align_corners, uint32_t interp) {
@@ -209,6 +209,34 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     float ws[1u << D];
     uint32_t rows3[8];
     if constexpr (D == 3) ge_rows3(pos_grid, hashmap_size, resolution, gridtype, align_corners, rows3);
+    constexpr bool paired = PAIRS && D == 3 && C == 2 && sizeof(T) == 2;
+    if constexpr (paired) {
+        // The two corners along x of a (y, z) pair are ROW NEIGHBOURS whenever row(x+1) == row(x) ^ 1: always on a dense level with an
+        // even row, and on a hashed level for every even x (the hash xors x in with prime 1, so x -> x+1 flips bit 0 only). One
+        // 8-byte load of the aligned row pair then serves both corners — the gathers are bound by the number of distinct cache-line
+        // requests, not by bytes (tools/bench_gather.hip) — and only the other lanes issue the second, 4-byte load.
+        {
+            const uint32_t *tw = reinterpret_cast<const uint32_t *>(table);
+            uint2 wide[4];
+            uint32_t nar[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tw + (rows3[2 * j] & ~1u));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                nar[j] = 0u;
+                if (rows3[2 * j + 1] != (rows3[2 * j] ^ 1u)) nar[j] = tw[rows3[2 * j + 1]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool odd = (rows3[2 * j] & 1u) != 0u, pr = rows3[2 * j + 1] == (rows3[2 * j] ^ 1u);
+                const uint32_t v0 = odd ? wide[j].y : wide[j].x;
+                const uint32_t v1 = pr ? (odd ? wide[j].x : wide[j].y) : nar[j];
+                const __half2 h0 = *reinterpret_cast<const __half2 *>(&v0), h1 = *reinterpret_cast<const __half2 *>(&v1);
+                vals[2 * j][0] = __low2float(h0); vals[2 * j][1] = __high2float(h0);
+                vals[2 * j + 1][0] = __low2float(h1); vals[2 * j + 1][1] = __high2float(h1);
+            }
+        }
+    }
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {             // :167-191
         float w = 1;
@@ -219,10 +247,12 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
             else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
         }
         ws[idx] = w;
-        uint32_t row;
-        if constexpr (D == 3) row = rows3[idx];
-        else row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-        GeVec<T, C>::ld(table + (uint64_t)row * C, vals[idx]);
+        if constexpr (!paired) {
+            uint32_t row;
+            if constexpr (D == 3) row = rows3[idx];
+            else row = ge_index<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+            GeVec<T, C>::ld(table + (uint64_t)row * C, vals[idx]);
+        }
     }
 #pragma unroll
     for (uint32_t idx = 0; idx < (1u << D); idx++) {
@@ -270,7 +300,8 @@ template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ inputs, const T *__restrict__ grid,
                                                       const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                       uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
-                                                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks, uint32_t plain) {
+                                                      uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks, uint32_t plain,
+                                                      uint32_t pairs) {
     uint32_t level, chunk;
     if (plain) { level = blockIdx.x / chunks; chunk = blockIdx.x - level * chunks; }
     else if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
@@ -281,8 +312,12 @@ __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ 
     float x[D];
     const bool oob = ge_load_point<D>(inputs, b, x);
     T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
-    ge_forward_one<T, D, C>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                            outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+    if (pairs && ((off0 | hashmap_size) & 1u) == 0u)                           // row pairs of this level are 8-byte aligned and inside it
+        ge_forward_one<T, D, C, true>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                                      outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+    else
+        ge_forward_one<T, D, C, false>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                                       outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
 }
 
 // Point-major launch, outputs [B, L*C]: consecutive lanes = consecutive levels of one point, so
@@ -961,6 +996,14 @@ static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
 
 static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * chunks * ((L + 7u) / 8u); }
 
+// FOC_GRID_PAIRS=0: one 4-byte load per corner (A/B runs). 16-byte groups of 4 rows (which would also cover x = 1 mod 4 on a hashed
+// level) were measured SLOWER: 0.064 vs 0.052 ms per 2 M random points and level — the 16-byte gather is not free like the 8-byte one.
+static bool ge_pairs_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("FOC_GRID_PAIRS"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
 template <typename T, uint32_t D, uint32_t C>
 static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
                              const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
@@ -974,7 +1017,8 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
     } else {
         const uint32_t chunks = foc_div_up(B, 256);
         hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
-                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain);
+                           (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,
+                           (ge_pairs_enabled() && ((uintptr_t)emb & 7u) == 0u && !dy_dx) ? 1u : 0u);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
     return FOC_OK;

@@ -343,3 +343,36 @@ def test_backward_propagates_non_finite_gradients(atomic, monkeypatch):
     for l in (0, 1, 3, 9, 11, 15):
         assert np.isfinite(got[off[l]:off[l + 1]]).all(), f"level {l} must stay finite"
     assert not torch.isfinite(ge).all()      # what GradScaler's unscale_ looks at
+
+
+@pytest.mark.parametrize("layout", ["reference", "odd_offsets", "unaligned_table"])
+def test_forward_row_pair_loads_and_their_fallbacks(layout):
+    """fp16 C=2 D=3 forward without dy_dx: the two corners along x share one 8-byte load when their rows are neighbours (every even x
+    on a hashed level, every even row on a dense one). Same bits as the oracle for (a) the reference's level offsets (multiples of 8:
+    pairs on every level), (b) levels that start at odd rows / have odd sizes (no aligned pairs: per-level fallback, and a hashed level
+    whose size is not a power of two), (c) a table whose base is only 4-byte aligned (whole launch falls back)."""
+    D, C, L, H = 3, 2, 8, 16
+    rng = np.random.default_rng(11)
+    pls = 1.5
+    S = float(np.log2(pls))
+    res = [int(np.ceil(H * pls ** l - 1e-9)) for l in range(L)]
+    if layout == "odd_offsets":
+        sizes = [min((r + 1) ** 3, 100003) for r in res]          # dense levels with odd sizes, hashed levels of a prime size
+    else:
+        sizes = [int(np.ceil(min((r + 1) ** 3, 2 ** 16) / 8) * 8) for r in res]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    table = rng.uniform(-1, 1, (int(off[-1]) + 1, C)).astype(np.float16)
+    B = 20000
+    x = _points(B, D, 5)
+    # scale as gridencoder.cu:112-113: exp2(level * S) * H - 1 -> resolution ceil(scale) + 1; the offsets above follow the same formula
+    xt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda()
+    tt_full = torch.from_numpy(table).cuda()
+    if layout == "unaligned_table":
+        tt, tab = tt_full[1:], table[1:]                            # base pointer 4 bytes past an aligned address
+        assert tt.data_ptr() % 8 == 4
+    else:
+        tt, tab = tt_full[:-1], table[:-1]
+    ref = oracle.grid_encode_forward(x, np.ascontiguousarray(tab), off, D, C, L, S, H, False, 0, False, 0, acc_mode=1)
+    out = torch.empty(L, B, C, dtype=torch.float16, device="cuda")
+    _be().grid_encode_forward(xt, tt, ot, out, B, D, C, L, S, H, None, 0, False, 0)
+    assert_bits_equal(to_np(out), ref, f"outputs [L,B,C] ({layout})")
