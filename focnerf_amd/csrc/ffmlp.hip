@@ -63,6 +63,22 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
     return r;
 }
 
+// ReLU gate on a chained fragment: d where a > 0, else +0. `a` is a post-ReLU activation (never negative, never -0), so "a > 0" is
+// "its 16 bits are not zero": min(bits, 1) is a 0/1 factor per half and a packed 16-bit integer multiply applies it to d's bits —
+// 2 packed instructions per 2 values instead of a compare and a select per value.
+__device__ __forceinline__ h8 relu_gate(const h8 d, const h8 a) {
+    const u32x4 db = __builtin_bit_cast(u32x4, d), ab = __builtin_bit_cast(u32x4, a);
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t m, o;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(ab[i]), "v"(0x00010001u));
+        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(db[i]), "v"(m));
+        r[i] = o;
+    }
+    return __builtin_bit_cast(h8, r);
+}
+
 // Planar network inputs: [in_dim/2][B] dwords (half2), i.e. the hash-grid encoder's native [L, B, C=2] output (gridencoder.cu:218)
 // read without the permute to [B, L*C]. Element (row, 16kc + 8h + 2j + {0,1}) lives in plane 8kc + 4h + j; for one j the 32 lanes
 // of a lane-half read 128 contiguous bytes.
@@ -701,20 +717,58 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                         *reinterpret_cast<h8 *>(myD + rr * WD + cc) = v;
                     }
                 }
+            } else if constexpr (RECOMP) {
+                // delta of forward layer NL-s: acc rounded to fp16 in the chained layout (the next stage's B operand), gated by that
+                // layer's activation there, and the same dwords go to the LDS tile (quad q of tile mt = half (q&1) of fragment 2mt+(q>>1)).
+                // Rows past B need no masking: their D_0 rows are zeros, so every later delta of such a row is an exact zero.
+                if (bwd_buf && relu) {                   // stored form asked for as well (cold): the buffer holds the gated values
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++)
+                                    if ((2 * mt + (q >> 1)) < KC && !(fa[NL - s][(2 * mt + (q >> 1)) < KC ? (2 * mt + (q >> 1)) : 0][nb][4 * (q & 1) + e] > (_Float16)0))
+                                        acc[mt][nb][4 * q + e] = 0.0f;
+                }
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        bf[kc][nb] = acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+                        if (relu) bf[kc][nb] = relu_gate(bf[kc][nb], fa[NL - s][kc][nb]);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t col = 32 * mt + 8 * q + 4 * h;
+                            if (col < HIDDEN) {
+                                const h8 f = bf[(2 * mt + (q >> 1)) < KC ? (2 * mt + (q >> 1)) : 0][nb];
+                                const h4 v = (q & 1) ? h4{f[4], f[5], f[6], f[7]} : h4{f[0], f[1], f[2], f[3]};
+                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + col) = v;
+                            }
+                        }
+                        if (bwd_buf) store_tile<false>(bwd_buf + (uint64_t)(s - 1) * B * HIDDEN, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
+                    }
             } else {
                 // delta of forward layer NL-s: acc, already masked; rounded to fp16 (what the reference stores in backward_buffer)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        const bool live = row0 + nb * 32 + c < B;
+                        // rows past B need no masking: their D_0 rows are zeros, so every later delta of such a row is an exact zero
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const uint32_t col = 32 * mt + 8 * q + 4 * h;
                             if (col < HIDDEN) {
                                 h4 v;
 #pragma unroll
-                                for (int e = 0; e < 4; e++) v[e] = live ? (_Float16)acc[mt][nb][4 * q + e] : (_Float16)0;
+                                for (int e = 0; e < 4; e++) v[e] = (_Float16)acc[mt][nb][4 * q + e];
                                 *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + col) = v;
                             }
                         }
@@ -775,8 +829,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                             const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
                             const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
                             u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
-                            if (!(o < OUT)) av = u32x4{0u, 0u, 0u, 0u};
-                            if (!(i < IN)) bv = u32x4{0u, 0u, 0u, 0u};
+                            // columns past OUT / IN of the LDS tiles hold stale values: only the 16-wide output stage and input widths
+                            // that are not a multiple of 32 have such columns inside a 32-wide tile
+                            if (s == 0 || (HIDDEN & 31)) { if (!(o < OUT)) av = u32x4{0u, 0u, 0u, 0u}; }
+                            if (s < NL ? (HIDDEN & 31) != 0 : (in_dim & 31u) != 0u) { if (!(i < IN)) bv = u32x4{0u, 0u, 0u, 0u}; }
                             dwacc[s] = mfma16(__builtin_bit_cast(h8, av), __builtin_bit_cast(h8, bv), dwacc[s]);
                         }
                     }
@@ -861,7 +917,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     }
                 }
             }
-            if (s < NL && relu) {
+            if (!RECOMP && s < NL && relu) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
