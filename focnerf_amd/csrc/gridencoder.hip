@@ -620,8 +620,13 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
             const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
             uint32_t rows[8];
             ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+            // the two corners along x almost always fall into the same segment (rows differ in their low bits only): one atomic for both
 #pragma unroll
-            for (int i = 0; i < 8; i++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[i] >> GB_SEG_SHIFT)], 1u);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
+                if (s0 == s1) atomicAdd(&hist[level * GB_MAX_SEGS + s0], 2u);
+                else { atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u); atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u); }
+            }
         }
     }
     __syncthreads();
@@ -750,7 +755,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 uint32_t rows[8];
                 ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 8; i++) {              // (one cursor atomic of 2 for the two corners along x, as in the count pass, gained nothing here)
                     const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
                     const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
                     if (pos >= NREC) continue;             // cannot happen when count and scatter agree
