@@ -53,6 +53,10 @@ SIGNATURES = {
     "foc_grid_planes_to_rows": (i32, [c_vp, c_vp, u32, u32, u32, c_vp]),
     "foc_grid_encode_backward_binned": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
                                               u32, i32, u32, i32, i32, c_vp, c_vp, u64, c_vp]),
+    "foc_grid_encode_forward_counted": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, c_vp, c_vp, u64, c_vp]),
+    "foc_grid_encode_backward_count": (i32, [c_vp, c_vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, c_vp, c_vp, u64, c_vp]),
+    "foc_grid_encode_backward_binned_counted": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
+                                                      u32, i32, u32, i32, i32, c_vp, c_vp, u64, c_vp]),
     "foc_grad_total_variation": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, c_vp]),
     "foc_freq_encode_forward": (i32, [c_vp, u32, u32, u32, u32, c_vp, c_vp]),
     "foc_freq_encode_backward": (i32, [c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp]),

@@ -166,8 +166,70 @@ class _gridencoder:
             _gridencoder._offsets_host[key] = h
         return h[1]
 
+    # ---- the gradient-independent half of the binned backward (record counts -> record ranges), run ahead of time ----------------
+    # It needs the sample positions only and is VALU/LDS work, while the forward gathers are bound by cache requests and leave the VALU
+    # idle: a training forward (`grid_encode_forward_counted`) lets it ride along in the same launch. The result lives in the header of
+    # the shared backward workspace; a ticket tells the backward whether that header is still the one of ITS forward — any other use of
+    # the workspace in between invalidates it, and the backward then counts again itself. (`standalone=True`: the count as its own
+    # launch, foc_grid_encode_backward_count, for callers whose forward is not the [L,B,C] kernel.)
+    _pre = {}                                               # device index -> dict(ticket, key)
+
     @staticmethod
-    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, grad_bl=False):
+    def _pre_state(device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = _gridencoder._pre.get(idx)
+        if st is None:
+            st = _gridencoder._pre[idx] = dict(ticket=0, key=None)
+        return idx, st
+
+    @staticmethod
+    def _invalidate_precount(device):
+        _, st = _gridencoder._pre_state(device)
+        st["ticket"] += 1
+        st["key"] = None
+
+    @staticmethod
+    def grid_encode_forward_counted(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, gridtype, align_corners, interp, standalone=False):
+        """[L,B,C] forward + the backward's count pass. Returns a ticket for `grid_encode_backward(..., precount=ticket)`, or None when
+        the binned path does not apply (then nothing was computed: call grid_encode_forward)."""
+        import os
+        if os.environ.get("FOC_GRID_PRECOUNT", "1") == "0" or os.environ.get("FOCNERF_GRID_ATOMIC", "0") == "1":
+            return None
+        _gridencoder._common(inputs, embeddings, offsets)
+        require_cuda(outputs); _contig(outputs)
+        dt = dtype_code(embeddings)
+        ws_bytes = lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
+        if not ws_bytes or B * 8 * L >= 2 ** 32 or B == 0:
+            return None
+        if outputs.dtype != embeddings.dtype or outputs.numel() != L * B * C:
+            raise RuntimeError("grid_encode_forward_counted: outputs must be [L,B,C] of the embeddings' dtype")
+        ws = _scratch.get("grid_bwd", ws_bytes, inputs.device)
+        host = _gridencoder._host_offsets(offsets)
+        if standalone:
+            check(lib.foc_grid_encode_backward_count(ptr(inputs), ptr(offsets), B, D, C, L, float(S), H, gridtype, int(bool(align_corners)), interp, dt,
+                                                     host, ptr(ws), ws_bytes, stream_of(inputs)), "grid_encode_backward_count")
+            check(lib.foc_grid_encode_forward(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, None, gridtype,
+                                              int(bool(align_corners)), interp, dt, None, stream_of(inputs)), "grid_encode_forward")
+        else:
+            check(lib.foc_grid_encode_forward_counted(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, gridtype,
+                                                      int(bool(align_corners)), interp, dt, host, ptr(ws), ws_bytes, stream_of(inputs)),
+                  "grid_encode_forward_counted")
+        idx, st = _gridencoder._pre_state(inputs.device)
+        st["ticket"] += 1
+        st["key"] = (inputs.data_ptr(), B, L, dt, ws.data_ptr())
+        return (idx, st["ticket"], st["key"])
+
+    @staticmethod
+    def _precount_valid(ticket, inputs, B, L, dt, ws):
+        if ticket is None:
+            return False
+        idx, number, key = ticket
+        st = _gridencoder._pre.get(idx)
+        return st is not None and st["ticket"] == number and st["key"] == key == (inputs.data_ptr(), B, L, dt, ws.data_ptr())
+
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, grad_bl=False,
+                             precount=None):
         _gridencoder._common(inputs, embeddings, offsets)
         require_cuda(grad, grad_embeddings, dy_dx, grad_inputs); _contig(grad, grad_embeddings, dy_dx, grad_inputs)
         dt = dtype_code(grad)                               # the reference dispatches on grad.scalar_type(), :498-499
@@ -180,9 +242,12 @@ class _gridencoder:
             # persistent grow-only scratch (2 GB at B = 2M): a fresh torch.empty per call makes the caching allocator
             # re-malloc it whenever the freed block was split in between (measured: 28 ms hiccups per step)
             ws = _scratch.get("grid_bwd", ws_bytes, grad.device)
-            check(lib.foc_grid_encode_backward_binned(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
-                                                      ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),
-                                                      _gridencoder._host_offsets(offsets), ptr(ws), ws_bytes, stream_of(inputs)), "grid_encode_backward_binned")
+            counted = _gridencoder._precount_valid(precount, inputs, B, L, dt, ws)
+            fn = lib.foc_grid_encode_backward_binned_counted if counted else lib.foc_grid_encode_backward_binned
+            check(fn(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                     ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),
+                     _gridencoder._host_offsets(offsets), ptr(ws), ws_bytes, stream_of(inputs)), "grid_encode_backward_binned")
+            _gridencoder._invalidate_precount(grad.device)  # the header now belongs to this pass (and a used ticket is spent)
             return
         check(lib.foc_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                                            ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, dt, int(bool(grad_bl)),

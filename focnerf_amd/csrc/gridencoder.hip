@@ -600,41 +600,90 @@ __global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict_
 
 // One point per thread count pass, the partner of k_gbin_scatter_pms (same tile, same run merging).
 #define GB_PMS_WG 1024u
-__global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__restrict__ inputs, const int32_t *__restrict__ offsets, GbHeader *__restrict__ hdr,
-                                                             uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-                                                             bool align_corners, uint32_t interp) {
-    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
+// count of one 1024-point tile by a workgroup of THREADS threads (1024 / THREADS points per thread, one after the other)
+template <uint32_t THREADS>
+__device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uint32_t n_wg, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
+                                              GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, const GeLevels &lv,
+                                              uint32_t gridtype, bool align_corners, uint32_t interp) {
+    static_assert(GB_PM_TILE % THREADS == 0 && THREADS % 64 == 0, "whole waves, whole tile");
     const uint32_t nslots = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_PMS_WG) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < nslots; i += THREADS) hist[i] = 0;
     __syncthreads();
-    const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
-    float x[3] = {0.f, 0.f, 0.f};
-    const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
-    for (uint32_t level = 0; level < L; level++) {
-        const uint32_t resolution = lv.resolution[level];
-        uint32_t pg[3]; float pf[3];
-        gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
-        bool emit = inside;
-        if (resolution <= GB_MERGE_MAX_RES) emit = gb_run_flags(inside, pg).tail;
-        if (emit) {
-            const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
-            uint32_t rows[8];
-            ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
-            // the two corners along x almost always fall into the same segment (rows differ in their low bits only): one atomic for both
+    for (uint32_t it = 0; it < GB_PM_TILE / THREADS; it++) {
+        const uint32_t b = tile * GB_PM_TILE + it * THREADS + threadIdx.x;
+        float x[3] = {0.f, 0.f, 0.f};
+        const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
+        for (uint32_t level = 0; level < L; level++) {
+            const uint32_t resolution = lv.resolution[level];
+            uint32_t pg[3]; float pf[3];
+            gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
+            bool emit = inside;
+            if (resolution <= GB_MERGE_MAX_RES) emit = gb_run_flags(inside, pg).tail;
+            if (emit) {
+                const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+                uint32_t rows[8];
+                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+                // the two corners along x almost always fall into the same segment (rows differ in their low bits only): one atomic for both
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
-                if (s0 == s1) atomicAdd(&hist[level * GB_MAX_SEGS + s0], 2u);
-                else { atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u); atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u); }
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
+                    if (s0 == s1) atomicAdd(&hist[level * GB_MAX_SEGS + s0], 2u);
+                    else { atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u); atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u); }
+                }
             }
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nslots; i += GB_PMS_WG) {
+    for (uint32_t i = threadIdx.x; i < nslots; i += THREADS) {
         const uint32_t hcount = hist[i];
         if (hcount) (void)__hip_atomic_fetch_add(&hdr->counts[i], hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wg_hist[(uint64_t)i * gridDim.x + blockIdx.x] = hcount;
+        wg_hist[(uint64_t)i * n_wg + tile] = hcount;
     }
+}
+
+__global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__restrict__ inputs, const int32_t *__restrict__ offsets, GbHeader *__restrict__ hdr,
+                                                             uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
+                                                             bool align_corners, uint32_t interp) {
+    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
+    gb_count_tile<GB_PMS_WG>(hist, blockIdx.x, gridDim.x, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp);
+}
+
+// The level-major forward (k_grid_fwd_lbc, plain walk, fp16 C = 2 D = 3, no dy_dx) with the backward's count pass riding along: every
+// `period`-th workgroup of the launch counts one 1024-point tile instead of encoding 256 points of one level. The gathers are bound by
+// cache-line requests and leave the VALU idle; the count is VALU/LDS work on the same positions. (As a separate kernel on a side
+// stream the count starved: its 1024-thread workgroups never found 16 free wave slots on a CU while the forward's 4-wave workgroups
+// kept back-filling, and it then ran into the MLP kernels and slowed those.)
+template <typename T>
+__global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restrict__ inputs, const T *__restrict__ grid, const int32_t *__restrict__ offsets,
+                                                          T *__restrict__ outputs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners,
+                                                          uint32_t interp, uint32_t chunks, bool pairs, GbHeader *__restrict__ hdr,
+                                                          uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0) {
+    __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
+    // the counting workgroups sit among the encoding workgroups of the FINE levels (from block w0 on, one in `period`): those are the
+    // request-bound ones; the coarse levels are instruction-bound themselves, and the last level is left alone so that no long-running
+    // counting workgroup starts at the very end of the launch
+    uint32_t f = blockIdx.x;                                // index among the encoding workgroups
+    if (blockIdx.x >= w0) {
+        const uint32_t g = blockIdx.x - w0, q = g / period, r = g - q * period;
+        if (r == period - 1u && q < n_tiles) {
+            gb_count_tile<256>(hist, q, n_tiles, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp);
+            return;
+        }
+        f = blockIdx.x - min(q, n_tiles);
+    }
+    const uint32_t level = f / chunks, chunk = f - level * chunks;
+    const uint32_t b = chunk * 256 + threadIdx.x;
+    if (level >= L || b >= B) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    float x[3];
+    const bool oob = ge_load_point<3>(inputs, b, x);
+    if (pairs && ((off0 | hashmap_size) & 1u) == 0u)
+        ge_forward_one<T, 3, 2, true>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
+                                      outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
+    else
+        ge_forward_one<T, 3, 2, false>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
+                                       outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
 }
 
 // Level-sequential, LDS-sorted scatter, one point per thread (1024-thread workgroups, two per CU for fp16 tables).
@@ -1135,22 +1184,59 @@ static uint64_t gb_recs_bytes(uint32_t B, uint32_t L, int dtype) {
     return ((dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 255) & ~(uint64_t)255;
 }
 
-template <typename T>
-static int gb_run(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, const GeLevels &lv,
-                  uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, hipStream_t st) {
+// The gradient-independent half of the pass (counts -> record ranges): needs the sample positions only, so a caller may run it ahead of
+// time, e.g. next to the forward pass (foc_grid_encode_backward_count).
+static int gb_count(const float *inputs, const int32_t *offsets, uint32_t B, uint32_t L, const GeLevels &lv, uint32_t gridtype, bool ac, uint32_t interp,
+                    int dtype, void *workspace, hipStream_t st) {
     GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
-    const uint64_t max_recs = gb_max_recs(B, L);
     if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
     const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
-    const dim3 grid(n_wg);
-    uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
-    hipLaunchKernelGGL(k_gbin_count_pt, grid, dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
+    uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, dtype));
+    hipLaunchKernelGGL(k_gbin_count_pt, dim3(n_wg), dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
     FOC_CHECK_LAUNCH("grid_encode_backward(count)");
     hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
     FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
     hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
     FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
+    return FOC_OK;
+}
+
+// forward [L,B,2] + the count pass in one launch, then the two scan kernels (foc_grid_encode_forward_counted)
+template <typename T>
+static int gb_forward_counted(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L, const GeLevels &lv,
+                              uint32_t gridtype, bool ac, uint32_t interp, void *workspace, hipStream_t st) {
+    GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
+    void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
+    if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_forward_counted: memset failed"); return FOC_E_LAUNCH; }
+    const uint32_t n_tiles = foc_div_up(B, GB_PM_TILE), chunks = foc_div_up(B, 256);
+    const uint32_t fwd_blocks = chunks * L;
+    const uint32_t lo = L >= 4 ? L / 2 : 0, hi = L >= 4 ? L - 1 : L;          // levels whose workgroups the counting ones are spread over
+    const uint32_t w0 = lo * chunks, period = ((hi - lo) * chunks) / n_tiles + 1u;
+    uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
+    hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
+                       interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0);
+    FOC_CHECK_LAUNCH("grid_encode_forward_counted");
+    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
+    FOC_CHECK_LAUNCH("grid_encode_forward_counted(scan)");
+    hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_tiles);
+    FOC_CHECK_LAUNCH("grid_encode_forward_counted(wgscan)");
+    return FOC_OK;
+}
+
+template <typename T>
+static int gb_run(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, const GeLevels &lv,
+                  uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, bool counted, hipStream_t st) {
+    GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
+    void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
+    const uint64_t max_recs = gb_max_recs(B, L);
+    const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
+    const dim3 grid(n_wg);
+    uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
+    if (!counted) {
+        const int rc = gb_count(inputs, offsets, B, L, lv, gridtype, ac, interp, sizeof(T) == 2 ? FOC_F16 : FOC_F32, workspace, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
                        interp, bl);
     FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
@@ -1222,13 +1308,8 @@ uint64_t foc_grid_encode_backward_workspace_bytes(uint32_t B, uint32_t D, uint32
     return gb_workspace_bytes(B, L, dtype);
 }
 
-int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,
-                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
-                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
-                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
-    (void)embeddings;
-    if (B == 0) return FOC_OK;
-    FOC_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_binned: null pointer");
+static int gb_check(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t gridtype, uint32_t interp, int dtype, const int32_t *offsets_host,
+                    uint64_t workspace_bytes) {
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_backward_binned: dtype must be FOC_F32 or FOC_F16");
     FOC_REQUIRE(D == 3 && C == 2, FOC_E_INVALID, "grid_encode_backward_binned: only D=3, C=2 (got D=%u C=%u)", D, C);
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && gridtype <= 1 && interp <= 1, FOC_E_INVALID, "grid_encode_backward_binned: bad L/gridtype/interp");
@@ -1237,12 +1318,51 @@ int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const
     for (uint32_t l = 0; l < L; l++)
         FOC_REQUIRE((uint32_t)(offsets_host[l + 1] - offsets_host[l]) <= GB_SEG * GB_MAX_SEGS, FOC_E_INVALID,
                     "grid_encode_backward_binned: level %u has more than %u rows", l, GB_SEG * GB_MAX_SEGS);
+    return FOC_OK;
+}
+
+int foc_grid_encode_backward_count(const float *inputs, const int32_t *offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                   uint32_t gridtype, int align_corners, uint32_t interp, int dtype, const int32_t *offsets_host, void *workspace,
+                                   uint64_t workspace_bytes, void *stream) {
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(inputs && offsets && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_count: null pointer");
+    const int rc = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+    if (rc) return rc;
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    return gb_count(inputs, offsets, B, L, lv, gridtype, align_corners != 0, interp, dtype, workspace, (hipStream_t)stream);
+}
+
+int foc_grid_encode_forward_counted(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C,
+                                    uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(inputs && embeddings && offsets && outputs && workspace && offsets_host, FOC_E_INVALID, "grid_encode_forward_counted: null pointer");
+    const int rc = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+    if (rc) return rc;
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FOC_F32) return gb_forward_counted<float>(inputs, embeddings, offsets, outputs, B, L, lv, gridtype, align_corners != 0, interp, workspace, st);
+    return gb_forward_counted<__half>(inputs, embeddings, offsets, outputs, B, L, lv, gridtype, align_corners != 0, interp, workspace, st);
+}
+
+static int gb_entry(const void *grad, const float *inputs, const int32_t *offsets, void *grad_embeddings,
+                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, bool counted, void *stream) {
+    if (B == 0) return FOC_OK;
+    FOC_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_binned: null pointer");
+    {
+        const int rc0 = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+        if (rc0) return rc0;
+    }
     GeLevels lv;
     ge_make_levels(L, S, H, lv);
     hipStream_t st = (hipStream_t)stream;
     const bool ac = align_corners != 0, bl = grad_is_bl != 0;
-    int rc = dtype == FOC_F32 ? gb_run<float>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, st)
-                              : gb_run<__half>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, st);
+    int rc = dtype == FOC_F32 ? gb_run<float>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, st)
+                              : gb_run<__half>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, st);
     if (rc) return rc;
     if (dy_dx && grad_inputs) {
         const uint32_t g = foc_grid_1d((uint64_t)B * 3, 256);
@@ -1256,6 +1376,24 @@ int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const
         FOC_CHECK_LAUNCH("grid_encode_backward(inputs)");
     }
     return FOC_OK;
+}
+
+int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
+    (void)embeddings;
+    return gb_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, dtype, grad_is_bl,
+                    offsets_host, workspace, workspace_bytes, false, stream);
+}
+
+int foc_grid_encode_backward_binned_counted(const void *grad, const float *inputs, const void *embeddings, const int32_t *offsets, void *grad_embeddings,
+                                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
+                                            uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                                            const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
+    (void)embeddings;
+    return gb_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, dtype, grad_is_bl,
+                    offsets_host, workspace, workspace_bytes, true, stream);
 }
 
 int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets, float weight, uint32_t B,

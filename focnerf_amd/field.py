@@ -62,12 +62,16 @@ class _hashgrid_mlp(Function):
         emb = _half_of(embeddings)                              # grid.py:41-44: half table under autocast (C even)
         w = _half_of(weights)                                   # ffmlp.py:23: custom_fwd(cast_inputs=half)
         enc = torch.empty(L, B, 2, device=x.device, dtype=torch.half)
-        _gridencoder.grid_encode_forward(x, emb, offsets, enc, B, 3, 2, L, S, H, None, gridtype, align_corners, interp)
+        # training: the backward's count pass rides along in the forward launch (backend.grid_encode_forward_counted)
+        ticket = _gridencoder.grid_encode_forward_counted(x, emb, offsets, enc, B, 3, 2, L, S, H, gridtype, align_corners, interp) if training else None
+        if ticket is None:
+            _gridencoder.grid_encode_forward(x, emb, offsets, enc, B, 3, 2, L, S, H, None, gridtype, align_corners, interp)
         h = torch.empty(B, 16, device=x.device, dtype=torch.half)
         _ffmlp.ffmlp_forward_planar(enc, w, B, input_dim, 16, hidden_dim, num_layers, activation, output_activation, h)
         if training:
             ctx.save_for_backward(x, emb, w, offsets, enc)
             ctx.cfg = (enc_cfg, mlp_cfg, B, L)
+            ctx.ticket = ticket
         return h
 
     @staticmethod
@@ -80,7 +84,8 @@ class _hashgrid_mlp(Function):
         g_w = torch.empty_like(w)
         _ffmlp.ffmlp_backward_planar(grad_h, enc, w, B, input_dim, 16, hidden_dim, num_layers, activation, output_activation, True, g_enc, g_w)
         g_emb = torch.zeros_like(emb)
-        _gridencoder.grid_encode_backward(g_enc, x, emb, offsets, g_emb, B, 3, 2, L, S, H, None, None, gridtype, align_corners, interp, grad_bl=False)
+        _gridencoder.grid_encode_backward(g_enc, x, emb, offsets, g_emb, B, 3, 2, L, S, H, None, None, gridtype, align_corners, interp, grad_bl=False,
+                                          precount=ctx.ticket)
         return None, g_emb, g_w, None, None, None, None
 
 

@@ -190,6 +190,29 @@ int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const
                                     const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes,
                                     void *stream);
 
+/* The binned pass in two halves, so that the gradient-independent one (record counts -> record ranges, which needs the
+ * sample positions only) can run ahead of time: foc_grid_encode_backward_count fills the workspace header on its own;
+ * foc_grid_encode_forward_counted is foc_grid_encode_forward ([L,B,C] outputs, no dy_dx; D = 3, C = 2) with that pass riding
+ * along in the same launch — the forward gathers are bound by cache requests and leave the VALU idle, so the count costs
+ * almost nothing there (a training forward). foc_grid_encode_backward_binned_counted then does
+ * the scatter + reduce for the SAME inputs / offsets / B / dtype on the SAME workspace (nothing else may have used the
+ * workspace in between; the caller orders the two calls, across streams with an event). */
+int foc_grid_encode_forward_counted(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                    const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream);
+int foc_grid_encode_backward_count(const float *inputs, const int32_t *offsets, uint32_t B, uint32_t D, uint32_t C,
+                                   uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                   uint32_t interp, int dtype, const int32_t *offsets_host, void *workspace,
+                                   uint64_t workspace_bytes, void *stream);
+int foc_grid_encode_backward_binned_counted(const void *grad, const float *inputs, const void *embeddings,
+                                            const int32_t *offsets, void *grad_embeddings,
+                                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                            const void *dy_dx, void *grad_inputs, uint32_t gridtype,
+                                            int align_corners, uint32_t interp, int dtype, int grad_is_bl,
+                                            const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes,
+                                            void *stream);
+
 /* gridencoder.cu:639-645  grad_total_variation(inputs, embeddings, grad, offsets, weight,
  *       B, D, C, L, S, H, gridtype, align_corners)   — inputs share `dtype` with embeddings. */
 int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad,

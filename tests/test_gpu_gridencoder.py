@@ -376,3 +376,69 @@ def test_forward_row_pair_loads_and_their_fallbacks(layout):
     out = torch.empty(L, B, C, dtype=torch.float16, device="cuda")
     _be().grid_encode_forward(xt, tt, ot, out, B, D, C, L, S, H, None, 0, False, 0)
     assert_bits_equal(to_np(out), ref, f"outputs [L,B,C] ({layout})")
+
+
+def test_precounted_backward_and_stale_tickets(monkeypatch):
+    """The fused encoder->MLP node runs the backward's count pass during the forward, on a side stream; a ticket ties the workspace
+    header to that forward. Gradients must equal the plain path's, also when another forward or another backward used the workspace in
+    between (stale ticket -> the backward counts again)."""
+    from focnerf_amd.field import hashgrid_mlp
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(3)
+    m = NeRFNetwork(bound=1).cuda().train()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    xa = torch.rand(5000, 3, device="cuda") * 2 - 1
+    xb = torch.rand(7000, 3, device="cuda") * 2 - 1
+
+    def grads(order, pre):
+        monkeypatch.setenv("FOC_GRID_PRECOUNT", pre)
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            ha = hashgrid_mlp(m.encoder, m.sigma_net, xa, 1)
+            hb = hashgrid_mlp(m.encoder, m.sigma_net, xb, 1)        # second forward: overwrites the header counted for `ha`
+        la, lb = (ha.float() ** 2).sum(), (hb.float().abs()).sum()
+        first, second = (la, lb) if order == "ab" else (lb, la)
+        first.backward()
+        second.backward()
+        torch.cuda.synchronize()
+        return m.encoder.embeddings.grad.clone(), m.sigma_net.weights.grad.clone()
+
+    ref = grads("ab", "0")
+    for order in ("ab", "ba"):
+        got = grads(order, "1")
+        for a, b in zip(ref, got):
+            scale = a.abs().max().item()
+            assert scale > 0 and torch.isfinite(b).all()
+            assert (a.float() - b.float()).abs().max().item() <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("standalone", [False, True])
+@pytest.mark.parametrize("B", [1, 1000, 70001])
+def test_counted_forward_and_counted_backward_match_the_plain_calls(B, standalone):
+    """foc_grid_encode_forward_counted (count pass riding in the forward launch) / foc_grid_encode_backward_count (its own launch) followed
+    by foc_grid_encode_backward_binned_counted: same encoding bits and same gradient bits as the plain forward + binned backward."""
+    D, C, L, H = 3, 2, 16, 16
+    pls, S, off, table = _setup(D, C, L, H, 19, 2048, 1, np.float16)
+    rng = np.random.default_rng(B)
+    x = _points(B, D, 9) if B > 8 else rng.random((B, D)).astype(np.float32)
+    g = (rng.standard_normal((L, B, C)) * 0.1).astype(np.float16)
+    xt, tt, ot, gt = (torch.from_numpy(a).cuda() for a in (x, table, off, g))
+    be = _be()
+    out0 = torch.empty(L, B, C, dtype=torch.float16, device="cuda")
+    be.grid_encode_forward(xt, tt, ot, out0, B, D, C, L, S, H, None, 0, False, 0)
+    ge0 = torch.zeros_like(tt)
+    be.grid_encode_backward(gt, xt, tt, ot, ge0, B, D, C, L, S, H, None, None, 0, False, 0)
+    out1 = torch.empty_like(out0)
+    ticket = be.grid_encode_forward_counted(xt, tt, ot, out1, B, D, C, L, S, H, 0, False, 0, standalone=standalone)
+    assert ticket is not None
+    assert torch.equal(out0, out1)
+    ge1 = torch.zeros_like(tt)
+    be.grid_encode_backward(gt, xt, tt, ot, ge1, B, D, C, L, S, H, None, None, 0, False, 0, precount=ticket)
+    # segments with more than 65 536 records (the coarse levels at the largest B) are summed in several chunks whose fp16 partial sums meet
+    # in half2 atomics: their order, hence the last bit, is not fixed from run to run
+    same = (lambda a, b: torch.equal(a, b)) if B <= 1000 else (lambda a, b: assert_half_close(to_np(b), to_np(a), ulps=2.0, atol=4 * 2.0 ** -10 * float(a.abs().max()), what="grad") is None)
+    assert same(ge0, ge1)
+    # a spent ticket is not honoured twice (the backward counts again) and still gives the same result
+    ge2 = torch.zeros_like(tt)
+    be.grid_encode_backward(gt, xt, tt, ot, ge2, B, D, C, L, S, H, None, None, 0, False, 0, precount=ticket)
+    assert same(ge0, ge2)
