@@ -160,11 +160,19 @@ class _gridencoder:
         if h is None:
             import ctypes
             arr = offsets.detach().cpu().numpy().astype("int32")
-            h = (arr, arr.ctypes.data_as(ctypes.c_void_p))
+            h = (arr, arr.ctypes.data_as(ctypes.c_void_p), int((arr[1:] - arr[:-1]).max()) if arr.size > 1 else 0)
             if len(_gridencoder._offsets_host) > 64:
                 _gridencoder._offsets_host.clear()
             _gridencoder._offsets_host[key] = h
         return h[1]
+
+    @staticmethod
+    def _binned_ok(offsets):
+        """The binned backward partitions a level into at most 64 segments of 8192 rows (log2_hashmap_size <= 19, the NeRF default);
+        larger tables take the scattered-atomic kernel."""
+        _gridencoder._host_offsets(offsets)
+        key = (offsets.data_ptr(), offsets.numel(), offsets._version, str(offsets.device))
+        return _gridencoder._offsets_host[key][2] <= 8192 * 64
 
     # ---- the gradient-independent half of the binned backward (record counts -> record ranges), run ahead of time ----------------
     # It needs the sample positions only and is VALU/LDS work, while the forward gathers are bound by cache requests and leave the VALU
@@ -199,7 +207,7 @@ class _gridencoder:
         require_cuda(outputs); _contig(outputs)
         dt = dtype_code(embeddings)
         ws_bytes = lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
-        if not ws_bytes or B * 8 * L >= 2 ** 32 or B == 0:
+        if not ws_bytes or B * 8 * L >= 2 ** 32 or B == 0 or not _gridencoder._binned_ok(offsets):
             return None
         if outputs.dtype != embeddings.dtype or outputs.numel() != L * B * C:
             raise RuntimeError("grid_encode_forward_counted: outputs must be [L,B,C] of the embeddings' dtype")
@@ -238,7 +246,7 @@ class _gridencoder:
         # D=3, C=2 tables: partition + LDS accumulation instead of scattered atomics (FOCNERF_GRID_ATOMIC=1 forces the atomic kernel)
         import os
         ws_bytes = 0 if os.environ.get("FOCNERF_GRID_ATOMIC", "0") == "1" else lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
-        if ws_bytes and B * 8 * L < 2 ** 32:
+        if ws_bytes and B * 8 * L < 2 ** 32 and _gridencoder._binned_ok(offsets):
             # persistent grow-only scratch (2 GB at B = 2M): a fresh torch.empty per call makes the caching allocator
             # re-malloc it whenever the freed block was split in between (measured: 28 ms hiccups per step)
             ws = _scratch.get("grid_bwd", ws_bytes, grad.device)

@@ -442,3 +442,29 @@ def test_counted_forward_and_counted_backward_match_the_plain_calls(B, standalon
     ge2 = torch.zeros_like(tt)
     be.grid_encode_backward(gt, xt, tt, ot, ge2, B, D, C, L, S, H, None, None, 0, False, 0, precount=ticket)
     assert same(ge0, ge2)
+
+
+def test_tables_beyond_the_binned_limit_take_the_atomic_kernel():
+    """log2_hashmap_size = 20: a level has 2^20 rows, more than the 64 x 8192 the binned backward partitions; the wrapper must route such
+    tables to the scattered-atomic kernel (and the counted forward must decline) instead of failing."""
+    from focnerf_amd.gridencoder import GridEncoder
+    from focnerf_amd.field import hashgrid_mlp
+    from focnerf_amd.ffmlp import FFMLP
+    torch.manual_seed(0)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=20, desired_resolution=2048).cuda()
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    mlp = FFMLP(32, 16, 64, 2).cuda().train()
+    x = torch.rand(3000, 3, device="cuda") * 2 - 1
+    with torch.autocast("cuda", dtype=torch.float16):
+        h = hashgrid_mlp(enc, mlp, x, 1)
+    (h.float() ** 2).sum().backward()
+    g = enc.embeddings.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    # against the public two-node path (grid_encode -> FFMLP)
+    g_fused = g.clone(); enc.embeddings.grad = None; mlp.weights.grad = None
+    with torch.autocast("cuda", dtype=torch.float16):
+        h2 = mlp.forward_padded(enc(x, 1))
+    (h2.float() ** 2).sum().backward()
+    assert torch.equal(h, h2)
+    scale = g_fused.abs().max().item()
+    assert (g_fused - enc.embeddings.grad).abs().max().item() <= 2e-2 * scale
