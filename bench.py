@@ -42,9 +42,9 @@ ALGO_BYTES = {
 
 # C-ABI op -> the HIP kernels it launches (names as rocprofv3 prints them)
 OP_KERNELS = {
-    "grid_encode_backward": ["k_gbin_count", "k_gbin_scan", "k_gbin_wgscan", "k_gbin_scatter", "k_gbin_reduce"],
+    "grid_encode_backward": ["k_gbin_count", "k_gbin_scans", "k_gbin_scatter", "k_gbin_reduce"],
     "grid_encode_forward": ["k_grid_fwd_bl", "k_grid_fwd_lbc", "k_grid_fwd_counted"],
-    "grid_encode_forward_counted": ["k_grid_fwd_counted", "k_gbin_scan", "k_gbin_wgscan"],
+    "grid_encode_forward_counted": ["k_grid_fwd_counted", "k_gbin_scans"],
     "ffmlp_forward": ["k_mlp_fwd"],
     "ffmlp_inference": ["k_mlp_fwd"],
     "ffmlp_backward": ["k_mlp_bwd", "k_mlp_dw", "k_mlp_dw_finalize"],

@@ -150,29 +150,27 @@ class _gridencoder:
         require_cuda(planes, rows); _contig(planes, rows)
         check(lib.foc_grid_planes_to_rows(ptr(planes), ptr(rows), B, L, unit_bytes, stream_of(planes)), "grid_planes_to_rows")
 
-    _offsets_host = {}
+    @staticmethod
+    def _host_entry(offsets):
+        """Host copy of the (tiny, immutable) level-offset table, kept ON the tensor object so that it dies with it and a new tensor at a
+        recycled address can never be mistaken for it; cached so that the backward does not synchronise on every call."""
+        h = getattr(offsets, "_foc_host", None)
+        if h is None or h[0] != offsets._version:
+            import ctypes
+            arr = offsets.detach().cpu().numpy().astype("int32")
+            h = (offsets._version, arr, arr.ctypes.data_as(ctypes.c_void_p), int((arr[1:] - arr[:-1]).max()) if arr.size > 1 else 0)
+            offsets._foc_host = h
+        return h
 
     @staticmethod
     def _host_offsets(offsets):
-        """Host copy of the (tiny, immutable) level-offset table; cached so the backward does not sync every call."""
-        key = (offsets.data_ptr(), offsets.numel(), offsets._version, str(offsets.device))
-        h = _gridencoder._offsets_host.get(key)
-        if h is None:
-            import ctypes
-            arr = offsets.detach().cpu().numpy().astype("int32")
-            h = (arr, arr.ctypes.data_as(ctypes.c_void_p), int((arr[1:] - arr[:-1]).max()) if arr.size > 1 else 0)
-            if len(_gridencoder._offsets_host) > 64:
-                _gridencoder._offsets_host.clear()
-            _gridencoder._offsets_host[key] = h
-        return h[1]
+        return _gridencoder._host_entry(offsets)[2]
 
     @staticmethod
     def _binned_ok(offsets):
         """The binned backward partitions a level into at most 64 segments of 8192 rows (log2_hashmap_size <= 19, the NeRF default);
         larger tables take the scattered-atomic kernel."""
-        _gridencoder._host_offsets(offsets)
-        key = (offsets.data_ptr(), offsets.numel(), offsets._version, str(offsets.device))
-        return _gridencoder._offsets_host[key][2] <= 8192 * 64
+        return _gridencoder._host_entry(offsets)[3] <= 8192 * 64
 
     # ---- the gradient-independent half of the binned backward (record counts -> record ranges), run ahead of time ----------------
     # It needs the sample positions only and is VALU/LDS work, while the forward gathers are bound by cache requests and leave the VALU

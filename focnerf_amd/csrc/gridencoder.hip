@@ -552,54 +552,51 @@ __device__ __forceinline__ float gb_run_sum(float v, const GbRun &run) {
     return v;
 }
 
-// single workgroup: prefix sums over L * 64 segment counts
-__global__ void __launch_bounds__(1024) k_gbin_scan(GbHeader *__restrict__ hdr, uint32_t L) {
-    __shared__ uint32_t s_rec[GE_MAX_LEVELS * GB_MAX_SEGS];
-    __shared__ uint32_t s_chk[GE_MAX_LEVELS * GB_MAX_SEGS];
-    const uint32_t n = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t c = hdr->counts[i];
-        s_rec[i] = c;
-        s_chk[i] = (c + GB_CHUNK - 1) / GB_CHUNK;
-        hdr->cursor[i] = 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {       // n <= 2048: a serial scan is ~2 us and keeps this trivially correct
-        uint32_t r = 0, k = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            hdr->base[i] = r; hdr->chunk_prefix[i] = k;
-            r += s_rec[i]; k += s_chk[i];
-        }
-        hdr->base[n] = r; hdr->chunk_prefix[n] = k;
-    }
-}
-
 // ---- one-point-per-thread count / scatter -------------------------------------------------------
 // A workgroup owns GB_PM_TILE points x all levels, keeps one LDS counter per (level, segment) and talks to the global counters
-// once per non-empty (level, segment); its own counts per slot give it a deterministic record range (k_gbin_wgscan).
+// once per non-empty (level, segment); its own counts per slot give it a deterministic record range (k_gbin_scans).
 #define GB_PM_TILE 1024u
+#define GB_PMS_WG 1024u                         // threads of the count / scatter workgroups: one point per thread
 
-// per slot: exclusive scan over the workgroups' counts, offset by the slot's global base (in place)
-__global__ void __launch_bounds__(256) k_gbin_wgscan(const GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t n_wg) {
-    __shared__ uint32_t s_wave[4];
+// Both scans in one launch of L * 64 + 1 workgroups (they are independent: the scatter adds a slot's base to its workgroup prefix itself):
+//   workgroups 0 .. L*64-1: per slot, exclusive scan over the workgroups' counts (in place);
+//   the last workgroup    : exclusive scans over the L * 64 slot counts -> record base and reduce-chunk prefix of every slot.
+__global__ void __launch_bounds__(256) k_gbin_scans(GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t n_wg, uint32_t L) {
+    __shared__ uint32_t s_wave[2][4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = L * GB_MAX_SEGS;
+    if (blockIdx.x == n) {
+        const uint32_t per = (n + 255) / 256;
+        const uint32_t lo = threadIdx.x * per, hi = min(n, lo + per);
+        uint32_t recs = 0, chks = 0;
+        for (uint32_t i = lo; i < hi; i++) { const uint32_t c = hdr->counts[i]; recs += c; chks += (c + GB_CHUNK - 1) / GB_CHUNK; }
+        const uint32_t ir = (uint32_t)wave_incl_sum_i((int)recs, (int)lane), ic = (uint32_t)wave_incl_sum_i((int)chks, (int)lane);
+        if (lane == 63) { s_wave[0][wave] = ir; s_wave[1][wave] = ic; }
+        __syncthreads();
+        uint32_t r = ir - recs, k = ic - chks;
+        for (uint32_t w = 0; w < wave; w++) { r += s_wave[0][w]; k += s_wave[1][w]; }
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t c = hdr->counts[i];
+            hdr->base[i] = r; hdr->chunk_prefix[i] = k;
+            r += c; k += (c + GB_CHUNK - 1) / GB_CHUNK;
+        }
+        if (threadIdx.x == 255) { hdr->base[n] = r; hdr->chunk_prefix[n] = k; }   // the last thread's range ends at n (empty ranges pass r, k through)
+        return;
+    }
     const uint32_t slot = blockIdx.x;
     uint32_t *col = wg_hist + (uint64_t)slot * n_wg;
     const uint32_t per = (n_wg + 255) / 256;
-    const uint32_t lo = threadIdx.x * per, hi = min(n_wg, lo + per);
+    const uint32_t lo = min(n_wg, threadIdx.x * per), hi = min(n_wg, lo + per);
     uint32_t local = 0;
     for (uint32_t i = lo; i < hi; i++) local += col[i];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = (uint32_t)wave_incl_sum_i((int)local, (int)lane);
-    if (lane == 63) s_wave[wave] = incl;
+    if (lane == 63) s_wave[0][wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t k = 0; k < wave; k++) wbase += s_wave[k];
-    uint32_t run = hdr->base[slot] + wbase + (incl - local);
+    uint32_t run = incl - local;
+    for (uint32_t k = 0; k < wave; k++) run += s_wave[0][k];
     for (uint32_t i = lo; i < hi; i++) { const uint32_t c = col[i]; col[i] = run; run += c; }
 }
 
-// One point per thread count pass, the partner of k_gbin_scatter_pms (same tile, same run merging).
-#define GB_PMS_WG 1024u
 // count of one 1024-point tile by a workgroup of THREADS threads (1024 / THREADS points per thread, one after the other)
 template <uint32_t THREADS>
 __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uint32_t n_wg, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
@@ -743,8 +740,9 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     auto fetch_bases = [&](uint32_t level) {
         if (threadIdx.x < GB_MAX_SEGS && level < L) {
             const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
-            nb0 = wg_base[(uint64_t)slot * n_wg + blockIdx.x];
-            nb1 = blockIdx.x + 1 < n_wg ? wg_base[(uint64_t)slot * n_wg + blockIdx.x + 1] : hdr->base[slot] + hdr->counts[slot];
+            const uint32_t sb = hdr->base[slot];           // wg_base holds the prefix inside the slot
+            nb0 = sb + wg_base[(uint64_t)slot * n_wg + blockIdx.x];
+            nb1 = sb + (blockIdx.x + 1 < n_wg ? wg_base[(uint64_t)slot * n_wg + blockIdx.x + 1] : hdr->counts[slot]);
         }
     };
     fetch_bases(0);
@@ -1195,10 +1193,8 @@ static int gb_count(const float *inputs, const int32_t *offsets, uint32_t B, uin
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, dtype));
     hipLaunchKernelGGL(k_gbin_count_pt, dim3(n_wg), dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
     FOC_CHECK_LAUNCH("grid_encode_backward(count)");
-    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
-    FOC_CHECK_LAUNCH("grid_encode_backward(scan)");
-    hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_wg);
-    FOC_CHECK_LAUNCH("grid_encode_backward(wgscan)");
+    hipLaunchKernelGGL(k_gbin_scans, dim3(L * GB_MAX_SEGS + 1), dim3(256), 0, st, hdr, wg_hist, n_wg, L);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scans)");
     return FOC_OK;
 }
 
@@ -1217,10 +1213,8 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
                        interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted");
-    hipLaunchKernelGGL(k_gbin_scan, dim3(1), dim3(1024), 0, st, hdr, L);
-    FOC_CHECK_LAUNCH("grid_encode_forward_counted(scan)");
-    hipLaunchKernelGGL(k_gbin_wgscan, dim3(L * GB_MAX_SEGS), dim3(256), 0, st, hdr, wg_hist, n_tiles);
-    FOC_CHECK_LAUNCH("grid_encode_forward_counted(wgscan)");
+    hipLaunchKernelGGL(k_gbin_scans, dim3(L * GB_MAX_SEGS + 1), dim3(256), 0, st, hdr, wg_hist, n_tiles, L);
+    FOC_CHECK_LAUNCH("grid_encode_forward_counted(scans)");
     return FOC_OK;
 }
 
