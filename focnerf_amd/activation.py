@@ -1,22 +1,28 @@
-"""trunc_exp — same autograd function as the reference's activation.py:5-17 (exp forward in
-fp32, exp(clamp(x, -15, 15)) in the backward)."""
+"""`trunc_exp`: the density activation of the NeRF networks.
+
+Behaviour of the reference's activation.py:5-17: exp evaluated in fp32 whatever the autocast dtype; the derivative is taken at the
+argument clamped to [-15, 15], so that one overflowing logit cannot turn the whole gradient into inf.
+(The fused render paths evaluate the same two expressions inside their kernels: csrc/fixedstep.hip, csrc/head.hip.)
+"""
 import torch
-from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
+
+from ._autograd import AmpOp
+
+_GRAD_CLAMP = 15.0
 
 
-class _trunc_exp(Function):
-    @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+class TruncatedExp(AmpOp):
+    cast = torch.float32
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
-    def backward(ctx, g):
-        x = ctx.saved_tensors[0]
-        return g * torch.exp(x.clamp(-15, 15))
+    def run(ctx, logits):
+        ctx.save_for_backward(logits)
+        return logits.exp()
+
+    @staticmethod
+    def grad(ctx, upstream):
+        (logits,) = ctx.saved_tensors
+        return upstream * logits.clamp(min=-_GRAD_CLAMP, max=_GRAD_CLAMP).exp()
 
 
-trunc_exp = _trunc_exp.apply
+trunc_exp = TruncatedExp.apply

@@ -1,130 +1,126 @@
-"""Fully fused fp16 MLP — public surface of the reference's ffmlp/ffmlp.py (`ffmlp_forward`,
-`FFMLP`, :15-168), backed by libfocnerf_hip.so (MFMA kernels, fp32 accumulation).
+"""Fully fused fp16 MLP on the matrix cores (csrc/ffmlp.hip).
 
-Notes on behaviour kept from the reference:
-  * the weight blob layout and the seed-42 U(+-sqrt(3/hidden)) init (ffmlp.py:120-144);
-  * the reference's FFMLP.forward pads the batch with `128 - B % 128` zero rows (ffmlp.py:157-159); results
-    for the first B rows do not depend on that padding, and the kernels here accept any B, so no pad copy is made.
-The stray `from turtle import ...` of ffmlp.py:2 is not reproduced.
+Drop-in for the reference's ffmlp/ffmlp.py: `ffmlp_forward(...)` with its positional arguments and `FFMLP(input_dim, output_dim,
+hidden_dim, num_layers, activation)` with its attributes, its single `weights` parameter in the reference's blob layout
+([hidden x input] | (num_layers - 1) x [hidden x hidden] | [padded_output x hidden], every matrix row-major with the output neuron
+as the row, ffmlp.py:120-122) and its seed-42 U(+-sqrt(3 / hidden)) initialisation (ffmlp.py:141-144).
+
+Differences that a caller cannot observe in the results:
+  * no batch padding: the reference copies the input into a zero-padded batch of k * 128 rows (ffmlp.py:157-159); the kernels handle a
+    ragged last tile, so that copy is not made;
+  * training keeps no activations for the shapes the single-pass backward kernel serves (`single_pass_backward`): it re-evaluates them on
+    chip from the inputs (same MFMA sequence, same bits). FOC_MLP_RECOMPUTE=0 stores them as the reference does (ffmlp.py:31);
+  * accumulation is fp32 on the matrix cores (the reference accumulates in fp16).
+The reference module's stray `from turtle import ...` (ffmlp.py:2) has no counterpart.
 """
 import math
 import os
 
 import torch
 import torch.nn as nn
-from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _ffmlp as _backend
+from ._autograd import AmpOp
+from .backend import _ffmlp as _kernels
+
+ACTIVATIONS = {'relu': 0, 'exponential': 1, 'sine': 2, 'sigmoid': 3, 'squareplus': 4, 'softplus': 5}
+NO_ACTIVATION = 6
+SUPPORTED_HIDDEN = (16, 32, 64, 128, 256)       # what the reference accepts (256 is not built here: the kernels reject it)
 
 
-def _fused_backward_ok(input_dim, hidden_dim, num_layers):
-    """Shapes served by the single-pass backward kernel (csrc/ffmlp.hip, k_mlp_bwd_fused)."""
+def convert_activation(name):
+    return ACTIVATIONS.get(name, NO_ACTIVATION)
+
+
+def single_pass_backward(input_dim, hidden_dim, num_layers):
+    """Shapes served by k_mlp_bwd_fused (activation gradients, weight gradients and input gradients in one pass)."""
     return hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4 and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0"
 
 
-class _ffmlp_forward(Function):
-    @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.half)
-    def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False):
-        B = inputs.shape[0]
-        inputs = inputs.contiguous()
-        weights = weights.contiguous()
-        outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
-        if not inference:
-            # The reference keeps every hidden activation for the backward pass ([num_layers, B, hidden], ffmlp.py:31). For the
-            # shapes the fused backward kernel covers it re-evaluates them on chip from `inputs` instead (same MFMA sequence, same
-            # bits), so nothing is written here and nothing is read back there; FOC_MLP_RECOMPUTE=0 keeps the stored form.
-            recompute = _fused_backward_ok(input_dim, hidden_dim, num_layers) and os.environ.get("FOC_MLP_RECOMPUTE", "1") != "0"
-            forward_buffer = None if recompute else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
-            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                                   forward_buffer, outputs)
-            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
-            ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
-        else:
-            # the kernel keeps activations in registers; no [B, hidden] scratch is needed (the reference allocates one, ffmlp.py:41)
-            _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                                     None, outputs)
-        return outputs
+_fused_backward_ok = single_pass_backward       # name used by focnerf_amd.field
+
+
+def _keeps_activations(input_dim, hidden_dim, num_layers):
+    return not (single_pass_backward(input_dim, hidden_dim, num_layers) and os.environ.get("FOC_MLP_RECOMPUTE", "1") != "0")
+
+
+class FusedMLP(AmpOp):
+    """rows [B, input_dim] half, weight blob half -> [B, output_dim (padded to 16)] half."""
+    cast = torch.half
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        B = grad.shape[0]
-        grad = grad.contiguous()
-        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
-        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
-        if calc_grad_inputs:
-            grad_inputs = torch.empty_like(inputs)
-        else:
-            grad_inputs = torch.zeros(1, device=grad.device, dtype=grad.dtype)   # dummy, as in the reference (:70)
-        grad_weights = torch.empty_like(weights)
-        # The fused backward keeps the activation gradients on chip; the [num_layers, B, hidden] buffer the reference allocates
-        # (ffmlp.py:73) is only needed by the two-kernel fallback (hidden_dim 128, input_dim > 64 or num_layers > 4).
-        fused_ok = _fused_backward_ok(input_dim, hidden_dim, num_layers)
-        backward_buffer = None if fused_ok else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
-        if calc_grad_inputs:
-            return grad_inputs, grad_weights, None, None, None, None, None, None, None, None
-        return None, grad_weights, None, None, None, None, None, None, None, None
+    def run(ctx, x, blob, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference, want_dx):
+        x, blob = x.contiguous(), blob.contiguous()
+        n = x.shape[0]
+        net = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation)
+        y = x.new_empty(n, output_dim)
+        if inference:
+            # activations stay in registers: no [B, hidden] scratch (the reference allocates one, ffmlp.py:41)
+            _kernels.ffmlp_inference(x, blob, n, *net, None, y)
+            return y
+        kept = x.new_empty(num_layers, n, hidden_dim) if _keeps_activations(input_dim, hidden_dim, num_layers) else None
+        _kernels.ffmlp_forward(x, blob, n, *net, kept, y)
+        ctx.save_for_backward(x, blob, kept)
+        ctx.net, ctx.want_dx = net, want_dx
+        return y
+
+    @staticmethod
+    def grad(ctx, dy):
+        x, blob, kept = ctx.saved_tensors
+        input_dim, _, hidden_dim, num_layers = ctx.net[:4]
+        n = dy.shape[0]
+        dx = torch.empty_like(x) if ctx.want_dx else x.new_zeros(1)
+        d_blob = torch.empty_like(blob)
+        # the [num_layers, B, hidden] gradient buffer of ffmlp.py:73 exists only for the two-kernel form (hidden 128, > 4 layers, wide inputs)
+        scratch = None if single_pass_backward(input_dim, hidden_dim, num_layers) else x.new_empty(num_layers, n, hidden_dim)
+        _kernels.ffmlp_backward(dy.contiguous(), x, blob, kept, n, *ctx.net, ctx.want_dx, scratch, dx, d_blob)
+        return (dx if ctx.want_dx else None, d_blob) + (None,) * 8
 
 
-ffmlp_forward = _ffmlp_forward.apply
-
-
-def convert_activation(act):
-    return {'relu': 0, 'exponential': 1, 'sine': 2, 'sigmoid': 3, 'squareplus': 4, 'softplus': 5}.get(act, 6)
+def ffmlp_forward(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference=False,
+                  calc_grad_inputs=False):
+    """Positional signature of the reference's `ffmlp_forward = _ffmlp_forward.apply` (ffmlp.py:25-26, :97)."""
+    return FusedMLP.apply(inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference,
+                          calc_grad_inputs)
 
 
 class FFMLP(nn.Module):
     def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation='relu'):
         super().__init__()
-        self.input_dim = input_dim
-        self.output_dim = output_dim
-        self.hidden_dim = hidden_dim
-        self.num_layers = num_layers
-        self.activation = convert_activation(activation)
-        self.output_activation = convert_activation('none')
+        if hidden_dim not in SUPPORTED_HIDDEN:
+            raise AssertionError(f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}")
+        if input_dim <= 0 or input_dim % 16:
+            raise AssertionError(f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}")
+        if output_dim > 16:
+            raise AssertionError(f"FFMLP current only supports output dim <= 16, but got {output_dim}")
+        if num_layers < 2:
+            raise AssertionError(f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}")
+        self.input_dim, self.output_dim, self.hidden_dim, self.num_layers = input_dim, output_dim, hidden_dim, num_layers
+        self.activation, self.output_activation = convert_activation(activation), convert_activation('none')
         self.tensorcore_width = 16
-
-        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
-        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
-        assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
-        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
-
-        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
+        self.padded_output_dim = -(-output_dim // 16) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
         self.reset_parameters()
-        _backend.allocate_splitk(self.num_layers + 1)
+        _kernels.allocate_splitk(num_layers + 1)              # kept for the call sequence; weight gradients need no side streams here
 
     def cleanup(self):
-        _backend.free_splitk()
+        _kernels.free_splitk()
 
-    def __repr__(self):
-        return (f"FFMLP: input_dim={self.input_dim} output_dim={self.output_dim} hidden_dim={self.hidden_dim} "
-                f"num_layers={self.num_layers} activation={self.activation}")
+    def extra_repr(self):
+        return (f"{self.input_dim} -> " + " -> ".join([str(self.hidden_dim)] * self.num_layers) + f" -> {self.output_dim}, "
+                f"activation={self.activation}, parameters={self.num_parameters}")
 
     def reset_parameters(self):
         torch.manual_seed(42)
-        std = math.sqrt(3 / self.hidden_dim)
-        self.weights.data.uniform_(-std, std)
-
-    def forward(self, inputs):
-        B, C = inputs.shape
-        # The reference pads the batch to a multiple of 128 with a full copy (ffmlp.py:157-159, and a whole extra block
-        # when B is already aligned); the kernels here handle the ragged last tile themselves, so the rows the caller
-        # sees are identical and the 2 x B x C bytes of copy traffic per call are gone.
-        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
-                                self.activation, self.output_activation, not self.training, inputs.requires_grad)
-        if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
-            outputs = outputs[:B, :self.output_dim]
-        return outputs
+        bound = math.sqrt(3 / self.hidden_dim)
+        self.weights.data.uniform_(-bound, bound)
 
     def forward_padded(self, inputs):
-        """The kernel's full [B, 16] output (columns >= output_dim are the padding neurons), without the slice copy —
-        used by the fused render path, whose composite kernel reads the 16-wide rows directly."""
-        return ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
-                             self.activation, self.output_activation, not self.training, inputs.requires_grad)
+        """The kernel's full [B, 16] result (columns >= output_dim belong to the padding neurons), without the slice copy: the fused
+        render path's composite kernel reads the 16-wide rows as they are."""
+        return ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers, self.activation,
+                             self.output_activation, not self.training, inputs.requires_grad)
+
+    def forward(self, inputs):
+        y = self.forward_padded(inputs)
+        return y if self.padded_output_dim == self.output_dim else y[:, :self.output_dim]

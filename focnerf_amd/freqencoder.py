@@ -1,53 +1,55 @@
-"""Frequency (sinusoidal) encoder — public surface of the reference's freqencoder/freq.py
-(`freq_encode`, `FreqEncoder`, :15-76), backed by libfocnerf_hip.so."""
+"""Frequency encoding [x, sin(2^f x), cos(2^f x)]_{f < degree} on the GPU (csrc/freqencoder.hip).
+
+Drop-in for the reference's freqencoder/freq.py: `freq_encode(inputs, degree, output_dim)` and `FreqEncoder(input_dim, degree)` with the
+same attributes; always fp32 (freq.py:17). The backward pass needs the encoding only (d sin = cos, d cos = -sin are already in it).
+"""
 import torch
 import torch.nn as nn
-from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _freqencoder as _backend
+from ._autograd import AmpOp, on_gpu, rows, unrows
+from .backend import _freqencoder as _kernels
 
 
-class _freq_encoder(Function):
-    @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # always fp32 (freq.py:17)
-    def forward(ctx, inputs, degree, output_dim):
-        if not inputs.is_cuda:
-            inputs = inputs.cuda()
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        _backend.freq_encode_forward(inputs, B, input_dim, degree, output_dim, outputs)
-        ctx.save_for_backward(inputs, outputs)
-        ctx.dims = [B, input_dim, degree, output_dim]
-        return outputs
+def encoded_width(input_dim, degree):
+    return input_dim * (1 + 2 * degree)
+
+
+class FrequencyEncoding(AmpOp):
+    cast = torch.float32
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        grad = grad.contiguous()
-        inputs, outputs = ctx.saved_tensors
-        B, input_dim, degree, output_dim = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.freq_encode_backward(grad, outputs, B, input_dim, degree, output_dim, grad_inputs)
-        return grad_inputs, None, None
+    def run(ctx, points, degree, width):
+        points = on_gpu(points).contiguous()
+        n, dim = points.shape
+        encoded = points.new_empty(n, width)
+        _kernels.freq_encode_forward(points, n, dim, degree, width, encoded)
+        ctx.save_for_backward(encoded)
+        ctx.geometry = (n, dim, degree, width)
+        return encoded
+
+    @staticmethod
+    def grad(ctx, upstream):
+        (encoded,) = ctx.saved_tensors
+        n, dim, degree, width = ctx.geometry
+        d_points = encoded.new_zeros(n, dim)
+        _kernels.freq_encode_backward(upstream.contiguous(), encoded, n, dim, degree, width, d_points)
+        return d_points, None, None
 
 
-freq_encode = _freq_encoder.apply
+freq_encode = FrequencyEncoding.apply
 
 
 class FreqEncoder(nn.Module):
+    """`output_dim = input_dim * (1 + 2 * degree)`; accepts any leading shape."""
+
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = input_dim + input_dim * 2 * degree
+        self.input_dim, self.degree = input_dim, degree
+        self.output_dim = encoded_width(input_dim, degree)
 
-    def __repr__(self):
-        return f"FreqEncoder: input_dim={self.input_dim} degree={self.degree} output_dim={self.output_dim}"
+    def extra_repr(self):
+        return f"input_dim={self.input_dim}, degree={self.degree}, output_dim={self.output_dim}"
 
-    def forward(self, inputs, **kwargs):
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = freq_encode(inputs, self.degree, self.output_dim)
-        return outputs.reshape(prefix_shape + [self.output_dim])
+    def forward(self, inputs, **_unused):
+        flat, lead = rows(inputs, self.input_dim)
+        return unrows(freq_encode(flat, self.degree, self.output_dim), lead)

@@ -1,170 +1,166 @@
-"""Multiresolution hash-grid encoder — public surface of the reference's gridencoder/grid.py
-(`grid_encode`, `GridEncoder`, :24-184), backed by libfocnerf_hip.so.
+"""Multiresolution hash-grid encoder on the GPU (csrc/gridencoder.hip).
 
-The kernels can write the encoding directly as [B, L*C] and read the incoming gradient in
-that layout, so the two permute copies of the reference wrapper (grid.py:57, :75) are gone;
-`FOCNERF_GRID_LBC=1` selects the reference's [L,B,C] kernel layout + permutes instead
-(same values, used by the parity tests to cover both entry points).
+Drop-in for the reference's gridencoder/grid.py: `grid_encode(...)` with its positional arguments and `GridEncoder` with its constructor
+arguments, attributes, parameter / buffer names (`embeddings`, `offsets`) and `grad_total_variation`.
+
+How a call is served (the reference always runs its [L,B,C] kernel and permutes, grid.py:47,57,75):
+  * forward  — level-major kernel into [L,B,C] planes + one transpose kernel to the [B, L*C] rows the caller gets; the point-major
+               kernel that writes rows directly sits behind FOCNERF_GRID_POINT_MAJOR=1, the reference's layout + torch permute behind
+               FOCNERF_GRID_LBC=1 (the parity tests run all three);
+  * backward — D = 3, C = 2 tables: partition + on-chip accumulation (no scattered atomics), reading the incoming gradient as
+               [B, L*C] rows; other shapes: the atomic kernel (FOCNERF_GRID_ATOMIC=1 forces it).
 """
 import os
+from dataclasses import dataclass
 
 import numpy as np
 import torch
 import torch.nn as nn
-from torch.autograd import Function
-from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _gridencoder as _backend
+from ._autograd import AmpOp, rows, unrows
+from .backend import _gridencoder as _kernels
 
-_gridtype_to_id = {'hash': 0, 'tiled': 1}
-_interp_to_id = {'linear': 0, 'smoothstep': 1}
-
-
-def _use_lbc():
-    return os.environ.get("FOCNERF_GRID_LBC", "0") == "1"
+GRID_TYPES = {"hash": 0, "tiled": 1}
+INTERPOLATIONS = {"linear": 0, "smoothstep": 1}
 
 
-class _grid_encode(Function):
-    @staticmethod
-    @custom_fwd(device_type="cuda")
-    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False, interpolation=0):
-        # inputs [B,D] float in [0,1]; embeddings [rows,C]; offsets int32 [L+1]  ->  [B, L*C]
-        inputs = inputs.contiguous()
-        B, D = inputs.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        S = np.log2(per_level_scale)      # float64 -> float32 at the ABI, as in the reference (grid.py:38)
-        H = base_resolution
+def _flag(name):
+    return os.environ.get(name, "0") == "1"
 
-        # half-precision table under autocast when C is even (grid.py:41-44)
-        if torch.is_autocast_enabled() and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
-        embeddings = embeddings.contiguous()
 
-        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
-        lbc = _use_lbc()
-        if lbc:
-            outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
-            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interpolation)
-            outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
-        else:
-            outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
-            unit = C * embeddings.element_size()
-            if unit in (4, 8) and os.environ.get("FOCNERF_GRID_POINT_MAJOR", "0") != "1":
-                # level-major kernel (one level's table in L2 at a time) + one transpose kernel: 0.45 vs 0.74 ms per 2 M incoherent points
-                planes = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
-                _backend.grid_encode_forward(inputs, embeddings, offsets, planes, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interpolation)
-                _backend.planes_to_rows(planes, outputs, B, L, unit)
-            else:
-                _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interpolation,
-                                             out_bl=True)
+@dataclass(frozen=True)
+class GridSpec:
+    """Everything the kernels need besides the tensors. `log2_scale` is what the reference passes as S (grid.py:38)."""
+    log2_scale: float
+    base_resolution: int
+    gridtype: int = 0
+    align_corners: bool = False
+    interpolation: int = 0
 
-        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
-        ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
-        ctx.align_corners = align_corners
-        ctx.lbc = lbc
-        return outputs
+    def tail(self):
+        return self.gridtype, self.align_corners, self.interpolation
+
+
+class HashGridEncode(AmpOp):
+    """points [B,D] in [0,1], table [rows,C], offsets int32 [L+1] -> [B, L*C]. Under autocast the table is read as fp16 when C is even
+    (grid.py:41-44) and the result has the table's dtype."""
 
     @staticmethod
-    @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
-        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
-        align_corners = ctx.align_corners
+    def run(ctx, points, table, offsets, spec, want_dx):
+        points = points.contiguous()
+        n, dim = points.shape
+        levels, chans = offsets.numel() - 1, table.shape[1]
+        if torch.is_autocast_enabled() and chans % 2 == 0:
+            table = table.to(torch.half)
+        table = table.contiguous()
+        like = dict(device=points.device, dtype=table.dtype)
+        dy_dx = torch.empty(n, levels * dim * chans, **like) if want_dx else None
+        shape = (n, dim, chans, levels, spec.log2_scale, spec.base_resolution)
 
-        grad = grad.to(embeddings.dtype)
-        lbc_bwd = ctx.lbc or os.environ.get("FOCNERF_GRID_BWD_LBC", "0") == "1"
-        if lbc_bwd:
-            grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()     # grid.py:75
+        reference_layout = _flag("FOCNERF_GRID_LBC")
+        unit = chans * table.element_size()
+        if reference_layout:
+            planes = torch.empty(levels, n, chans, **like)
+            _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())
+            encoded = planes.permute(1, 0, 2).reshape(n, levels * chans)
+        elif unit in (4, 8) and not _flag("FOCNERF_GRID_POINT_MAJOR"):
+            planes = torch.empty(levels, n, chans, **like)
+            encoded = torch.empty(n, levels * chans, **like)
+            _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())
+            _kernels.planes_to_rows(planes, encoded, n, levels, unit)
         else:
-            grad = grad.contiguous()
-        grad_embeddings = torch.zeros_like(embeddings)
-        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
-        _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
-                                      align_corners, interpolation, grad_bl=not lbc_bwd)
-        if dy_dx is not None:
-            grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+            encoded = torch.empty(n, levels * chans, **like)
+            _kernels.grid_encode_forward(points, table, offsets, encoded, *shape, dy_dx, *spec.tail(), out_bl=True)
+
+        ctx.save_for_backward(points, table, offsets, dy_dx)
+        ctx.call = (shape, spec, reference_layout)
+        return encoded
+
+    @staticmethod
+    def grad(ctx, upstream):
+        points, table, offsets, dy_dx = ctx.saved_tensors
+        shape, spec, reference_layout = ctx.call
+        n, dim, chans, levels = shape[:4]
+        upstream = upstream.to(table.dtype)
+        planes_in = reference_layout or _flag("FOCNERF_GRID_BWD_LBC")
+        upstream = upstream.view(n, levels, chans).permute(1, 0, 2).contiguous() if planes_in else upstream.contiguous()
+        d_table = torch.zeros_like(table)
+        d_points = torch.zeros_like(points, dtype=table.dtype) if dy_dx is not None else None
+        _kernels.grid_encode_backward(upstream, points, table, offsets, d_table, *shape, dy_dx, d_points, *spec.tail(), grad_bl=not planes_in)
+        if d_points is not None:
+            d_points = d_points.to(points.dtype)
+        return d_points, d_table, None, None, None
 
 
-grid_encode = _grid_encode.apply
+def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
+                interpolation=0):
+    """Positional signature of the reference's `grid_encode = _grid_encode.apply` (grid.py:27-28, :92)."""
+    spec = GridSpec(float(np.log2(per_level_scale)), int(base_resolution), int(gridtype), bool(align_corners), int(interpolation))
+    return HashGridEncode.apply(inputs, embeddings, offsets, spec, bool(calc_grad_inputs))
 
 
 def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
-    """Rows per level, rounded up to a multiple of 8 (reference grid.py:117-128)."""
-    offsets, offset = [], 0
-    max_params = 2 ** log2_hashmap_size
-    for i in range(num_levels):
-        resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-        params_in_level = min(max_params, (resolution if align_corners else resolution + 1) ** input_dim)
-        params_in_level = int(np.ceil(params_in_level / 8) * 8)
-        offsets.append(offset)
-        offset += params_in_level
-    offsets.append(offset)
-    return np.array(offsets, dtype=np.int32)
+    """First row of every level (+ the total): a level holds min(2^log2_hashmap_size, cells^input_dim) rows, padded to a multiple
+    of 8, with cells = ceil(base * scale^level) (+1 unless align_corners) — the table layout of grid.py:117-128."""
+    cap = 2 ** log2_hashmap_size
+    sizes = []
+    for level in range(num_levels):
+        cells = int(np.ceil(base_resolution * per_level_scale ** level)) + (0 if align_corners else 1)
+        sizes.append(-(-min(cap, cells ** input_dim) // 8) * 8)
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
 
 
 class GridEncoder(nn.Module):
     def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
                  desired_resolution=None, gridtype='hash', align_corners=False, interpolation='linear'):
         super().__init__()
-        if desired_resolution is not None:   # overrides per_level_scale (grid.py:101-102)
+        if desired_resolution is not None:
+            # geometric growth from base_resolution to desired_resolution over the levels (takes precedence, grid.py:101-102)
             per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.base_resolution = per_level_scale, base_resolution
+        self.log2_hashmap_size, self.max_params = log2_hashmap_size, 2 ** log2_hashmap_size
         self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
-        self.gridtype_id = _gridtype_to_id[gridtype]
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
+        self.gridtype, self.gridtype_id = gridtype, GRID_TYPES[gridtype]
+        self.interpolation, self.interp_id = interpolation, INTERPOLATIONS[interpolation]
         self.align_corners = align_corners
-        self.max_params = 2 ** log2_hashmap_size
 
         offsets = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        total_rows = int(offsets[-1])
         self.register_buffer('offsets', torch.from_numpy(offsets))
-        self.n_params = int(offsets[-1]) * level_dim
-        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.n_params = total_rows * level_dim
+        self.embeddings = nn.Parameter(torch.empty(total_rows, level_dim))
         self.reset_parameters()
 
     def reset_parameters(self):
-        std = 1e-4
-        self.embeddings.data.uniform_(-std, std)
+        self.embeddings.data.uniform_(-1e-4, 1e-4)            # grid.py:139-141
 
-    def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
-                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+    def extra_repr(self):
+        finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
+        return (f"input_dim={self.input_dim}, levels={self.num_levels} x {self.level_dim}, resolution {self.base_resolution}..{finest} "
+                f"(x{self.per_level_scale:.4f}), table={tuple(self.embeddings.shape)}, {self.gridtype}/{self.interpolation}, "
+                f"align_corners={self.align_corners}")
+
+    def _unit_cube(self, x, bound):
+        return (x + bound) / (2 * bound)
 
     def forward(self, inputs, bound=1):
-        # inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
-        inputs = (inputs + bound) / (2 * bound)
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad,
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]."""
+        flat, lead = rows(self._unit_cube(inputs, bound), self.input_dim)
+        encoded = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, flat.requires_grad,
                               self.gridtype_id, self.align_corners, self.interp_id)
-        return outputs.view(prefix_shape + [self.output_dim])
+        return unrows(encoded, lead)
 
-    @torch.autocast(device_type="cuda", enabled=False)   # always fp32 (grid.py:163-164)
+    @torch.autocast(device_type="cuda", enabled=False)
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
-        D = self.input_dim
-        C = self.embeddings.shape[1]
-        L = self.offsets.shape[0] - 1
-        S = np.log2(self.per_level_scale)
-        H = self.base_resolution
-        if inputs is None:
-            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
-        else:
-            inputs = (inputs + bound) / (2 * bound)
-            inputs = inputs.view(-1, self.input_dim)
-            B = inputs.shape[0]
+        """Adds the total-variation gradient at `inputs` (default: B uniform samples) to `embeddings.grad`, in fp32 (grid.py:163-184):
+        call it between loss.backward() and optimizer.step()."""
         if self.embeddings.grad is None:
             raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
-        _backend.grad_total_variation(inputs.contiguous(), self.embeddings, self.embeddings.grad, self.offsets, weight, B, D, C, L, S, H,
+        if inputs is None:
+            at = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            at, _ = rows(self._unit_cube(inputs, bound), self.input_dim)
+        _kernels.grad_total_variation(at.contiguous(), self.embeddings, self.embeddings.grad, self.offsets, weight, at.shape[0], self.input_dim,
+                                      self.embeddings.shape[1], self.offsets.numel() - 1, np.log2(self.per_level_scale), self.base_resolution,
                                       self.gridtype_id, self.align_corners)

@@ -1,75 +1,64 @@
-"""NeRFRenderer — host-side mirror of the reference's renderer, the CALLER of the hot path.
+"""NeRFRenderer: the CALLER of the hot path, kept here so that the ops can be driven end to end where the reference tree is absent.
 
-Follows legacy/nerf/renderer.py (the only renderer in the reference whose occupancy-grid path
-runs) for `run_cuda` / `update_extra_state` (:256-376, :445-536) and
-nerf/renderer.py:126-238 for the fixed-step `run` (FOC's default path: num_steps=512,
-upsample_steps=0, colour queried where weights > 1e-10). It exists so the ops can be driven
-end-to-end on the GPU box, where the reference tree is absent; the reference's own renderer
-works unchanged on top of the same ops.
+It offers what the reference's renderers offer to a trainer — `render`, `run` (fixed-step sampling, FOC's default: nerf/renderer.py:126-238),
+`run_cuda` (occupancy-grid marching; the variant that actually runs is legacy/nerf/renderer.py:256-376),
+`mark_untrained_grid`, `update_extra_state`, `reset_extra_state` — with the same arguments, buffers (`aabb_train`, `aabb_infer`,
+`density_grid`, `density_bitfield`, `step_counter`) and result dictionaries, so that checkpoints and trainer code carry over; the
+reference's own renderer also works unchanged on the same ops.
 
-Additions over the reference caller (both optional, both default to reference behaviour):
-  * `device_compaction=True` in the inference loop keeps the alive-ray list on the device
-    between iterations for the compaction itself (order preserving), instead of the boolean
-    mask of legacy/nerf/renderer.py:363;
-  * `weight_thresh` makes the colour-query mask threshold explicit (1e-10 FOC / 1e-4 legacy);
-  * density-grid maintenance (`mark_untrained_grid`, `update_extra_state`) runs on the device through
-    csrc/densitygrid.hip; `FOC_FUSED_GRID_UPDATE=0` selects the torch expressions of the
-    reference, which stay in this file as the parity baseline.
+What differs from the reference caller:
+  * the density-grid maintenance runs on the device (csrc/densitygrid.hip) instead of Python loops over 128^3 cells
+    with host round trips; the torch restatements used to check it live with the tests (tests/torch_baselines.py);
+  * `run_cuda(..., device_compaction=True)` compacts the list of live rays on the device (order preserving);
+  * `run(..., weight_thresh=...)` names the threshold below which a sample's colour is not queried (1e-10 in FOC, 1e-4 in the legacy
+    renderer), and `return_fields` controls whether the per-sample fields COMBINED.py merges are returned.
 """
-import os
 import math
-
 import time
 
 import torch
 import torch.nn as nn
 
-from . import raymarching
+from . import densitygrid, raymarching
+
+_MARCH_ALIGN = 128          # sample lists are padded to multiples of this many rows (the MLP batch granularity of the reference)
 
 
-def custom_meshgrid(*args):
-    return torch.meshgrid(*args, indexing='ij')
+def _flat_rays(rays_o, rays_d):
+    lead = tuple(rays_o.shape[:-1])
+    return rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), lead
 
 
 class NeRFRenderer(nn.Module):
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
         super().__init__()
-        self.bound = bound
-        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.bound, self.density_scale, self.min_near = bound, density_scale, min_near
+        self.density_thresh, self.bg_radius, self.cuda_ray = density_thresh, bg_radius, cuda_ray
+        self.cascade = 1 + math.ceil(math.log2(bound))          # one occupancy cascade per doubling of the box
         self.grid_size = 128
-        self.density_scale = density_scale
-        self.min_near = min_near
-        self.density_thresh = density_thresh
-        self.bg_radius = bg_radius
-
-        aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
-        self.register_buffer('aabb_train', aabb_train)
-        self.register_buffer('aabb_infer', aabb_train.clone())
-
-        self.cuda_ray = cuda_ray
+        box = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32)
+        self.register_buffer('aabb_train', box)
+        self.register_buffer('aabb_infer', box.clone())
         if cuda_ray:
-            self.register_buffer('density_grid', torch.zeros([self.cascade, self.grid_size ** 3]))
-            self.register_buffer('density_bitfield', torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
-            self._mean_density = 0
-            self._mean_density_dev = None            # fused update: the mean stays on the device until someone reads `mean_density`
-            self.iter_density = 0
-            self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
-            self.mean_count = 0
-            self.local_step = 0
+            cells = self.grid_size ** 3
+            self.register_buffer('density_grid', torch.zeros(self.cascade, cells))
+            self.register_buffer('density_bitfield', torch.zeros(self.cascade * cells // 8, dtype=torch.uint8))
+            self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))      # samples marched in the last 16 training steps
+            self._mean_density, self._mean_density_dev = 0, None
+            self.iter_density = self.mean_count = self.local_step = 0
 
+    # the reference keeps `mean_density` as a Python float; the device-side update leaves it on the GPU until somebody asks
     @property
     def mean_density(self):
-        """Python float like the reference's attribute (renderer.py:497); synchronises only if a fused update left it on the device."""
         if getattr(self, "_mean_density_dev", None) is not None:
-            self._mean_density = float(self._mean_density_dev.item())
-            self._mean_density_dev = None
+            self._mean_density, self._mean_density_dev = float(self._mean_density_dev.item()), None
         return self._mean_density
 
     @mean_density.setter
     def mean_density(self, value):
-        self._mean_density = value
-        self._mean_density_dev = None
+        self._mean_density, self._mean_density_dev = value, None
 
+    # ---- what a network has to provide
     def forward(self, x, d):
         raise NotImplementedError()
 
@@ -79,340 +68,204 @@ class NeRFRenderer(nn.Module):
     def color(self, x, d, mask=None, **kwargs):
         raise NotImplementedError()
 
+    def _aabb(self):
+        return self.aabb_train if self.training else self.aabb_infer
+
+    def _background_colour(self, rays_o, rays_d, bg_color):
+        if self.bg_radius > 0:
+            return self.background(raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius), rays_d)
+        return 1 if bg_color is None else bg_color
+
+    # ------------------------------------------------------------------ fixed number of samples per ray
+    def run(self, rays_o, rays_d, yolo_details=None, num_steps=512, upsample_steps=0, bg_color=None, perturb=False, weight_thresh=1e-10,
+            return_fields=None, **kwargs):
+        """`num_steps` equidistant samples between the box entry and exit of every ray, density at all of them, colour where the
+        compositing weight exceeds `weight_thresh`, then alpha compositing with torch ops — the computation of nerf/renderer.py:126-238
+        for `upsample_steps=0` (the only value FOC uses, main_nerf.py:31-32), in its order of operations.
+
+        yolo_details = (sample mask [1,N,T], box, object feature) from the trainer (nerf/utils.py:57-154): handed on to `color()`, and
+        in training it yields `criterion_outside_mask`, the norm of the densities outside the mask (:163-165).
+        Result: depth, image, weights_sum, criterion_outside_mask, timing (host seconds before / after the colour query) and, with
+        `return_fields` (default: only in eval mode), densities [N,T,1] and rgbs [N,T,3]."""
+        if upsample_steps != 0:
+            raise NotImplementedError("hierarchical resampling (upsample_steps > 0) is not part of the FOC configuration")
+        want_fields = (not self.training) if return_fields is None else return_fields
+        started = time.time()
+        o, d, lead = _flat_rays(rays_o, rays_d)
+        n, T, box = o.shape[0], num_steps, self._aabb()
+
+        near, far = (t.unsqueeze(-1) for t in raymarching.near_far_from_aabb(o, d, box, self.min_near))
+        span = far - near
+        spacing = span / T
+        z = near + span * torch.linspace(0.0, 1.0, T, device=o.device).unsqueeze(0).expand(n, T)
+        if perturb:
+            z = z + (torch.rand(z.shape, device=o.device) - 0.5) * spacing
+        points = o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1)
+        points = torch.min(torch.max(points, box[:3]), box[3:])
+
+        field = self.density(points.reshape(-1, 3))
+        sigma = field['sigma'].view(n, T)
+        outside = None
+        if self.training and yolo_details is not None:
+            outside = torch.norm(sigma[~yolo_details[0].squeeze(0)] - 0)
+
+        step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
+        alpha = 1 - torch.exp(-step * self.density_scale * sigma)
+        survive = torch.cat([torch.ones_like(alpha[..., :1]), 1 - alpha + 1e-15], dim=-1)
+        weights = alpha * torch.cumprod(survive, dim=-1)[..., :-1]
+
+        per_sample = {k: v.reshape(n * T, -1) for k, v in field.items()}
+        view_dirs = d.view(-1, 1, 3).expand_as(points)
+        colour = self.color(points.reshape(-1, 3), view_dirs.reshape(-1, 3), mask=(weights > weight_thresh).reshape(-1),
+                            yolo_details=yolo_details, **per_sample).view(n, -1, 3)
+        queried = time.time()
+
+        opacity = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z - near) / span).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * colour, dim=-2)
+        image = image + (1 - opacity).unsqueeze(-1) * self._background_colour(o, d, bg_color)
+
+        out = {'depth': depth.view(*lead), 'image': image.view(*lead, 3), 'weights_sum': opacity, 'criterion_outside_mask': outside,
+               'timing': [queried - started, time.time() - queried]}
+        if want_fields:
+            out['densities'], out['rgbs'] = sigma.unsqueeze(-1), colour
+        return out
+
+    # ------------------------------------------------------------------ occupancy-grid marching
+    def _finish(self, image, depth, opacity, near, far, background, lead):
+        image = image + (1 - opacity).unsqueeze(-1) * background
+        depth = torch.clamp(depth - near, min=0) / (far - near)
+        return image.view(*lead, 3), depth.view(*lead)
+
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4,
+                 device_compaction=False, **kwargs):
+        """Samples only where the occupancy bitfield is set (legacy/nerf/renderer.py:256-376). Training: one marching pass, one
+        evaluation of the field, one compositing node. Inference: rays advance a few samples at a time and leave the list once they are
+        opaque or out of the box."""
+        o, d, lead = _flat_rays(rays_o, rays_d)
+        n, dev = o.shape[0], o.device
+        near, far = raymarching.near_far_from_aabb(o, d, self._aabb(), self.min_near)
+        background = self._background_colour(o, d, bg_color)
+        out = {}
+        if self.training:
+            slot = self.step_counter[self.local_step % 16]
+            slot.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size, near,
+                                                                    far, slot, self.mean_count, perturb, _MARCH_ALIGN, force_all_rays,
+                                                                    dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            opacity, depth, image = raymarching.composite_rays_train(self.density_scale * sigmas, rgbs, deltas, rays, T_thresh)
+            out['weights_sum'] = opacity
+        else:
+            opacity, depth, image = (torch.zeros(n, *tail, dtype=torch.float32, device=dev) for tail in ((), (), (3,)))
+            alive = torch.arange(n, dtype=torch.int32, device=dev)
+            t_now = near.clone()
+            marched = 0
+            while marched < max_steps and alive.shape[0] > 0:
+                live = alive.shape[0]
+                burst = max(min(n // live, 8), 1)                 # fewer live rays -> more samples per ray and launch
+                xyzs, dirs, deltas = raymarching.march_rays(live, burst, alive, t_now, o, d, self.bound, self.density_bitfield, self.cascade,
+                                                            self.grid_size, near, far, _MARCH_ALIGN, perturb and marched == 0, dt_gamma,
+                                                            max_steps)
+                sigmas, rgbs = self(xyzs, dirs)
+                raymarching.composite_rays(live, burst, alive, t_now, self.density_scale * sigmas, rgbs, deltas, opacity, depth, image, T_thresh)
+                if device_compaction:
+                    kept, count = raymarching.compact_alive(alive)
+                    alive = kept[:int(count.item())]
+                else:
+                    alive = alive[alive >= 0]
+                marched += burst
+        out['image'], out['depth'] = self._finish(image, depth, opacity, near, far, background, lead)
+        return out
+
+    # ------------------------------------------------------------------ occupancy-grid maintenance (device side)
+    def _require_grid(self, what):
+        if not self.density_bitfield.is_cuda:
+            raise RuntimeError(f"{what}: the occupancy grid is maintained by HIP kernels; move the module to the GPU first")
+
     def reset_extra_state(self):
         if not self.cuda_ray:
             return
         self.density_grid.zero_()
-        self.mean_density = 0
-        self.iter_density = 0
         self.step_counter.zero_()
-        self.mean_count = 0
-        self.local_step = 0
+        self.mean_density = 0
+        self.iter_density = self.mean_count = self.local_step = 0
 
-    # ------------------------------------------------------------------ fixed-step path
-    def run(self, rays_o, rays_d, yolo_details=None, num_steps=512, upsample_steps=0, bg_color=None, perturb=False, weight_thresh=1e-10,
-            return_fields=None, **kwargs):
-        """nerf/renderer.py:126-238 (upsample_steps must be 0, FOC's setting main_nerf.py:31-32).
-
-        `yolo_details` = (ray mask [1,N] bool, bbox, object feature) as produced by nerf/utils.py:57-154; it is handed to
-        `color()` and, in training, gives the outside-mask density penalty of :165. `return_fields` (None = the reference's
-        behaviour in eval mode, off in training where only image/criterion are consumed) adds `densities [N,T,1]` and
-        `rgbs [N,T,3]`, the per-sample fields COMBINED.py merges."""
-        assert upsample_steps == 0, "only the FOC configuration (upsample_steps=0) is implemented"
-        if return_fields is None:
-            return_fields = not self.training
-        t_start = time.time()
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-        aabb = self.aabb_train if self.training else self.aabb_infer
-
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
-        nears = nears.unsqueeze(-1)
-        fars = fars.unsqueeze(-1)
-
-        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
-        z_vals = nears + (fars - nears) * z_vals
-        sample_dist = (fars - nears) / num_steps
-        if perturb:
-            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
-
-        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
-        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
-
-        density_outputs = self.density(xyzs.reshape(-1, 3))
-        criterion_outside_mask = None
-        if self.training and yolo_details is not None:      # :163-165
-            criterion_outside_mask = torch.norm(density_outputs['sigma'].view(N, num_steps)[~yolo_details[0].squeeze(0)] - 0)
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(N, num_steps, -1)
-
-        deltas = z_vals[..., 1:] - z_vals[..., :-1]
-        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
-        alphas = 1 - torch.exp(-deltas * self.density_scale * density_outputs['sigma'].squeeze(-1))
-        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
-        weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
-
-        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
-        sigma_field = density_outputs['sigma']
-        for k, v in density_outputs.items():
-            density_outputs[k] = v.view(-1, v.shape[-1])
-
-        mask = weights > weight_thresh
-        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), yolo_details=yolo_details, **density_outputs)
-        rgbs = rgbs.view(N, -1, 3)
-        t_mid = time.time()
-
-        weights_sum = weights.sum(dim=-1)
-        ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
-        depth = torch.sum(weights * ori_z_vals, dim=-1)
-        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
-
-        if self.bg_radius > 0:
-            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
-            bg_color = self.background(sph, rays_d.reshape(-1, 3))
-        elif bg_color is None:
-            bg_color = 1
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-
-        results = {
-            'depth': depth.view(*prefix),
-            'image': image.view(*prefix, 3),
-            'weights_sum': weights_sum,
-            'criterion_outside_mask': criterion_outside_mask,
-            'timing': [t_mid - t_start, time.time() - t_mid],     # host-side stage times, as the reference reports them (:190,226)
-        }
-        if return_fields:   # what COMBINED.py's run() hands to the combiner (:528-534)
-            results['densities'] = sigma_field
-            results['rgbs'] = rgbs
-        return results
-
-    # ------------------------------------------------------------------ occupancy-grid path
-    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
-                 T_thresh=1e-4, device_compaction=False, **kwargs):
-        """legacy/nerf/renderer.py:256-376."""
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N = rays_o.shape[0]
-        device = rays_o.device
-
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
-
-        if self.bg_radius > 0:
-            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
-            bg_color = self.background(sph, rays_d)
-        elif bg_color is None:
-            bg_color = 1
-
-        results = {}
-        if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
-                                                                    force_all_rays, dt_gamma, max_steps)
-            sigmas, rgbs = self(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-            image = image.view(*prefix, 3)
-            depth = depth.view(*prefix)
-            results['weights_sum'] = weights_sum
-        else:
-            dtype = torch.float32
-            weights_sum = torch.zeros(N, dtype=dtype, device=device)
-            depth = torch.zeros(N, dtype=dtype, device=device)
-            image = torch.zeros(N, 3, dtype=dtype, device=device)
-            n_alive = N
-            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
-            rays_t = nears.clone()
-            step = 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
-                                                            self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
-                                                            perturb if step == 0 else False, dt_gamma, max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
-                sigmas = self.density_scale * sigmas
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
-                if device_compaction:
-                    out, n_out = raymarching.compact_alive(rays_alive)
-                    rays_alive = out[:int(n_out.item())]
-                else:
-                    rays_alive = rays_alive[rays_alive >= 0]
-                step += n_step
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-            image = image.view(*prefix, 3)
-            depth = depth.view(*prefix)
-
-        results['depth'] = depth
-        results['image'] = image
-        return results
-
-    # ------------------------------------------------------------------ density grid maintenance
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        """nerf/renderer.py:356-418 / legacy :380-443: cells no training camera sees get density -1 (never marched, never updated)."""
+        """Cells that no training camera sees get density -1: they are never marched and never updated (nerf/renderer.py:356-418).
+        Returns the per-cell camera count [cascade, H^3]. (`S`, the reference's chunk size, has no meaning here.)"""
         if not self.cuda_ray:
-            return
-        import numpy as np
-        if isinstance(poses, np.ndarray):
-            poses = torch.from_numpy(poses)
-        dev = self.density_bitfield.device
-        poses = poses.to(dev).float()
-        if dev.type == "cuda" and os.environ.get("FOC_FUSED_GRID_UPDATE", "1") != "0":
-            from . import densitygrid
-            count = densitygrid.mark_untrained_grid(poses, intrinsic, self.bound, self.cascade, self.grid_size, self.density_grid, return_count=True)
-        else:
-            B = poses.shape[0]
-            fx, fy, cx, cy = intrinsic
-            X = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            count = torch.zeros_like(self.density_grid)
-            for xs in X:
-                for ys in X:
-                    for zs in X:
-                        xx, yy, zz = custom_meshgrid(xs, ys, zs)
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
-                        for cas in range(self.cascade):
-                            bound = min(2 ** cas, self.bound)
-                            half_grid_size = bound / self.grid_size
-                            cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                            head = 0
-                            while head < B:
-                                tail = min(head + S, B)
-                                cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                                cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                                mask_z = cam_xyzs[:, :, 2] > 0
-                                mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                                mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                                mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-                                count[cas, indices] += mask
-                                head += S
-            self.density_grid[count == 0] = -1
-        return count
-
-    @torch.no_grad()
-    def _update_extra_state_fused(self, decay):
-        """update_extra_state through csrc/densitygrid.hip: same sampling scheme, EMA and threshold, one host read (mean_count)."""
-        from . import densitygrid
-        dev = self.density_bitfield.device
-        C, H = self.cascade, self.grid_size
-        if self.iter_density < 16:
-            jitter = torch.rand(C * H ** 3, 3, device=dev)
-            xyzs = densitygrid.grid_cells_xyz(C, H, self.bound, jitter, dev)
-            indices = None
-        else:
-            N = H ** 3 // 4
-            rand_coords = torch.randint(0, H, (C, N, 3), device=dev, dtype=torch.int32)
-            rand_pick = torch.rand(C, N, device=dev)
-            jitter = torch.rand(C * 2 * N, 3, device=dev)
-            indices, xyzs = densitygrid.grid_update_sample(self.density_grid, C, H, self.bound, rand_coords, rand_pick, jitter)
-        sigmas = self.density(xyzs)['sigma'].reshape(-1).detach()
-        mean_dev = torch.empty(1, dtype=torch.float32, device=dev)
-        densitygrid.grid_update_apply(self.density_grid, C, H, sigmas, indices, self.density_scale, decay, self.density_thresh, self.density_bitfield, mean_dev)
-        self._mean_density_dev = mean_dev
-        self.iter_density += 1
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
-        self.local_step = 0
+            return None
+        self._require_grid("mark_untrained_grid")
+        poses = torch.as_tensor(poses).to(self.density_bitfield.device).float()
+        return densitygrid.mark_untrained_grid(poses, intrinsic, self.bound, self.cascade, self.grid_size, self.density_grid, return_count=True)
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
-        """legacy/nerf/renderer.py:445-536."""
+        """Re-estimates the occupancy grid from the current density field (legacy/nerf/renderer.py:445-536): the first 16 calls visit
+        every cell, later calls visit H^3/4 random cells plus H^3/4 random occupied cells per cascade; the grid keeps
+        max(old * decay, new), and cells above min(mean density, density_thresh) are marked occupied. Also refreshes `mean_count`,
+        the sample budget of the next training steps, from the last (up to) 16 marching passes — the one host read of this call."""
         if not self.cuda_ray:
             return
-        if self.density_bitfield.is_cuda and os.environ.get("FOC_FUSED_GRID_UPDATE", "1") != "0":
-            return self._update_extra_state_fused(decay)
-        tmp_grid = - torch.ones_like(self.density_grid)
-        dev = self.density_bitfield.device
+        self._require_grid("update_extra_state")
+        dev, C, H = self.density_bitfield.device, self.cascade, self.grid_size
         if self.iter_density < 16:
-            X = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            Y = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            Z = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            for xs in X:
-                for ys in Y:
-                    for zs in Z:
-                        xx, yy, zz = custom_meshgrid(xs, ys, zs)
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                        for cas in range(self.cascade):
-                            bound = min(2 ** cas, self.bound)
-                            half_grid_size = bound / self.grid_size
-                            cas_xyzs = xyzs * (bound - half_grid_size)
-                            cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-                            sigmas = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
-                            sigmas *= self.density_scale
-                            tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
+            visited = None
+            at = densitygrid.grid_cells_xyz(C, H, self.bound, torch.rand(C * H ** 3, 3, device=dev), dev)
         else:
-            N = self.grid_size ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
-                occ_indices = occ_indices[rand_mask]
-                occ_coords = raymarching.morton3D_invert(occ_indices)
-                indices = torch.cat([indices, occ_indices], dim=0)
-                coords = torch.cat([coords, occ_coords], dim=0)
-                xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                bound = min(2 ** cas, self.bound)
-                half_grid_size = bound / self.grid_size
-                cas_xyzs = xyzs * (bound - half_grid_size)
-                cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-                sigmas = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
-                sigmas *= self.density_scale
-                tmp_grid[cas, indices] = sigmas.to(tmp_grid.dtype)
-
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+            k = H ** 3 // 4
+            visited, at = densitygrid.grid_update_sample(self.density_grid, C, H, self.bound,
+                                                         torch.randint(0, H, (C, k, 3), device=dev, dtype=torch.int32),
+                                                         torch.rand(C, k, device=dev), torch.rand(C * 2 * k, 3, device=dev))
+        sigmas = self.density(at)['sigma'].reshape(-1).detach()
+        mean = torch.empty(1, dtype=torch.float32, device=dev)
+        densitygrid.grid_update_apply(self.density_grid, C, H, sigmas, visited, self.density_scale, decay, self.density_thresh,
+                                      self.density_bitfield, mean)
+        self._mean_density_dev = mean
         self.iter_density += 1
-
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        recent = min(16, self.local_step)
+        if recent > 0:
+            self.mean_count = int(self.step_counter[:recent, 0].sum().item() / recent)
         self.local_step = 0
 
     @torch.no_grad()
     def set_density_grid(self, density_grid, density_thresh=None):
-        """Install a precomputed density grid [cascade, H^3] (Morton order) and pack it — used by the
-        synthetic scenes of bench.py / the tests in place of a trained grid."""
+        """Installs a given grid [cascade, H^3] (Morton order) and packs it: the synthetic scenes of bench.py and the tests use it in
+        place of a trained grid."""
         assert self.cuda_ray
         self.density_grid.copy_(density_grid)
         self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
-        thresh = min(self.mean_density, self.density_thresh) if density_thresh is None else density_thresh
-        self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
+        level = min(self.mean_density, self.density_thresh) if density_thresh is None else density_thresh
+        self.density_bitfield = raymarching.packbits(self.density_grid, level, self.density_bitfield)
 
+    # ------------------------------------------------------------------ whole views
     def render(self, rays_o, rays_d, yolo_details=None, staged=False, max_ray_batch=4096, **kwargs):
-        """nerf/renderer.py:511-560 (and legacy/nerf/renderer.py:539-573, which has no `yolo_details`).
-
-        Staged rendering assembles `densities [B,N,T]` and `rgbs [B,N,T,3]` for the whole view like the reference when the
-        chunks carry them (`return_fields`, default on in eval mode): 1.3 + 3.9 GB per 800x800x512 view."""
+        """rays [B,N,3] -> result dictionary of `run` / `run_cuda`. `staged` (fixed-step path only) walks a view in chunks of
+        `max_ray_batch` rays and assembles depth [B,N], image [B,N,3] and — when the chunks carry them — densities [B,N,T] and
+        rgbs [B,N,T,3] for the whole view, as nerf/renderer.py:511-560 does (1.3 + 3.9 GB for 800 x 800 x 512)."""
         if self.cuda_ray:
-            _run = self.run_cuda                         # takes no yolo_details (renderer.py:243)
-        else:
-            _run = lambda o, d, **kw: self.run(o, d, yolo_details, **kw)
+            return self.run_cuda(rays_o, rays_d, **kwargs)                    # the marching path knows no yolo_details (renderer.py:243)
+        if not staged:
+            return self.run(rays_o, rays_d, yolo_details, **kwargs)
         B, N = rays_o.shape[:2]
-        device = rays_o.device
-        if staged and not self.cuda_ray:
-            depth = torch.empty((B, N), device=device)
-            image = torch.empty((B, N, 3), device=device)
-            densities = rgbs = None
-            for b in range(B):
-                head = 0
-                while head < N:
-                    tail = min(head + max_ray_batch, N)
-                    results_ = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
-                    depth[b:b + 1, head:tail] = results_['depth']
-                    image[b:b + 1, head:tail] = results_['image']
-                    if 'densities' in results_:
-                        if densities is None:
-                            T = results_['densities'].shape[1]
-                            densities = torch.empty((B, N, T), device=device)
-                            rgbs = torch.empty((B, N, T, 3), device=device)
-                        densities[b:b + 1, head:tail] = results_['densities'].permute(2, 0, 1)
-                        rgbs[b:b + 1, head:tail] = results_['rgbs']
-                    head += max_ray_batch
-            results = {'depth': depth, 'image': image, 'timing': results_.get('timing')}
-            if densities is not None:
-                results['densities'] = densities
-                results['rgbs'] = rgbs
-        else:
-            results = _run(rays_o, rays_d, **kwargs)
-        return results
+        dev = rays_o.device
+        depth, image = torch.empty(B, N, device=dev), torch.empty(B, N, 3, device=dev)
+        densities = rgbs = None
+        for b in range(B):
+            for lo in range(0, N, max_ray_batch):
+                hi = min(lo + max_ray_batch, N)
+                part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, **kwargs)
+                depth[b:b + 1, lo:hi], image[b:b + 1, lo:hi] = part['depth'], part['image']
+                if 'densities' in part:
+                    if densities is None:
+                        T = part['densities'].shape[1]
+                        densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
+                    densities[b:b + 1, lo:hi] = part['densities'].permute(2, 0, 1)
+                    rgbs[b:b + 1, lo:hi] = part['rgbs']
+        out = {'depth': depth, 'image': image, 'timing': part.get('timing')}
+        if densities is not None:
+            out['densities'], out['rgbs'] = densities, rgbs
+        return out
