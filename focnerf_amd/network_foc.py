@@ -41,12 +41,8 @@ class NeRFNetwork(NeRFRenderer):
     def __init__(self, encoding="HashGrid", encoding_dir="SphericalHarmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
                  num_layers_color=3, hidden_dim_color=64, yolo_encoding_dim=16, bound=1, n_chunks=5, yolo_feats_encoder_dim=144, **kwargs):
         super().__init__(bound, **kwargs)
-        self.num_layers = num_layers
-        self.hidden_dim = hidden_dim
-        self.yolo_encoding_dim = yolo_encoding_dim
-        self.geo_feat_dim = geo_feat_dim
-        self.yolo_feats_encoder_dim = yolo_feats_encoder_dim
-        self.n_chunks = n_chunks
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.yolo_encoding_dim, self.yolo_feats_encoder_dim, self.n_chunks = yolo_encoding_dim, yolo_feats_encoder_dim, n_chunks
 
         self.encoder, self.in_dim = get_encoder("hashgrid", desired_resolution=2048 * bound)          # :478-488
         self.sigma_net = FFMLP(input_dim=self.in_dim, output_dim=1 + self.geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
@@ -110,19 +106,14 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(self.color_net(h))
 
     def color(self, x, d, yolo_details=None, mask=None, geo_feat=None, **kwargs):
-        """:607-654: encodes the raw object feature, evaluates the colour net where `mask` is set."""
+        """Colour of the samples selected by `mask` (all if None), conditioned on the encoded object feature; the others get 0
+        (network_tcnn.py:607-654)."""
         obj_feat = self.encode_object_feature(yolo_details, x.device)
-        if mask is not None:
-            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
-            if not mask.any():
-                return rgbs
-            d = d[mask]
-            geo_feat = geo_feat[mask]
-        h = self._color_torch(d, geo_feat, obj_feat)
-        if mask is not None:
-            rgbs[mask] = h.to(rgbs.dtype)
-        else:
-            rgbs = h
+        if mask is None:
+            return self._color_torch(d, geo_feat, obj_feat)
+        rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+        if mask.any():
+            rgbs[mask] = self._color_torch(d[mask], geo_feat[mask], obj_feat).to(rgbs.dtype)
         return rgbs
 
     def run(self, rays_o, rays_d, yolo_details=None, fused=False, **kwargs):
@@ -133,10 +124,6 @@ class NeRFNetwork(NeRFRenderer):
         return super().run(rays_o, rays_d, yolo_details, **kwargs)
 
     def get_params(self, lr):
-        return [
-            {'params': self.encoder.parameters(), 'lr': lr},
-            {'params': self.sigma_net.parameters(), 'lr': lr},
-            {'params': self.encoder_dir.parameters(), 'lr': lr},
-            {'params': self.color_net.parameters(), 'lr': lr},
-            {'params': self.yolo_feat_encoder.parameters(), 'lr': lr},
-        ]
+        """One optimizer group per sub-module, the object-feature encoder included."""
+        parts = (self.encoder, self.sigma_net, self.encoder_dir, self.color_net, self.yolo_feat_encoder)
+        return [{'params': m.parameters(), 'lr': lr} for m in parts]
