@@ -525,7 +525,7 @@ __device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap
 // lanes a run of lanes with equal cells is summed on the lanes (segmented DPP scan, fp32) and only the run's last lane emits
 // records. The count and the scatter kernel derive the run structure from the same values with the same code, so their record
 // counts agree by construction.
-#define GB_MERGE_MAX_RES 320u                  // levels above this resolution are not merged (cells < 2^10 per axis needed for the key)
+#define GB_MERGE_MAX_RES 700u                  // levels above this resolution are not merged (cells < 2^10 per axis needed for the key)
 template <int CTRL>
 __device__ __forceinline__ uint32_t gb_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 struct GbRun { uint32_t f0, f1, f2, f3; bool tail; };       // f_k: "do not add from lane - 2^k" at scan step k
