@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
 #define GB_SEG_SHIFT 13u
 #define GB_SEG (1u << GB_SEG_SHIFT)            // rows per segment
 #define GB_MAX_SEGS 64u                        // per level: covers 2^19-row levels
-#define GB_CHUNK 65536u                        // records per reduce workgroup
+#define GB_CHUNK 32768u                        // records (two corners each) per reduce workgroup
 #define GB_WG 256u
 
 struct GbHeader {                              // lives at the start of the workspace
@@ -620,12 +620,12 @@ __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uin
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
                 ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
-                // the two corners along x almost always fall into the same segment (rows differ in their low bits only): one atomic for both
+                // one record per pair of corners along x (they share their segment unless they straddle an 8192-row boundary: then one each)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
-                    if (s0 == s1) atomicAdd(&hist[level * GB_MAX_SEGS + s0], 2u);
-                    else { atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u); atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u); }
+                    atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u);
+                    if (s0 != s1) atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u);
                 }
             }
         }
@@ -697,12 +697,16 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
     bool align_corners, uint32_t interp, bool grad_bl) {
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
-    constexpr uint32_t NREC = GB_PM_TILE * 8u;
+    // a record carries the two corners along x of one (y, z) corner pair: 4 per point, 5 when one pair straddles a segment boundary
+    // (two pairs of a point cannot: their rows differ by less than 8192 and not by a multiple of it on a dense level, and a hashed
+    // level's x never reaches 8191)
+    constexpr uint32_t NREC = GB_PM_TILE * 5u;
+    constexpr uint32_t VW = sizeof(T) == 2 ? 1 : 2;         // dwords per corner value
     __shared__ uint32_t cur[2][GB_MAX_SEGS];               // next free staging position per segment (double-buffered by level parity)
     __shared__ uint32_t pre[2][GB_MAX_SEGS + 1];           // first staging position per segment; [64] = records of this level
     __shared__ uint32_t gb[2][GB_MAX_SEGS];                // this workgroup's first global record per segment MINUS its first staging position
-    __shared__ uint2 s_rec[NREC];                          // {local row | segment << 16, value word 0}: one 8-byte LDS access per record
-    __shared__ uint32_t s_v1[sizeof(T) == 2 ? 1 : NREC];
+    __shared__ uint32_t s_rows[NREC];                      // local row of corner 0 | local row of corner 1 << 13 | segment << 26
+    __shared__ uint32_t s_val[2 * VW][NREC];               // corner 0 value words, corner 1 value words
     const uint32_t n_wg = gridDim.x;
     const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
     float x[3] = {0.f, 0.f, 0.f};
@@ -801,30 +805,34 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
                 ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {              // (one cursor atomic of 2 for the two corners along x, as in the count pass, gained nothing here)
-                    const uint32_t seg = rows[i] >> GB_SEG_SHIFT;
+                auto place = [&](uint32_t seg, uint32_t r0, uint32_t r1, int i0, int i1) {      // i1 < 0: corner 1 carries nothing
                     const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
-                    if (pos >= NREC) continue;             // cannot happen when count and scatter agree
-                    s_rec[pos] = make_uint2((rows[i] & (GB_SEG - 1u)) | (seg << 16), pv0[i]);
-                    if constexpr (sizeof(T) != 2) s_v1[pos] = pv1[i];
+                    if (pos >= NREC) return;               // cannot happen when count and scatter agree
+                    s_rows[pos] = (r0 & (GB_SEG - 1u)) | ((r1 & (GB_SEG - 1u)) << 13) | (seg << 26);
+                    s_val[0][pos] = pv0[i0];
+                    s_val[VW][pos] = i1 >= 0 ? pv0[i1 >= 0 ? i1 : 0] : 0u;
+                    if constexpr (sizeof(T) != 2) { s_val[1][pos] = pv1[i0]; s_val[VW + 1][pos] = i1 >= 0 ? pv1[i1 >= 0 ? i1 : 0] : 0u; }
+                };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t r0 = rows[2 * j], r1 = rows[2 * j + 1];
+                    const uint32_t s0 = r0 >> GB_SEG_SHIFT, s1 = r1 >> GB_SEG_SHIFT;
+                    if (s0 == s1) place(s0, r0, r1, 2 * j, 2 * j + 1);
+                    else { place(s0, r0, r0, 2 * j, -1); place(s1, r1, r1, 2 * j + 1, -1); }
                 }
             }
         }
         __syncthreads();
         const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
+        uint32_t *rec_rows = reinterpret_cast<uint32_t *>(recs);                       // [max_recs] rows, then [max_recs] values (16-byte aligned)
+        uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
         for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
-            const uint2 rec = s_rec[j];
-            const uint32_t at = gb[pb][rec.x >> 16] + j;
+            const uint32_t rw = s_rows[j];
+            const uint32_t at = gb[pb][rw >> 26] + j;
             if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
-            if constexpr (sizeof(T) == 2) {
-                reinterpret_cast<uint2 *>(recs)[at] = make_uint2(rec.x & 0xFFFFu, rec.y);
-            } else {
-                uint32_t *rr = reinterpret_cast<uint32_t *>(recs);
-                float2 *vv = reinterpret_cast<float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-                rr[at] = rec.x & 0xFFFFu;
-                vv[at] = make_float2(__uint_as_float(rec.y), __uint_as_float(s_v1[j]));
-            }
+            rec_rows[at] = rw & 0x3FFFFFFu;
+            if constexpr (sizeof(T) == 2) reinterpret_cast<uint2 *>(rec_vals)[at] = make_uint2(s_val[0][j], s_val[1][j]);
+            else reinterpret_cast<uint4 *>(rec_vals)[at] = make_uint4(s_val[0][j], s_val[1][j], s_val[2][j], s_val[3][j]);
         }
         // no barrier here: the next level's setup writes the other parity of cur/pre/gb, and its staging writes come after
         // the barrier that follows the setup, which every thread reaches only once its copy-out loop is done
@@ -873,50 +881,58 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     // Software pipeline: the next UNR records per lane are in flight while the current ones go through the LDS adds
     // (with a plain load -> wait -> add loop the HBM latency was exposed once per iteration: 1.15 ms for 2.1 GB).
     constexpr uint32_t UNR = 4;
+    const uint32_t *rec_rows = reinterpret_cast<const uint32_t *>(recs);           // record = rows word + the values of its two corners
+    const uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
     if constexpr (sizeof(T) == 2) {
-        const uint2 *rr = reinterpret_cast<const uint2 *>(recs);
-        uint2 cur[UNR], nxt[UNR];
+        const uint2 *vv = reinterpret_cast<const uint2 *>(rec_vals);
+        uint32_t cr[UNR], nr[UNR]; uint2 cv[UNR], nv[UNR];
         uint32_t i0 = lo + threadIdx.x;
 #pragma unroll
-        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; cur[u] = i < hi ? rr[i] : make_uint2(0xFFFFFFFFu, 0u); }
+        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rec_rows[i] : NONE; cv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
+        // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT (and order
+        // independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
+        auto add = [&](uint32_t row, uint32_t hv) {
+            if ((hv & 0x7C00u) == 0x7C00u || (hv & 0x7C000000u) == 0x7C000000u) {       // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
+                atomicOr(&s_bad[row >> 5], 1u << (row & 31u));
+                return;
+            }
+            atomicAdd(&acci[row * 2], gb_half_to_fixed(hv & 0xFFFFu));
+            atomicAdd(&acci[row * 2 + 1], gb_half_to_fixed(hv >> 16));
+        };
         while (i0 < hi) {
             const uint32_t i1 = i0 + GB_RTHREADS * UNR;
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; nxt[u] = i < hi ? rr[i] : make_uint2(0xFFFFFFFFu, 0u); }
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rec_rows[i] : NONE; nv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
-                if (cur[u].x != 0xFFFFFFFFu) {
-                    // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT
-                    // (and order independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
-                    const uint32_t hv = cur[u].y;
-                    if ((hv & 0x7C00u) == 0x7C00u || (hv & 0x7C000000u) == 0x7C000000u) {   // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
-                        atomicOr(&s_bad[cur[u].x >> 5], 1u << (cur[u].x & 31u));
-                        continue;
-                    }
-                    atomicAdd(&acci[cur[u].x * 2], gb_half_to_fixed(hv & 0xFFFFu));
-                    atomicAdd(&acci[cur[u].x * 2 + 1], gb_half_to_fixed(hv >> 16));
+                if (cr[u] != NONE) {
+                    add(cr[u] & (GB_SEG - 1u), cv[u].x);
+                    add((cr[u] >> 13) & (GB_SEG - 1u), cv[u].y);
                 }
             }
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) cur[u] = nxt[u];
+            for (uint32_t u = 0; u < UNR; u++) { cr[u] = nr[u]; cv[u] = nv[u]; }
             i0 = i1;
         }
     } else {
-        const uint32_t *rr = reinterpret_cast<const uint32_t *>(recs);
-        const float2 *vv = reinterpret_cast<const float2 *>(rr + ((max_recs + 1) & ~(uint64_t)1));
-        uint32_t cr[UNR], nr[UNR]; float2 cv[UNR], nv[UNR];
+        const float4 *vv = reinterpret_cast<const float4 *>(rec_vals);
+        uint32_t cr[UNR], nr[UNR]; float4 cv[UNR], nv[UNR];
         uint32_t i0 = lo + threadIdx.x;
 #pragma unroll
-        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rr[i] : 0xFFFFFFFFu; cv[u] = ok ? vv[i] : make_float2(0.f, 0.f); }
+        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rec_rows[i] : NONE; cv[u] = ok ? vv[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
         while (i0 < hi) {
             const uint32_t i1 = i0 + GB_RTHREADS * UNR;
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rr[i] : 0xFFFFFFFFu; nv[u] = ok ? vv[i] : make_float2(0.f, 0.f); }
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rec_rows[i] : NONE; nv[u] = ok ? vv[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
-                if (cr[u] != 0xFFFFFFFFu) {
-                    atomicAdd(&acc[cr[u] * 2], (double)cv[u].x);
-                    atomicAdd(&acc[cr[u] * 2 + 1], (double)cv[u].y);
+                if (cr[u] != NONE) {
+                    const uint32_t r0 = cr[u] & (GB_SEG - 1u), r1 = (cr[u] >> 13) & (GB_SEG - 1u);
+                    atomicAdd(&acc[r0 * 2], (double)cv[u].x);
+                    atomicAdd(&acc[r0 * 2 + 1], (double)cv[u].y);
+                    atomicAdd(&acc[r1 * 2], (double)cv[u].z);
+                    atomicAdd(&acc[r1 * 2 + 1], (double)cv[u].w);
                 }
             }
 #pragma unroll
@@ -1170,16 +1186,18 @@ static int ge_tv_c(uint32_t C, const void *inputs, const void *emb, void *grad, 
 
 
 // ---- binned backward: host side --------------------------------------------------------------
-static uint64_t gb_max_recs(uint32_t B, uint32_t L) { return (uint64_t)B * 8u * L; }
+// records (pairs of corners along x) a pass can produce: 4 per (point, level), 5 when a pair straddles a segment boundary
+static uint64_t gb_max_recs(uint32_t B, uint32_t L) { return (uint64_t)B * 5u * L; }
+static uint64_t gb_rec_array_bytes(uint64_t m, int dtype) { return ((m + 3) & ~(uint64_t)3) * 4 + m * (dtype == FOC_F16 ? 8 : 16); }
 static uint64_t gb_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
     const uint64_t hdr = (sizeof(GbHeader) + 255) & ~(uint64_t)255;
     const uint64_t m = gb_max_recs(B, L);
     const uint64_t wg = (uint64_t)foc_div_up(B, GB_PM_TILE) * L * GB_MAX_SEGS * 4;      // per-workgroup counts / bases of the point-major passes
-    return hdr + (dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 256 + wg + 256;
+    return hdr + gb_rec_array_bytes(m, dtype) + 256 + wg + 256;
 }
 static uint64_t gb_recs_bytes(uint32_t B, uint32_t L, int dtype) {
     const uint64_t m = gb_max_recs(B, L);
-    return ((dtype == FOC_F16 ? m * 8 : ((m + 1) & ~(uint64_t)1) * 4 + m * 8) + 255) & ~(uint64_t)255;
+    return (gb_rec_array_bytes(m, dtype) + 255) & ~(uint64_t)255;
 }
 
 // The gradient-independent half of the pass (counts -> record ranges): needs the sample positions only, so a caller may run it ahead of
