@@ -11,6 +11,8 @@ stream and calls the C ABI of libfocnerf_hip.so (include/focnerf.h); a non-zero 
 becomes a RuntimeError, like TORCH_CHECK in the reference. Outputs are written in place
 into caller-allocated tensors, exactly as in the reference.
 """
+import math
+
 import torch
 
 from . import _lib
@@ -167,10 +169,11 @@ class _gridencoder:
         return _gridencoder._host_entry(offsets)[2]
 
     @staticmethod
-    def _binned_ok(offsets):
-        """The binned backward partitions a level into at most 64 segments of 8192 rows (log2_hashmap_size <= 19, the NeRF default);
-        larger tables take the scattered-atomic kernel."""
-        return _gridencoder._host_entry(offsets)[3] <= 8192 * 64
+    def _binned_ok(offsets, S, H, L, gridtype):
+        """The binned backward serves hash grids whose levels have at most 64 segments of 8192 rows (log2_hashmap_size <= 19, the NeRF
+        default) and a resolution below 8191 (gb_check in csrc/gridencoder.hip says why); everything else takes the scattered-atomic kernel."""
+        finest = math.ceil(2.0 ** (float(S) * (L - 1)) * H - 1.0) + 1
+        return gridtype == 0 and finest <= 8190 and _gridencoder._host_entry(offsets)[3] <= 8192 * 64
 
     # ---- the gradient-independent half of the binned backward (record counts -> record ranges), run ahead of time ----------------
     # It needs the sample positions only and is VALU/LDS work, while the forward gathers are bound by cache requests and leave the VALU
@@ -205,7 +208,7 @@ class _gridencoder:
         require_cuda(outputs); _contig(outputs)
         dt = dtype_code(embeddings)
         ws_bytes = lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
-        if not ws_bytes or B * 8 * L >= 2 ** 32 or B == 0 or not _gridencoder._binned_ok(offsets):
+        if not ws_bytes or B * 8 * L >= 2 ** 32 or B == 0 or not _gridencoder._binned_ok(offsets, S, H, L, gridtype):
             return None
         if outputs.dtype != embeddings.dtype or outputs.numel() != L * B * C:
             raise RuntimeError("grid_encode_forward_counted: outputs must be [L,B,C] of the embeddings' dtype")
@@ -244,7 +247,7 @@ class _gridencoder:
         # D=3, C=2 tables: partition + LDS accumulation instead of scattered atomics (FOCNERF_GRID_ATOMIC=1 forces the atomic kernel)
         import os
         ws_bytes = 0 if os.environ.get("FOCNERF_GRID_ATOMIC", "0") == "1" else lib.foc_grid_encode_backward_workspace_bytes(B, D, C, L, dt)
-        if ws_bytes and B * 8 * L < 2 ** 32 and _gridencoder._binned_ok(offsets):
+        if ws_bytes and B * 8 * L < 2 ** 32 and _gridencoder._binned_ok(offsets, S, H, L, gridtype):
             # persistent grow-only scratch (2 GB at B = 2M): a fresh torch.empty per call makes the caching allocator
             # re-malloc it whenever the freed block was split in between (measured: 28 ms hiccups per step)
             ws = _scratch.get("grid_bwd", ws_bytes, grad.device)

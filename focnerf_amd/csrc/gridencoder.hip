@@ -1320,8 +1320,8 @@ uint64_t foc_grid_encode_backward_workspace_bytes(uint32_t B, uint32_t D, uint32
     return gb_workspace_bytes(B, L, dtype);
 }
 
-static int gb_check(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t gridtype, uint32_t interp, int dtype, const int32_t *offsets_host,
-                    uint64_t workspace_bytes) {
+static int gb_check(uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, uint32_t interp, int dtype,
+                    const int32_t *offsets_host, uint64_t workspace_bytes) {
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grid_encode_backward_binned: dtype must be FOC_F32 or FOC_F16");
     FOC_REQUIRE(D == 3 && C == 2, FOC_E_INVALID, "grid_encode_backward_binned: only D=3, C=2 (got D=%u C=%u)", D, C);
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && gridtype <= 1 && interp <= 1, FOC_E_INVALID, "grid_encode_backward_binned: bad L/gridtype/interp");
@@ -1330,6 +1330,16 @@ static int gb_check(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t gri
     for (uint32_t l = 0; l < L; l++)
         FOC_REQUIRE((uint32_t)(offsets_host[l + 1] - offsets_host[l]) <= GB_SEG * GB_MAX_SEGS, FOC_E_INVALID,
                     "grid_encode_backward_binned: level %u has more than %u rows", l, GB_SEG * GB_MAX_SEGS);
+    // The scatter stages at most 5 two-corner records per point and level: a pair of corners along x splits into two records only when
+    // its rows straddle an 8192-row boundary, which on a hash grid at most one pair of a point can do — a dense level is at most
+    // 2^19 rows, so the pairs' rows differ by less than 8192 and not by a multiple of it; a hashed level's pairs split only at
+    // x = 8191 (mod 8192), which a resolution below that never reaches. Tiled grids and finer levels take the atomic kernel.
+    FOC_REQUIRE(gridtype == 0, FOC_E_INVALID, "grid_encode_backward_binned: hash grids only (gridtype 0); use foc_grid_encode_backward");
+    GeLevels lv;
+    ge_make_levels(L, S, H, lv);
+    for (uint32_t l = 0; l < L; l++)
+        FOC_REQUIRE(lv.resolution[l] <= GB_SEG - 2u, FOC_E_INVALID, "grid_encode_backward_binned: level %u has resolution %u (> %u)", l,
+                    lv.resolution[l], GB_SEG - 2u);
     return FOC_OK;
 }
 
@@ -1338,7 +1348,7 @@ int foc_grid_encode_backward_count(const float *inputs, const int32_t *offsets, 
                                    uint64_t workspace_bytes, void *stream) {
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && offsets && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_count: null pointer");
-    const int rc = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+    const int rc = gb_check(B, D, C, L, S, H, gridtype, interp, dtype, offsets_host, workspace_bytes);
     if (rc) return rc;
     GeLevels lv;
     ge_make_levels(L, S, H, lv);
@@ -1350,7 +1360,7 @@ int foc_grid_encode_forward_counted(const float *inputs, const void *embeddings,
                                     const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && embeddings && offsets && outputs && workspace && offsets_host, FOC_E_INVALID, "grid_encode_forward_counted: null pointer");
-    const int rc = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+    const int rc = gb_check(B, D, C, L, S, H, gridtype, interp, dtype, offsets_host, workspace_bytes);
     if (rc) return rc;
     GeLevels lv;
     ge_make_levels(L, S, H, lv);
@@ -1366,7 +1376,7 @@ static int gb_entry(const void *grad, const float *inputs, const int32_t *offset
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && inputs && offsets && grad_embeddings && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_binned: null pointer");
     {
-        const int rc0 = gb_check(B, D, C, L, gridtype, interp, dtype, offsets_host, workspace_bytes);
+        const int rc0 = gb_check(B, D, C, L, S, H, gridtype, interp, dtype, offsets_host, workspace_bytes);
         if (rc0) return rc0;
     }
     GeLevels lv;

@@ -468,3 +468,26 @@ def test_tables_beyond_the_binned_limit_take_the_atomic_kernel():
     assert torch.equal(h, h2)
     scale = g_fused.abs().max().item()
     assert (g_fused - enc.embeddings.grad).abs().max().item() <= 2e-2 * scale
+
+
+@pytest.mark.parametrize("what", ["tiled", "very_fine"])
+def test_grids_outside_the_two_corner_record_bound_take_the_atomic_kernel(what):
+    """The binned backward's staging holds 5 two-corner records per point and level, a bound that holds for hash grids with resolutions
+    below 8191 (csrc/gridencoder.hip, gb_check). Tiled D=3/C=2 grids and finer hash grids must be routed to the atomic kernel by the
+    wrapper and give the oracle's gradient."""
+    D, C, L, H = 3, 2, (4 if what == "tiled" else 12), 16
+    gridtype = 1 if what == "tiled" else 0
+    desired = 512 if what == "tiled" else 16384
+    pls, S, off, table = _setup(D, C, L, H, 15, desired, 1, np.float32)
+    B = 3000
+    x = _points(B, D, 8, oob=False)
+    grad = (np.random.default_rng(2).standard_normal((L, B, C)) * 0.1).astype(np.float32)
+    ref = oracle.grid_encode_backward(grad, x, off, int(off[-1]), D, C, L, S, H, None, gridtype, False, 0)
+    xt, tt, ot, gt = (torch.from_numpy(a).cuda() for a in (x, table, off, grad))
+    ge = torch.zeros_like(tt)
+    _be().grid_encode_backward(gt, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, False, 0)
+    got = to_np(ge)
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.abs(got - ref).max() <= 1e-5 * scale
+    out = torch.empty(L, B, C, dtype=torch.float32, device="cuda")
+    assert _be().grid_encode_forward_counted(xt, tt, ot, out, B, D, C, L, S, H, gridtype, False, 0) is None
