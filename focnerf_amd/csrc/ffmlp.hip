@@ -97,6 +97,7 @@ struct MlpHead {
     const _Float16 *ray_sh;        // [B / samples_per_ray, 16]
     const _Float16 *grad_h0;       // backward: [B], gradient of h[:,0] (the density path), merged into grad_h column 0
     uint32_t samples_per_ray;
+    uint32_t out_width;            // 16: [B,16] outputs / output gradients; 4: only columns 0..3 exist in memory ([B,4]: rgb logits + 1 pad)
 };
 // the loads and the shift are separate so that a prefetching caller can keep the raw dwords in flight
 __device__ __forceinline__ void ld_head_raw(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
@@ -320,7 +321,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
                     for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
                 }
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) store_tile<false>(outputs, 16, row0 + nb * 32 + c, B, 0, 16, o[nb], h);
+                for (int nb = 0; nb < NB; nb++) {
+                    if (IMODE == 2 && hd.out_width == 4u) {
+                        // of the colour network's 16 padded outputs only the rgb logits are ever read: lanes of half 0 hold neurons 0..3
+                        const uint64_t row = row0 + nb * 32 + c;
+                        if (h == 0 && row < B) {
+                            const h4 v = {(_Float16)o[nb][0], (_Float16)o[nb][1], (_Float16)o[nb][2], (_Float16)o[nb][3]};
+                            *reinterpret_cast<h4 *>(outputs + row * 4) = v;
+                        }
+                    } else store_tile<false>(outputs, 16, row0 + nb * 32 + c, B, 0, 16, o[nb], h);
+                }
             }
         }
     }
@@ -609,7 +619,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
         for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
             const uint32_t idx = lane + 64 * it, rr = idx >> 1, cc = (idx & 1) * 8;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < RW * 2 && r0 + rr < B) v = *reinterpret_cast<const h8 *>(grad + (r0 + rr) * 16 + cc);
+            if (idx < RW * 2 && r0 + rr < B) {
+                if (IMODE == 2 && hd.out_width == 4u) {      // [B,4] output gradients: columns 4..15 are zeros that were never written
+                    if (cc == 0) { const h4 q = *reinterpret_cast<const h4 *>(grad + (r0 + rr) * 4); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+                } else v = *reinterpret_cast<const h8 *>(grad + (r0 + rr) * 16 + cc);
+            }
             g_nxt[it] = v;
         }
 #pragma unroll
@@ -1200,7 +1214,7 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u});
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u, 16u});
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
@@ -1248,7 +1262,7 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
                        (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
-                       head ? *head : MlpHead{nullptr, nullptr, 1u});
+                       head ? *head : MlpHead{nullptr, nullptr, 1u, 16u});
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
     hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
     FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
@@ -1402,19 +1416,20 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
 
 // The colour network of the fixed-step training path, fed from the sigma network's output rows and a per-ray SH table (input mode 2).
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights, uint32_t B, uint32_t hidden_dim,
-                           uint32_t num_layers, uint32_t activation, void *outputs, void *stream) {
+                           uint32_t num_layers, uint32_t activation, void *outputs, uint32_t out_width, void *stream) {
     int rc = mlp_check("color_head_forward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(h && ray_sh && weights && outputs, FOC_E_INVALID, "color_head_forward: null pointer");
     FOC_REQUIRE(hidden_dim == 64 && samples_per_ray >= 1, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64 (got %u), samples_per_ray >= 1", hidden_dim);
-    const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray};
+    FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_forward: out_width must be 16 or 4 (got %u)", out_width);
+    const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray, out_width};
     return mlp_fwd_launch<64, false>(h, weights, B, 32, num_layers, activation == 0, nullptr, outputs, 0, (hipStream_t)stream, &hd);
 }
 
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
                             uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
-                            void *stream) {
+                            uint32_t out_width, void *stream) {
     int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     FOC_REQUIRE(hidden_dim == 64 && (num_layers == 2 || num_layers == 3) && samples_per_ray >= 1, FOC_E_INVALID,
@@ -1426,7 +1441,8 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
         return FOC_OK;
     }
     FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");
-    const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray};
+    FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_backward: out_width must be 16 or 4 (got %u)", out_width);
+    const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray, out_width};
     const int relu = activation == 0;
     if (num_layers == 2) return mlp_bwd_fused_launch<64, 2>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);
     return mlp_bwd_fused_launch<64, 3>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);

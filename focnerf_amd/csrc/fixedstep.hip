@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
                                                      const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
                                                      float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
                                                      float *__restrict__ sigma_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
-                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, uint32_t c_ld) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
         const bool valid = i < T;
         const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
         const float sigma = expf((float)h[s * 16]);                             // trunc_exp forward (activation.py:9)
-        const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+        const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * c_ld);
         const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
         float delta = g.sample_dist;
         if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
                                                      const _Float16 *__restrict__ c, const float *__restrict__ sigma_in, const float *__restrict__ trans_in,
                                                      const float *__restrict__ weights, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ noise, const float *__restrict__ bg_ray, float bg_scalar, uint32_t N, uint32_t T,
-                                                     float density_scale, float thresh, _Float16 *__restrict__ grad_c, _Float16 *__restrict__ grad_h0) {
+                                                     float density_scale, float thresh, _Float16 *__restrict__ grad_c, _Float16 *__restrict__ grad_h0, uint32_t c_ld) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -362,13 +362,16 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
 #pragma unroll
         for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
         if (w > thresh) {
-            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * 16);
+            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * c_ld);
             const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
             const float y0 = fs_sigmoid_h((float)cc[0]), y1 = fs_sigmoid_h((float)cc[1]), y2 = fs_sigmoid_h((float)cc[2]);
             gw += g0 * y0 + g1 * y1 + g2 * y2;
             o0[0] = foc_f2h(g0 * w * y0 * (1 - y0)); o0[1] = foc_f2h(g1 * w * y1 * (1 - y1)); o0[2] = foc_f2h(g2 * w * y2 * (1 - y2));
         }
-        if (valid) { h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16); dst[0] = o0; dst[1] = o1; }
+        if (valid) {
+            if (c_ld == 4u) *reinterpret_cast<uint2 *>(grad_c + s * 4) = *reinterpret_cast<const uint2 *>(&o0);     // rgb + 1 zero: the columns that exist
+            else { h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16); dst[0] = o0; dst[1] = o1; }
+        }
         // ---- density head backward (k_fs_head_bwd)
         const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
         float delta = g.sample_dist;
@@ -502,24 +505,26 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
 
 int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
                            uint32_t N, uint32_t T, float density_scale, float thresh, float *sigma, float *trans, float *weights, float *weights_sum,
-                           float *depth, float *image, void *stream) {
+                           float *depth, float *image, uint32_t c_width, void *stream) {
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_forward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(h && c && nears && fars && sigma && trans && weights && weights_sum && depth && image, FOC_E_INVALID, "fixed_tail_forward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_forward: T must be >= 2");
     hipLaunchKernelGGL(k_fs_tail_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, (const _Float16 *)c, nears, fars, noise,
-                       bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image);
+                       bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image, c_width);
     FOC_CHECK_LAUNCH("fixed_tail_forward");
     return FOC_OK;
 }
 
 int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c, const float *sigma, const float *trans,
                             const float *weights, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
-                            uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, void *stream) {
+                            uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width, void *stream) {
     if (N == 0) return FOC_OK;
+    FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_backward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(grad_image && c && sigma && trans && weights && nears && fars && grad_c && grad_h0, FOC_E_INVALID, "fixed_tail_backward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_backward: T must be >= 2");
     hipLaunchKernelGGL(k_fs_tail_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, grad_image, grad_ws, grad_depth, (const _Float16 *)c, sigma,
-                       trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0);
+                       trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0, c_width);
     FOC_CHECK_LAUNCH("fixed_tail_backward");
     return FOC_OK;
 }

@@ -128,9 +128,12 @@ def tail_fusable(model):
             and not getattr(model, "uses_object_feature", False) and os.environ.get("FOC_FUSED_TAIL", "1") != "0")
 
 
+_C_WIDTH = 4        # columns of the colour network's output that exist in memory on the fused tail (rgb logits + one pad)
+
+
 class _render_tail(Function):
     """Density head -> colour network -> composite as ONE node: h [M,16] half + the colour network's weight blob ->
-    image [N,3], weights_sum [N], depth [N] (+ sigma [M], weights [M], c [M,16], not differentiable).
+    image [N,3], weights_sum [N], depth [N] (+ sigma [M], weights [M], c [M,4] = rgb logits + one pad column, not differentiable).
 
     Same values and gradients as `_density_head` -> `FFMLP.forward_padded` -> `_fixed_composite`, bit for bit, without the colour
     network's input: its kernels read h and one SH row per ray (foc_color_head_forward), and in the backward pass the colour
@@ -147,8 +150,10 @@ class _render_tail(Function):
         dev, M = h.device, N * T
         st = stream_of(h)
         w16 = _half_of(cweights)
-        c = torch.empty(M, 16, dtype=torch.float16, device=dev)
-        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), st), "color_head_forward")
+        # of the colour network's 16 padded outputs only the rgb logits are ever read: they travel as [M,4] rows (as does their gradient)
+        c = torch.empty(M, _C_WIDTH, dtype=torch.float16, device=dev)
+        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), _C_WIDTH, st),
+              "color_head_forward")
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         trans = torch.empty(M, dtype=torch.float32, device=dev)
         weights = torch.empty(M, dtype=torch.float32, device=dev)
@@ -156,7 +161,7 @@ class _render_tail(Function):
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         check(lib.foc_fixed_tail_forward(ptr(h), ptr(c), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T, float(density_scale),
-                                         float(thresh), ptr(sigma), ptr(trans), ptr(weights), ptr(ws), ptr(depth), ptr(image), st), "fixed_tail_forward")
+                                         float(thresh), ptr(sigma), ptr(trans), ptr(weights), ptr(ws), ptr(depth), ptr(image), _C_WIDTH, st), "fixed_tail_forward")
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise if noise is not None else empty,
                               bg_ray if bg_ray is not None else empty)
@@ -181,12 +186,12 @@ class _render_tail(Function):
         grad_c = torch.empty_like(c)
         grad_h0 = torch.empty(M, dtype=torch.float16, device=dev)
         check(lib.foc_fixed_tail_backward(ptr(g_image), ptr(g_ws), ptr(g_depth), ptr(c), ptr(sigma), ptr(trans), ptr(weights), ptr(nears), ptr(fars),
-                                          ptr(noise), ptr(bg_ray), bg_scalar, N, T, ds, thresh, ptr(grad_c), ptr(grad_h0), st), "fixed_tail_backward")
+                                          ptr(noise), ptr(bg_ray), bg_scalar, N, T, ds, thresh, ptr(grad_c), ptr(grad_h0), _C_WIDTH, st), "fixed_tail_backward")
         grad_h = torch.empty_like(h)
         g_w = torch.empty_like(w16)
         wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(32, 64, num_layers), dev)
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
-                                          ptr(g_w), ptr(wsb), st), "color_head_backward")
+                                          ptr(g_w), ptr(wsb), _C_WIDTH, st), "color_head_backward")
         return (grad_h, g_w) + (None,) * 12
 
 
@@ -284,7 +289,10 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
                'criterion_outside_mask': criterion_outside_mask, 'timing': [t_mid - t_start, time.time() - t_mid]}
     if return_fields:
         from .head import rgb_head
-        rgb = rgb_head(c.detach()) * (weights > weight_thresh).unsqueeze(-1)     # half-rounded sigmoid, fp32 tensor (the composite's values)
+        c16 = c.detach()
+        if c16.shape[1] != 16:                                                    # fused tail: [M,4] logits -> the 16-wide rows rgb_head reads
+            c16 = torch.nn.functional.pad(c16, (0, 16 - c16.shape[1]))
+        rgb = rgb_head(c16) * (weights > weight_thresh).unsqueeze(-1)            # half-rounded sigmoid, fp32 tensor (the composite's values)
         results['densities'] = sigma.view(N, T, 1)
         results['rgbs'] = rgb.view(N, T, 3)
     return results

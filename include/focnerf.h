@@ -308,14 +308,16 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
  * input_dim 32, output_dim 16) on that cin. outputs [B,16] fp16.
  * Backward: grad [B,16] fp16 -> grad_weights (blob layout of foc_ffmlp_backward, same workspace) and grad_h [B,16] fp16 =
  * [grad_h0 | grad_cin[:,16:31]] with grad_h0 [B] fp16 (NULL = zeros) the density path's gradient of h[:,0]
- * (foc_fixed_head_backward) — the row the sigma network's backward consumes, written once. hidden_dim 64, 2 or 3 layers. */
+ * (foc_fixed_head_backward) — the row the sigma network's backward consumes, written once. hidden_dim 64, 2 or 3 layers.
+ * out_width 16: outputs / grad are [B,16]; 4: only the columns that are ever read exist, outputs / grad are [B,4] (of the 16 padded
+ * outputs of a 3-output network columns 0..2 are the rgb logits; the gradient of the others is zero by construction). */
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights,
                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
-                           void *outputs, void *stream);
+                           void *outputs, uint32_t out_width, void *stream);
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray,
                             const void *grad_h0, const void *weights, uint32_t B, uint32_t hidden_dim,
                             uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights,
-                            void *workspace, void *stream);
+                            void *workspace, uint32_t out_width, void *stream);
 
 /* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
  * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the
@@ -384,15 +386,18 @@ int foc_fixed_head_backward(const void *h, const float *sigma, const float *tran
 
 /* Training tail in one pass per direction (one wave per ray): foc_fixed_head_forward (cin NULL) + foc_fixed_composite_forward,
  * and foc_fixed_composite_backward + foc_fixed_head_backward (grad_h0 form) — the same bits as the pairs; the weights are not
- * re-read, their gradient never leaves the lane, and the backward does not read h (exp(clamp(h0,-15,15)) = clamp(sigma, ...)). */
+ * re-read, their gradient never leaves the lane, and the backward does not read h (exp(clamp(h0,-15,15)) = clamp(sigma, ...)).
+ * c_width 16: c and grad_c are [M,16] rows as above; 4: they are [M,4] (rgb logits + one pad column), the compact form
+ * foc_color_head_forward / _backward exchange with out_width 4. */
 int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise,
                            const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
                            float *sigma, float *trans, float *weights, float *weights_sum, float *depth, float *image,
-                           void *stream);
+                           uint32_t c_width, void *stream);
 int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c,
                             const float *sigma, const float *trans, const float *weights, const float *nears,
                             const float *fars, const float *noise, const float *bg_ray, float bg_scalar, uint32_t N,
-                            uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, void *stream);
+                            uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width,
+                            void *stream);
 
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL
