@@ -183,14 +183,18 @@ def sample_batch(poses, intr, device, gen):
     return rays_o, rays_d, target
 
 
-def train_step(model, opt, scaler, rays_o, rays_d, target, fused=True):
+def train_step(model, opt, scaler, rays_o, rays_d, target, fused=True, sched=None):
+    """One iteration of the reference trainer's loop (nerf/utils.py:1108-1119): zero_grad, autocast forward + loss, scaled backward,
+    GradScaler step + update, per-step LR schedule (its EMA update runs once per epoch, :1124, not per step)."""
+    opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.float16):
         out = model.render(rays_o, rays_d, staged=False, num_steps=NUM_STEPS, upsample_steps=0, perturb=True, bg_color=None, fused=fused)
         loss = torch.nn.functional.mse_loss(out["image"], target)
-    opt.zero_grad(set_to_none=True)
     scaler.scale(loss).backward()
     scaler.step(opt)
     scaler.update()
+    if sched is not None:
+        sched.step()
     return loss
 
 
@@ -302,6 +306,9 @@ def main():
     bound = 1
     model = build_model(bound, device, cuda_ray=False, seed=rank).train()
     opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    import warnings
+    warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before")     # a GradScaler-skipped first step
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / 30000, 1))              # main_nerf.py:477
     scaler = torch.amp.GradScaler("cuda")
     poses, intr = make_training_rays(device, bound, 8, seed=rank)
     gen = torch.Generator().manual_seed(1000 + rank)
@@ -317,13 +324,13 @@ def main():
     t_init = time.perf_counter()
     i = 0
     while i < 8 or (time.perf_counter() - t_init < 0.75 and i < 400):
-        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused)
+        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused, sched=sched)
         i += 1
         if i % 8 == 0:
             torch.cuda.synchronize()
     init_steps = i
     for i in range(args.warmup):
-        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused)
+        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused, sched=sched)
     barrier()
     timer.enabled = True
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -331,7 +338,7 @@ def main():
     t0 = time.perf_counter()
     step_marks[0].record()
     for i in range(args.steps):
-        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused)
+        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused, sched=sched)
         step_marks[i + 1].record()
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
