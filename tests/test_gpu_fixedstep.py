@@ -237,14 +237,17 @@ def test_amp_overflow_steps_are_detected_and_skipped():
     assert np.isfinite(losses).all()
 
 
+@pytest.mark.parametrize("c_width", [4, 16])
 @pytest.mark.parametrize("N,T,layers,perturb,bg", [(96, 512, 3, False, "scalar"), (37, 65, 3, True, "ray"), (50, 128, 2, False, "scalar"), (1, 2, 3, False, "scalar")])
-def test_render_tail_node_is_bitwise_the_three_node_chain(N, T, layers, perturb, bg):
+def test_render_tail_node_is_bitwise_the_three_node_chain(N, T, layers, perturb, bg, c_width, monkeypatch):
     """`_render_tail` (density head -> colour network fed from h and a per-ray SH row -> composite, one autograd node) against
     `_density_head` -> FFMLP.forward_padded -> `_fixed_composite`, which materialise the colour network's [M,32] input and its gradient:
     image, weights_sum, depth, sigma, weights, colour logits and grad_h must be the SAME BITS (every value of the colour input sits at
     the k position it has in the materialised row); the weight gradient differs only by the order of its fp32 atomics."""
     from focnerf_amd.ffmlp import FFMLP
+    from focnerf_amd import fixedstep
     from focnerf_amd.fixedstep import _density_head, _fixed_composite, _render_tail, ray_sh_rows
+    monkeypatch.setattr(fixedstep, "_C_WIDTH", c_width)        # colour logits as [M,4] (default) or full [M,16] rows: both ABI forms
     g = torch.Generator(device="cuda").manual_seed(N * 1000 + T)
     M = N * T
     h0 = (torch.randn(M, 16, generator=g, device="cuda") * 0.7).half()
