@@ -76,8 +76,8 @@ SIGNATURES = {
     "foc_fixed_sample": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp]),
     "foc_fixed_tail_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_fixed_tail_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, u32, c_vp]),
-    "foc_fixed_head_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp]),
-    "foc_fixed_head_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, u32, c_vp, c_vp]),
+    "foc_fixed_head_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
+    "foc_fixed_head_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, u32, c_vp]),
     "foc_color_head_forward": (i32, [c_vp, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, u32, c_vp]),
     "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_fixed_composite_forward": (i32, [c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp]),

@@ -95,8 +95,7 @@ __global__ void __launch_bounds__(256) k_fs_head_fwd(const _Float16 *__restrict_
                                                      const float *__restrict__ fars, const float *__restrict__ noise, uint32_t N, uint32_t T,
                                                      float density_scale, float *__restrict__ sigma_out, float *__restrict__ trans_out,
                                                      float *__restrict__ weights_out, float *__restrict__ weights_sum, float *__restrict__ depth,
-                                                     _Float16 *__restrict__ cin, const _Float16 *__restrict__ obj, uint32_t cin_ld,
-                                                     _Float16 *__restrict__ ray_sh) {
+                                                     _Float16 *__restrict__ cin, const _Float16 *__restrict__ obj, uint32_t cin_ld) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -104,12 +103,11 @@ __global__ void __launch_bounds__(256) k_fs_head_fwd(const _Float16 *__restrict_
     h8 shlo, shhi;
     h8 ob1 = {0, 0, 0, 0, 0, 0, 0, 0}, ob2 = {0, 0, 0, 0, 0, 0, 0, 0};   // cin columns 32..39 / 40..47 of the 48-wide form: obj[1..8], obj[9..15] | 0
     _Float16 ob0 = (_Float16)0;                                          // column 31: obj[0] (the 32-wide form has its zero pad there)
-    if (cin || ray_sh) {
+    if (cin) {
         float sh[16];
         fs_sh16(rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], sh);
 #pragma unroll
         for (int k = 0; k < 8; k++) { shlo[k] = foc_f2h(sh[k]); shhi[k] = foc_f2h(sh[8 + k]); }
-        if (ray_sh && lane == 0) { h8 *dst = reinterpret_cast<h8 *>(ray_sh + (uint64_t)n * 16); dst[0] = shlo; dst[1] = shhi; }
         if (obj) {
             ob0 = obj[0];
 #pragma unroll
@@ -175,7 +173,7 @@ __global__ void __launch_bounds__(256) k_fs_head_bwd(const _Float16 *__restrict_
                                                      const float *__restrict__ nears, const float *__restrict__ fars, const float *__restrict__ noise,
                                                      const float *__restrict__ grad_w, const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
                                                      const _Float16 *__restrict__ grad_cin, uint32_t N, uint32_t T, float density_scale,
-                                                     _Float16 *__restrict__ grad_h, uint32_t cin_ld, _Float16 *__restrict__ grad_h0) {
+                                                     _Float16 *__restrict__ grad_h, uint32_t cin_ld) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -205,8 +203,7 @@ __global__ void __launch_bounds__(256) k_fs_head_bwd(const _Float16 *__restrict_
         const float dsigma = dalpha * (delta * density_scale) * ex;
         const _Float16 h0 = h[s * 16];
         const float dh0 = dsigma * expf(fminf(fmaxf((float)h0, -15.0f), 15.0f));   // trunc_exp backward (activation.py:15)
-        if (valid && grad_h0) grad_h0[s] = foc_f2h(dh0);          // column 0 only: the colour network's backward writes the row (foc_color_head_backward)
-        else if (valid) {
+        if (valid) {
             h8 o0, o1;
             if (grad_cin) {
                 const h8 c2 = *reinterpret_cast<const h8 *>(grad_cin + s * cin_ld + 16), c3 = *reinterpret_cast<const h8 *>(grad_cin + s * cin_ld + 24);
@@ -458,27 +455,27 @@ int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *near
 
 int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars, const float *noise, uint32_t N, uint32_t T,
                            float density_scale, float *sigma, float *trans, float *weights, float *weights_sum, float *depth, void *cin,
-                           const void *obj_feat, uint32_t cin_width, void *ray_sh, void *stream) {
+                           const void *obj_feat, uint32_t cin_width, void *stream) {
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(h && rays_d && nears && fars && sigma && trans && weights && weights_sum && depth, FOC_E_INVALID, "fixed_head_forward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_forward: T must be >= 2");
     FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "fixed_head_forward: cin_width must be 32 or 48 (got %u)", cin_width);
     FOC_REQUIRE(!obj_feat || cin_width == 48, FOC_E_INVALID, "fixed_head_forward: an object feature needs the 48-wide colour input");
     hipLaunchKernelGGL(k_fs_head_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, rays_d, nears, fars, noise, N, T,
-                       density_scale, sigma, trans, weights, weights_sum, depth, (_Float16 *)cin, (const _Float16 *)obj_feat, cin_width, (_Float16 *)ray_sh);
+                       density_scale, sigma, trans, weights, weights_sum, depth, (_Float16 *)cin, (const _Float16 *)obj_feat, cin_width);
     FOC_CHECK_LAUNCH("fixed_head_forward");
     return FOC_OK;
 }
 
 int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears, const float *fars, const float *noise,
                             const float *grad_w, const float *grad_ws, const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
-                            float density_scale, void *grad_h, uint32_t cin_width, void *grad_h0, void *stream) {
+                            float density_scale, void *grad_h, uint32_t cin_width, void *stream) {
     if (N == 0) return FOC_OK;
-    FOC_REQUIRE(h && sigma && trans && nears && fars && (grad_h || grad_h0), FOC_E_INVALID, "fixed_head_backward: null pointer");
+    FOC_REQUIRE(h && sigma && trans && nears && fars && grad_h, FOC_E_INVALID, "fixed_head_backward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_backward: T must be >= 2");
     FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "fixed_head_backward: cin_width must be 32 or 48 (got %u)", cin_width);
     hipLaunchKernelGGL(k_fs_head_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, sigma, trans, nears, fars, noise,
-                       grad_w, grad_ws, grad_depth, (const _Float16 *)grad_cin, N, T, density_scale, (_Float16 *)grad_h, cin_width, (_Float16 *)grad_h0);
+                       grad_w, grad_ws, grad_depth, (const _Float16 *)grad_cin, N, T, density_scale, (_Float16 *)grad_h, cin_width);
     FOC_CHECK_LAUNCH("fixed_head_backward");
     return FOC_OK;
 }

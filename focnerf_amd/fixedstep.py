@@ -62,7 +62,7 @@ class _density_head(Function):
             assert obj_feat.numel() == 16
         cin = torch.empty(M, width, dtype=torch.float16, device=dev)
         check(lib.foc_fixed_head_forward(ptr(h), ptr(rays_d), ptr(nears), ptr(fars), ptr(noise), N, T, float(density_scale), ptr(sigma), ptr(trans),
-                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), ptr(obj_feat), width, None, stream_of(h)), "fixed_head_forward")
+                                         ptr(weights), ptr(ws), ptr(depth), ptr(cin), ptr(obj_feat), width, stream_of(h)), "fixed_head_forward")
         ctx.save_for_backward(h, sigma, trans, nears, fars, noise if noise is not None else torch.empty(0, device=dev))
         ctx.has_noise = noise is not None
         ctx.dims = (N, T, float(density_scale))
@@ -81,7 +81,7 @@ class _density_head(Function):
         g_cin = g_cin.contiguous().half() if g_cin is not None else None
         grad_h = torch.empty_like(h)
         check(lib.foc_fixed_head_backward(ptr(h), ptr(sigma), ptr(trans), ptr(nears), ptr(fars), ptr(noise), ptr(g_weights), ptr(g_ws), ptr(g_depth),
-                                          ptr(g_cin), N, T, ds, ptr(grad_h), ctx.width, None, stream_of(h)), "fixed_head_backward")
+                                          ptr(g_cin), N, T, ds, ptr(grad_h), ctx.width, stream_of(h)), "fixed_head_backward")
         g_obj = None
         if ctx.width == 48 and ctx.needs_input_grad[8] and g_cin is not None:
             g_obj = g_cin[:, 31:47].float().sum(0)                 # one feature vector feeds every sample

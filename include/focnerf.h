@@ -303,12 +303,12 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
 
 /* The colour network of a ray-ordered sample list without its materialised input (network_ff.py:104-108 builds
  * cin = [SH16(dir) | h[:,1:16] | 0] per sample, 64 B written and read twice): the kernels take the sigma network's output
- * rows h [B,16] fp16 and one SH row per ray, ray_sh [B / samples_per_ray, 16] fp16 (foc_fixed_head_forward), and place
+ * rows h [B,16] fp16 and one SH row per ray, ray_sh [B / samples_per_ray, 16] fp16 (foc_fixed_sample), and place
  * every value at the k position it has in cin — same bits as foc_ffmlp_forward / foc_ffmlp_backward (forward_buffer NULL,
  * input_dim 32, output_dim 16) on that cin. outputs [B,16] fp16.
  * Backward: grad [B,16] fp16 -> grad_weights (blob layout of foc_ffmlp_backward, same workspace) and grad_h [B,16] fp16 =
  * [grad_h0 | grad_cin[:,16:31]] with grad_h0 [B] fp16 (NULL = zeros) the density path's gradient of h[:,0]
- * (foc_fixed_head_backward) — the row the sigma network's backward consumes, written once. hidden_dim 64, 2 or 3 layers.
+ * (foc_fixed_tail_backward) — the row the sigma network's backward consumes, written once. hidden_dim 64, 2 or 3 layers.
  * out_width 16: outputs / grad are [B,16]; 4: only the columns that are ever read exist, outputs / grad are [B,4] (of the 16 padded
  * outputs of a 3-output network columns 0..2 are the rgb logits; the gradient of the others is zero by construction). */
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights,
@@ -372,20 +372,16 @@ int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *near
 int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars,
                            const float *noise, uint32_t N, uint32_t T, float density_scale,
                            float *sigma, float *trans, float *weights, float *weights_sum, float *depth,
-                           void *cin, const void *obj_feat, uint32_t cin_width, void *ray_sh, void *stream);
-/* ray_sh [N,16] fp16 or NULL: the SH values of each ray's direction as they stand in cin columns 0..15, for
- * foc_color_head_forward (which then needs no cin at all).
- * grad_w [M], grad_ws [N], grad_depth [N], grad_cin [M,cin_width] fp16 (each may be NULL) -> grad_h [M,16] fp16
- * (the object-feature gradient is the column sum of grad_cin[:,31:47], left to the caller).
- * grad_h0 [M] fp16 non-NULL: only the gradient of h[:,0] is written, there; grad_h and grad_cin are not touched
- * (foc_color_head_backward assembles the row). */
+                           void *cin, const void *obj_feat, uint32_t cin_width, void *stream);
+/* grad_w [M], grad_ws [N], grad_depth [N], grad_cin [M,cin_width] fp16 (each may be NULL) -> grad_h [M,16] fp16
+ * (the object-feature gradient is the column sum of grad_cin[:,31:47], left to the caller). */
 int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears,
                             const float *fars, const float *noise, const float *grad_w, const float *grad_ws,
                             const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
-                            float density_scale, void *grad_h, uint32_t cin_width, void *grad_h0, void *stream);
+                            float density_scale, void *grad_h, uint32_t cin_width, void *stream);
 
 /* Training tail in one pass per direction (one wave per ray): foc_fixed_head_forward (cin NULL) + foc_fixed_composite_forward,
- * and foc_fixed_composite_backward + foc_fixed_head_backward (grad_h0 form) — the same bits as the pairs; the weights are not
+ * and foc_fixed_composite_backward + column 0 of foc_fixed_head_backward (written as grad_h0 [M] fp16) — the same bits as the pairs; the weights are not
  * re-read, their gradient never leaves the lane, and the backward does not read h (exp(clamp(h0,-15,15)) = clamp(sigma, ...)).
  * c_width 16: c and grad_c are [M,16] rows as above; 4: they are [M,4] (rgb logits + one pad column), the compact form
  * foc_color_head_forward / _backward exchange with out_width 4. */
