@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h
 }
 
 template <int NLS, int NLC, bool PLANAR>
-__global__ void __launch_bounds__(MLP_BLOCK) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
+__global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
                                                           const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
                                                           int relu, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
     constexpr int HIDDEN = 64, MT = 2, KC = 4, NB = 2, IN = 32, KS0 = 2;
