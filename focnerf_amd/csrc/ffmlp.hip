@@ -1056,6 +1056,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
     };
     // one hidden stack: acc (pre-activation of layer 0) -> pre-activation of the output layer input; returns the B fragments of the last hidden layer
     auto hidden_stack = [&](f16v (&acc)[MT][NB], h8 (&bf)[KC][NB], const _Float16 *img, uint32_t f_hidden, int nl) {
+#pragma unroll 1
         for (int l = 1; l <= nl; l++) {
 #pragma unroll
             for (int kc = 0; kc < KC; kc++)
