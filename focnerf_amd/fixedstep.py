@@ -207,7 +207,7 @@ def _background(bg_color, N, dev):
 
 
 def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, bg_color=None, perturb=False, weight_thresh=1e-10,
-                       return_fields=None, **kwargs):
+                       return_fields=None, _out=None, **kwargs):
     """Drop-in for NeRFRenderer.run(..., upsample_steps=0) on a focnerf_amd NeRFNetwork (fp16 autocast semantics); same result
     dictionary (`return_fields` None = on in eval mode, like the reference's run(), off in training)."""
     import time
@@ -231,8 +231,11 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         # inference: sample -> encoder planes -> whole-field kernel -> weights + mask + composite kernel
         sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T)
         bg_ray, bg_scalar = _background(bg_color, N, dev)
-        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        # `_out` = (depth [N], image [N,3]) fp32 contiguous views of the caller's whole-view buffers (NeRFRenderer.render, staged)
+        direct = (_out is not None and _out[0].dtype == torch.float32 and _out[1].dtype == torch.float32 and _out[0].is_contiguous()
+                  and _out[1].is_contiguous() and _out[0].numel() == N and _out[1].numel() == 3 * N and _out[0].device == dev)
+        depth, image = (_out[0].view(N), _out[1].view(N, 3)) if direct else (torch.empty(N, dtype=torch.float32, device=dev),
+                                                                              torch.empty(N, 3, dtype=torch.float32, device=dev))
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
         rgb_masked = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if return_fields else None
         check(lib.foc_fixed_render_inference(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T,

@@ -257,8 +257,13 @@ class NeRFRenderer(nn.Module):
         for b in range(B):
             for lo in range(0, N, max_ray_batch):
                 hi = min(lo + max_ray_batch, N)
-                part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, **kwargs)
-                depth[b:b + 1, lo:hi], image[b:b + 1, lo:hi] = part['depth'], part['image']
+                # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
+                into = (depth[b, lo:hi], image[b, lo:hi])
+                part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, _out=into, **kwargs)
+                if part['depth'].data_ptr() != into[0].data_ptr():
+                    depth[b:b + 1, lo:hi] = part['depth']
+                if part['image'].data_ptr() != into[1].data_ptr():
+                    image[b:b + 1, lo:hi] = part['image']
                 if 'densities' in part:
                     if densities is None:
                         T = part['densities'].shape[1]
