@@ -413,12 +413,12 @@ def test_precounted_backward_and_stale_tickets(monkeypatch):
 
 
 @pytest.mark.parametrize("standalone", [False, True])
-@pytest.mark.parametrize("B", [1, 1000, 70001])
-def test_counted_forward_and_counted_backward_match_the_plain_calls(B, standalone):
+@pytest.mark.parametrize("B,L", [(1, 16), (1000, 16), (70001, 16), (5000, 2), (3000, 5)])
+def test_counted_forward_and_counted_backward_match_the_plain_calls(B, L, standalone):
     """foc_grid_encode_forward_counted (count pass riding in the forward launch) / foc_grid_encode_backward_count (its own launch) followed
     by foc_grid_encode_backward_binned_counted: same encoding bits and same gradient bits as the plain forward + binned backward."""
-    D, C, L, H = 3, 2, 16, 16
-    pls, S, off, table = _setup(D, C, L, H, 19, 2048, 1, np.float16)
+    D, C, H = 3, 2, 16
+    pls, S, off, table = _setup(D, C, L, H, 19, 2048 if L == 16 else 256, 1, np.float16)
     rng = np.random.default_rng(B)
     x = _points(B, D, 9) if B > 8 else rng.random((B, D)).astype(np.float32)
     g = (rng.standard_normal((L, B, C)) * 0.1).astype(np.float16)
