@@ -47,6 +47,21 @@ static inline uint32_t foc_grid_1d(uint64_t n, uint32_t block, uint32_t max_bloc
 // which differs from the two-step rounding in about one value in 2^13.
 __device__ __forceinline__ _Float16 foc_f2h(float v) { asm volatile("" : "+v"(v)); return (_Float16)v; }
 
+// Zero fill as a KERNEL. hipMemsetAsync must not be used in this library: captured into a HIP graph, its node fills with garbage from
+// the second replay on (ROCm 7.2 / gfx950: the first 8 KiB header of the binned grid backward came back as 0x4f20_2200_2b4c_3438-like
+// words that advance by the memset size per replay, tools/_diag: counts of 5 * 10^11 records and an out-of-bounds read in the reduce).
+__global__ static void __launch_bounds__(256) k_foc_zero(uint32_t *__restrict__ p, uint64_t n_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline hipError_t foc_zero_async(void *p, size_t bytes, hipStream_t st) {       // p 4-byte aligned, bytes a multiple of 4
+    const uint64_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_foc_zero, dim3((uint32_t)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), n);
+    return hipGetLastError();
+}
+
 // wave64 reductions / scans via DPP-backed shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1275,7 +1275,7 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
-    if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
+    if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t grid = foc_div_up(B, 4 * RW);
     const uint32_t cap = mlp_num_cus() * 2;
     if (grid > cap) grid = cap;
@@ -1321,7 +1321,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     FOC_CHECK_LAUNCH("ffmlp_backward(activations)");
     // weight gradients
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
-    if (hipMemsetAsync(ws, 0, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
+    if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t gx = foc_div_up(B, DW_CHUNK);
     static int wgs_per_cu = 0;                   // split-K workgroups per CU over all layers (FOC_DW_WGS_PER_CU overrides, for tuning)
     if (!wgs_per_cu) { const char *e = getenv("FOC_DW_WGS_PER_CU"); wgs_per_cu = e ? atoi(e) : 8; if (wgs_per_cu < 1) wgs_per_cu = 1; }
@@ -1379,7 +1379,7 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
     if (B == 0) {                                   // empty batch (null data pointers): the weight gradient is all zeros
         FOC_REQUIRE(grad_weights, FOC_E_INVALID, "ffmlp_backward: null pointer");
         const size_t n_w = (size_t)hidden_dim * (input_dim + (size_t)hidden_dim * (num_layers - 1) + 16);
-        if (hipMemsetAsync(grad_weights, 0, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("ffmlp_backward: memset failed"); return FOC_E_LAUNCH; }
+        if (foc_zero_async(grad_weights, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("ffmlp_backward: memset failed"); return FOC_E_LAUNCH; }
         return FOC_OK;
     }
     FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
@@ -1456,7 +1456,7 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
     if (B == 0) {
         FOC_REQUIRE(grad_weights, FOC_E_INVALID, "color_head_backward: null pointer");
         const size_t n_w = (size_t)64 * (32 + (size_t)64 * (num_layers - 1) + 16);
-        if (hipMemsetAsync(grad_weights, 0, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("color_head_backward: memset failed"); return FOC_E_LAUNCH; }
+        if (foc_zero_async(grad_weights, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("color_head_backward: memset failed"); return FOC_E_LAUNCH; }
         return FOC_OK;
     }
     FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");

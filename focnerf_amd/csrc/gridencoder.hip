@@ -871,8 +871,10 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
         const uint32_t c = blockIdx.x - hdr->chunk_prefix[lo];
         const uint32_t cnt = hdr->counts[lo];
         s_slot = lo;
-        s_lo = hdr->base[lo] + c * GB_CHUNK;
-        s_hi = hdr->base[lo] + min(cnt, (c + 1) * GB_CHUNK);
+        // clamped to the record arrays: a header that does not belong to these records must not turn into an out-of-bounds read
+        const uint64_t b0 = hdr->base[lo];
+        s_lo = (uint32_t)min(b0 + (uint64_t)c * GB_CHUNK, max_recs);
+        s_hi = (uint32_t)min(b0 + min(cnt, (c + 1) * GB_CHUNK), max_recs);
     }
     for (uint32_t i = threadIdx.x; i < GB_SEG * 2; i += GB_RTHREADS) acc[i] = 0.0;
     if (threadIdx.x < GB_SEG / 32) s_bad[threadIdx.x] = 0u;
@@ -1206,7 +1208,7 @@ static int gb_count(const float *inputs, const int32_t *offsets, uint32_t B, uin
                     int dtype, void *workspace, hipStream_t st) {
     GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
-    if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
+    if (foc_zero_async(hdr->counts, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_backward: memset failed"); return FOC_E_LAUNCH; }
     const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, dtype));
     hipLaunchKernelGGL(k_gbin_count_pt, dim3(n_wg), dim3(GB_PMS_WG), 0, st, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, ac, interp);
@@ -1222,7 +1224,7 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
                               uint32_t gridtype, bool ac, uint32_t interp, void *workspace, hipStream_t st) {
     GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
-    if (hipMemsetAsync(hdr->counts, 0, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_forward_counted: memset failed"); return FOC_E_LAUNCH; }
+    if (foc_zero_async(hdr->counts, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_forward_counted: memset failed"); return FOC_E_LAUNCH; }
     const uint32_t n_tiles = foc_div_up(B, GB_PM_TILE), chunks = foc_div_up(B, 256);
     const uint32_t fwd_blocks = chunks * L;
     const uint32_t lo = L >= 4 ? L / 2 : 0, hi = L >= 4 ? L - 1 : L;          // levels whose workgroups the counting ones are spread over

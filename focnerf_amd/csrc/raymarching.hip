@@ -656,7 +656,7 @@ int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out,
     FOC_REQUIRE(n_out && scratch, FOC_E_INVALID, "compact_alive: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nb = foc_div_up(n_alive, 1024);
-    if (n_alive == 0) { (void)hipMemsetAsync(n_out, 0, sizeof(int32_t), st); return FOC_OK; }
+    if (n_alive == 0) { (void)foc_zero_async(n_out, sizeof(int32_t), st); return FOC_OK; }
     FOC_REQUIRE(rays_alive && out, FOC_E_INVALID, "compact_alive: null pointer");
     hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(1024), 0, st, rays_alive, n_alive, scratch);
     FOC_CHECK_LAUNCH("compact_alive(count)");

@@ -63,7 +63,8 @@ class _hashgrid_mlp(Function):
         w = _half_of(weights)                                   # ffmlp.py:23: custom_fwd(cast_inputs=half)
         enc = torch.empty(L, B, 2, device=x.device, dtype=torch.half)
         # training: the backward's count pass rides along in the forward launch (backend.grid_encode_forward_counted)
-        ticket = _gridencoder.grid_encode_forward_counted(x, emb, offsets, enc, B, 3, 2, L, S, H, gridtype, align_corners, interp) if training else None
+        ticket = _gridencoder.grid_encode_forward_counted(x, emb, offsets, enc, B, 3, 2, L, S, H, gridtype, align_corners, interp,
+                                                          standalone=os.environ.get("FOC_GRID_PRECOUNT", "1") == "2") if training else None
         if ticket is None:
             _gridencoder.grid_encode_forward(x, emb, offsets, enc, B, 3, 2, L, S, H, None, gridtype, align_corners, interp)
         h = torch.empty(B, 16, device=x.device, dtype=torch.half)

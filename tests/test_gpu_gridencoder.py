@@ -491,3 +491,48 @@ def test_grids_outside_the_two_corner_record_bound_take_the_atomic_kernel(what):
     assert scale > 0 and np.abs(got - ref).max() <= 1e-5 * scale
     out = torch.empty(L, B, C, dtype=torch.float32, device="cuda")
     assert _be().grid_encode_forward_counted(xt, tt, ot, out, B, D, C, L, S, H, gridtype, False, 0) is None
+
+
+def test_encoder_mlp_node_replays_in_a_hip_graph_with_new_data():
+    """Forward (count pass riding along) + backward of the encoder -> MLP node captured once and replayed on other inputs: the record
+    counts, the table gradient and the weight gradient must follow the data of each replay. Guards the zero fills inside the library:
+    as hipMemsetAsync nodes they came back with a garbage fill value from the second replay on (ROCm 7.2), the header held ~5 * 10^11
+    'records' and the reduce read out of bounds; they are kernels now (csrc/common.h, foc_zero_async)."""
+    from focnerf_amd.field import hashgrid_mlp
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(1)
+    m = NeRFNetwork(bound=1).cuda().train()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    B = 6000
+    xs = [torch.rand(B, 3, device="cuda") * 2 - 1 for _ in range(4)]
+
+    def step(x):
+        m.encoder.embeddings.grad = None
+        m.sigma_net.weights.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            h = hashgrid_mlp(m.encoder, m.sigma_net, x, 1)
+        (h.float() ** 2).sum().backward()
+        return m.encoder.embeddings.grad, m.sigma_net.weights.grad
+
+    want = []
+    for x in xs:
+        ge, gw = step(x)
+        want.append((ge.clone(), gw.clone()))
+    static_x = xs[0].clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step(static_x)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ge_s, gw_s = step(static_x)
+    for rounds in range(2):                                  # every input twice: nothing may carry over between replays
+        for x, (ge, gw) in zip(xs, want):
+            static_x.copy_(x)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(ge_s, ge), f"table gradient, round {rounds}"
+            scale = gw.abs().max().item()
+            assert (gw_s.float() - gw.float()).abs().max().item() <= 2e-3 * scale, f"weight gradient, round {rounds}"
