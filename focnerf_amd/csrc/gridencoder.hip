@@ -293,6 +293,18 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     }
 }
 
+// Encoding workgroup f of a plain level walk -> chunk of 256 points and the range of levels it encodes: the `lc` leading levels (the
+// small dense tables, 1.4 MiB together for the default grid) are done by ONE workgroup per chunk, which loads its points once; the
+// levels from `lc` up follow one at a time. At those small levels a launch moves 12 bytes of position per 4 bytes of result: what
+// they cost is reading the positions (0.015 ms per level and 2 M points), not the gathers.
+__device__ __forceinline__ void ge_walk(uint32_t f, uint32_t chunks, uint32_t lc, uint32_t &chunk, uint32_t &l0, uint32_t &l1) {
+    const uint32_t grp = f / chunks;
+    chunk = f - grp * chunks;
+    if (lc < 2u) { l0 = grp; l1 = grp + 1u; }
+    else if (grp == 0u) { l0 = 0u; l1 = lc; }
+    else { l0 = lc + grp - 1u; l1 = l0 + 1u; }
+}
+
 // Level-major launch, outputs [L,B,C]: thread = point. `plain`: blocks are numbered level by level, so the whole chip walks ONE
 // level at a time and every XCD's 4 MiB L2 holds that level's table (<= 2 MiB at 2^19 x half2); otherwise a level is pinned to one
 // XCD (ge_decode_block), which balances badly because the cost of a level grows ~5x from level 0 to 15 (tools/time_levels.py).
@@ -301,23 +313,25 @@ __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ 
                                                       const int32_t *__restrict__ offsets, T *__restrict__ outputs,
                                                       uint32_t B, uint32_t L, GeLevels lv, T *__restrict__ dy_dx,
                                                       uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t chunks, uint32_t plain,
-                                                      uint32_t pairs) {
-    uint32_t level, chunk;
-    if (plain) { level = blockIdx.x / chunks; chunk = blockIdx.x - level * chunks; }
-    else if (!ge_decode_block(blockIdx.x, chunks, L, level, chunk)) return;
+                                                      uint32_t pairs, uint32_t lc) {
+    uint32_t chunk, l0, l1;
+    if (plain) ge_walk(blockIdx.x, chunks, lc, chunk, l0, l1);
+    else { if (!ge_decode_block(blockIdx.x, chunks, L, l0, chunk)) return; l1 = l0 + 1u; }
     const uint32_t b = chunk * 256 + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    if (b >= B || l0 >= L) return;
     float x[D];
     const bool oob = ge_load_point<D>(inputs, b, x);
-    T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
-    if (pairs && ((off0 | hashmap_size) & 1u) == 0u)                           // row pairs of this level are 8-byte aligned and inside it
-        ge_forward_one<T, D, C, true>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                                      outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
-    else
-        ge_forward_one<T, D, C, false>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                                       outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+    for (uint32_t level = l0; level < l1; level++) {
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+        T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
+        if (pairs && ((off0 | hashmap_size) & 1u) == 0u)                       // row pairs of this level are 8-byte aligned and inside it
+            ge_forward_one<T, D, C, true>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                                          outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+        else
+            ge_forward_one<T, D, C, false>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
+                                           outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+    }
 }
 
 // Point-major launch, outputs [B, L*C]: consecutive lanes = consecutive levels of one point, so
@@ -654,7 +668,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restrict__ inputs, const T *__restrict__ grid, const int32_t *__restrict__ offsets,
                                                           T *__restrict__ outputs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners,
                                                           uint32_t interp, uint32_t chunks, bool pairs, GbHeader *__restrict__ hdr,
-                                                          uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0) {
+                                                          uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0, uint32_t lc) {
     __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
     // the counting workgroups sit among the encoding workgroups of the FINE levels (from block w0 on, one in `period`): those are the
     // request-bound ones; the coarse levels are instruction-bound themselves, and the last level is left alone so that no long-running
@@ -668,19 +682,22 @@ __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restric
         }
         f = blockIdx.x - min(q, n_tiles);
     }
-    const uint32_t level = f / chunks, chunk = f - level * chunks;
+    uint32_t chunk, l0, l1;
+    ge_walk(f, chunks, lc, chunk, l0, l1);
     const uint32_t b = chunk * 256 + threadIdx.x;
-    if (level >= L || b >= B) return;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    if (l0 >= L || b >= B) return;
     float x[3];
     const bool oob = ge_load_point<3>(inputs, b, x);
-    if (pairs && ((off0 | hashmap_size) & 1u) == 0u)
-        ge_forward_one<T, 3, 2, true>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
-                                      outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
-    else
-        ge_forward_one<T, 3, 2, false>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
-                                       outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
+    for (uint32_t level = l0; level < l1; level++) {
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+        if (pairs && ((off0 | hashmap_size) & 1u) == 0u)
+            ge_forward_one<T, 3, 2, true>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
+                                          outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
+        else
+            ge_forward_one<T, 3, 2, false>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
+                                           outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
+    }
 }
 
 // Level-sequential, LDS-sorted scatter, one point per thread (1024-thread workgroups, two per CU for fp16 tables).
@@ -1066,6 +1083,17 @@ static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
 
 static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * chunks * ((L + 7u) / 8u); }
 
+// Leading levels encoded by one workgroup per chunk (ge_walk): dense tables of at most 2^18 rows each (resolution <= 63), at most
+// L / 2 of them; fewer than two -> plain walk. FOC_GRID_FUSE_SMALL=0 switches it off.
+static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("FOC_GRID_FUSE_SMALL"); on = e ? atoi(e) : 1; }
+    if (!on) return 0u;
+    uint32_t lc = 0;
+    while (lc < L / 2 && lv.resolution[lc] <= 63u) lc++;
+    return lc >= 2u ? lc : 0u;
+}
+
 // FOC_GRID_PAIRS=0: one 4-byte load per corner (A/B runs). 16-byte groups of 4 rows (which would also cover x = 1 mod 4 on a hashed
 // level) were measured SLOWER: 0.064 vs 0.052 ms per 2 M random points and level — the 16-byte gather is not free like the 8-byte one.
 static bool ge_pairs_enabled() {
@@ -1086,9 +1114,11 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
                            (T *)dy_dx, gridtype, ac, interp);
     } else {
         const uint32_t chunks = foc_div_up(B, 256);
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * L : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+        const uint32_t lc = lm_plain ? ge_small_levels(L, lv) : 0u;
+        const uint32_t groups = lc >= 2u ? L - lc + 1u : L;
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,
-                           (ge_pairs_enabled() && ((uintptr_t)emb & 7u) == 0u && !dy_dx) ? 1u : 0u);
+                           (ge_pairs_enabled() && ((uintptr_t)emb & 7u) == 0u && !dy_dx) ? 1u : 0u, lc);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
     return FOC_OK;
@@ -1226,12 +1256,14 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
     if (foc_zero_async(hdr->counts, sizeof(hdr->counts), st) != hipSuccess) { foc_set_error("grid_encode_forward_counted: memset failed"); return FOC_E_LAUNCH; }
     const uint32_t n_tiles = foc_div_up(B, GB_PM_TILE), chunks = foc_div_up(B, 256);
-    const uint32_t fwd_blocks = chunks * L;
-    const uint32_t lo = L >= 4 ? L / 2 : 0, hi = L >= 4 ? L - 1 : L;          // levels whose workgroups the counting ones are spread over
+    const uint32_t lc = ge_small_levels(L, lv);
+    const uint32_t groups = lc >= 2u ? L - lc + 1u : L;                          // the small levels are one group of workgroups
+    const uint32_t fwd_blocks = chunks * groups;
+    const uint32_t lo = groups >= 4 ? groups / 2 : 0, hi = groups >= 4 ? groups - 1 : groups;   // groups whose workgroups the counting ones are spread over
     const uint32_t w0 = lo * chunks, period = ((hi - lo) * chunks) / n_tiles + 1u;
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
     hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
-                       interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0);
+                       interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0, lc);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted");
     hipLaunchKernelGGL(k_gbin_scans, dim3(L * GB_MAX_SEGS + 1), dim3(256), 0, st, hdr, wg_hist, n_tiles, L);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted(scans)");
