@@ -1083,14 +1083,16 @@ static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
 
 static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * chunks * ((L + 7u) / 8u); }
 
-// Leading levels encoded by one workgroup per chunk (ge_walk): dense tables of at most 2^18 rows each (resolution <= 63), at most
-// L / 2 of them; fewer than two -> plain walk. FOC_GRID_FUSE_SMALL=0 switches it off.
+// Leading levels encoded by one workgroup per chunk (ge_walk): resolution <= 160 and at most L / 2 of them; fewer than two -> plain
+// walk. Measured on FOC's 16-level grid (forward + count, 2 M points): threshold 63 0.358 ms, 120 0.353, 160 0.350 (8 levels),
+// 250 without the L / 2 cap 0.353, 600 0.422, every level 0.640. FOC_GRID_FUSE_SMALL=0 switches it off.
 static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
     static int on = -1;
     if (on < 0) { const char *e = getenv("FOC_GRID_FUSE_SMALL"); on = e ? atoi(e) : 1; }
     if (!on) return 0u;
+    const uint32_t finest = on > 1 ? (uint32_t)on : 160u;            // a value above 1 is taken as the resolution threshold (A/B runs)
     uint32_t lc = 0;
-    while (lc < L / 2 && lv.resolution[lc] <= 63u) lc++;
+    while (lc < L / 2 && lv.resolution[lc] <= finest) lc++;
     return lc >= 2u ? lc : 0u;
 }
 
@@ -1260,7 +1262,9 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     const uint32_t groups = lc >= 2u ? L - lc + 1u : L;                          // the small levels are one group of workgroups
     const uint32_t fwd_blocks = chunks * groups;
     const uint32_t lo = groups >= 4 ? groups / 2 : 0, hi = groups >= 4 ? groups - 1 : groups;   // groups whose workgroups the counting ones are spread over
-    const uint32_t w0 = lo * chunks, period = ((hi - lo) * chunks) / n_tiles + 1u;
+    // an ODD period: workgroups go to the 8 XCDs round-robin, so an even one puts every counting workgroup on the same 1, 2 or 4 XCDs
+    // (period 16, which any B that is not a multiple of 1024 gave for 4 host groups, made this launch 3-4x slower than for B = k * 1024)
+    const uint32_t w0 = lo * chunks, fit = ((hi - lo) * chunks) / n_tiles + 1u, period = (fit & 1u) ? fit : fit - 1u;
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
     hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
                        interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0, lc);
