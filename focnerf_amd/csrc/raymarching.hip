@@ -172,12 +172,17 @@ __device__ __forceinline__ bool rm_cell(const uint8_t *__restrict__ grid, const 
 }
 
 // Empty cell: jump to the voxel exit (:389-398).
-__device__ __forceinline__ float rm_skip(const RmParams &p, const RmCell &c, float t, float dx, float dy, float dz,
-                                         float rdx, float rdy, float rdz) {
+__device__ __forceinline__ float rm_skip_target(const RmParams &p, const RmCell &c, float t, float dx, float dy, float dz,
+                                                float rdx, float rdy, float rdz) {
     const float tx = fmaf(fmaf(fmaf(0.5f, rm_sign(dx), (float)c.nx + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.x) * rdx;
     const float ty = fmaf(fmaf(fmaf(0.5f, rm_sign(dy), (float)c.ny + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.y) * rdy;
     const float tz = fmaf(fmaf(fmaf(0.5f, rm_sign(dz), (float)c.nz + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.z) * rdz;
-    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+
+__device__ __forceinline__ float rm_skip(const RmParams &p, const RmCell &c, float t, float dx, float dy, float dz,
+                                         float rdx, float rdy, float rdz) {
+    const float tt = rm_skip_target(p, c, t, dx, dy, dz, rdx, rdy, rdz);
     do { t += rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max); } while (t < tt);
     return t;
 }
@@ -219,6 +224,86 @@ __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ ra
         else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
     }
     counts[n] = (int32_t)num_steps;
+}
+
+// ---------------------------------------------------------------- R6 pass 1, one WAVE per ray
+// The loop above is a chain of dependent cell lookups, one ray per lane: with 4096 rays that is 64 waves, each as slow as its longest
+// ray (0.135 ms per training batch). But the values `t` can take do not depend on the occupancy grid at all: both branches advance it
+// by t += clamp(t * dt_gamma, dt_min, dt_max) (:385 and :397), so every ray walks a fixed lattice t_0, t_1, ... and the grid only
+// decides which lattice points are visited and which of those are emitted. Here a wave takes 64 consecutive lattice points of ONE ray
+// (lane j = point j, generated with the loop's own expression), looks all 64 cells up at once, and then replays the loop's control
+// flow on wave-uniform bit masks: an occupied visited point emits and moves to the next lane, an empty one moves to the first lane
+// whose t is not below its voxel exit (carried into the next 64 points when there is none). Same visits, same emitted t, bit for bit.
+#define RM_MAX_ROUNDS (1u << 22)                           // x 64 lattice points: far beyond any real ray; makes the loop finite whatever the inputs
+__global__ void __launch_bounds__(256) k_march_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                              const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
+                              const float *__restrict__ nears, const float *__restrict__ fars,
+                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (n >= N) return;                                    // whole wave
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float far = fars[n];
+    float t_cur = nears[n];
+    t_cur = fmaf(rm_clamp(t_cur * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t_cur);
+    float *strip = tstrip + (uint64_t)n * max_steps;
+    uint32_t num_steps = 0;
+    bool skipping = false;                                 // inside the do-while of an empty cell whose exit `skip_to` lies beyond the last 64 points
+    float skip_to = 0.0f;
+    for (uint32_t round = 0; round < RM_MAX_ROUNDS; round++) {
+        // lane j: t_cur advanced j times. Every lane runs the same recurrence; each new value enters at lane 63 while the earlier
+        // ones move down one lane (DPP wave_shl:1), so the 64th insertion leaves value j in lane j and costs one move per step.
+        float T = t_cur, t_next = t_cur;
+#pragma unroll 8
+        for (uint32_t j = 0; j < 64; j++) {
+            T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
+            t_next += rm_clamp(t_next * p.dt_gamma, p.dt_min, p.dt_max);
+        }
+        const uint64_t in_range = __ballot(T < far);
+        uint32_t k = 0;                                    // lane of the lattice point the loop is at
+        if (skipping) {
+            const uint64_t landed = __ballot(!(T < skip_to));
+            if (landed == 0ull) {
+                if (!((in_range >> 63) & 1ull)) break;     // t only grows: wherever the skip lands, it is beyond `far`
+                t_cur = t_next;
+                continue;
+            }
+            k = (uint32_t)__builtin_ctzll(landed);
+            skipping = false;
+        }
+        RmCell c;
+        const bool occupied_here = rm_cell(grid, p, ox, oy, oz, dx, dy, dz, T, c);
+        const float exit_here = rm_skip_target(p, c, T, dx, dy, dz, rdx, rdy, rdz);
+        const uint64_t emit_ok = __ballot(occupied_here) & in_range;
+        uint64_t emitted = 0ull;
+        uint32_t room = max_steps - num_steps;             // > 0 here
+        bool done = false;
+        while (k < 64u) {
+            if (!((in_range >> k) & 1ull) || room == 0u) { done = true; break; }       // the loop condition of :359
+            if ((emit_ok >> k) & 1ull) {                   // a run of occupied points: each emits and steps to its successor
+                const uint64_t rest = ~(emit_ok >> k);     // bit 0 clear
+                uint32_t len = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - k;
+                len = len < 64u - k ? len : 64u - k;
+                len = len < room ? len : room;
+                emitted |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << k;
+                room -= len;
+                k += len;
+            } else {
+                const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, exit_here), (int)k));
+                const uint64_t above = k >= 63u ? 0ull : (~0ull << (k + 1u));
+                const uint64_t landed = __ballot(!(T < tt)) & above;                    // do { advance } while (t < tt): at least one advance
+                if (landed == 0ull) { skipping = true; skip_to = tt; break; }
+                k = (uint32_t)__builtin_ctzll(landed);
+            }
+        }
+        if ((emitted >> lane) & 1ull) strip[num_steps + (uint32_t)__builtin_popcountll(emitted & ((1ull << lane) - 1ull))] = T;
+        num_steps += (uint32_t)__builtin_popcountll(emitted);
+        if (done) break;
+        t_cur = t_next;
+    }
+    if (lane == 0) counts[n] = (int32_t)num_steps;
 }
 
 // ---------------------------------------------------------------- R6 pass 2: ordered slot reservation
@@ -582,7 +667,13 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     hipStream_t st = (hipStream_t)stream;
     float *tstrip = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + rm_strip_offset(N));
-    hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
+    static int serial = -1;                                // FOC_MARCH_SERIAL=1: one ray per lane (A/B runs and the parity test of the two)
+    if (serial < 0) { const char *e = getenv("FOC_MARCH_SERIAL"); serial = e ? atoi(e) : 0; }
+    if (serial)
+        hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
+    else
+        hipLaunchKernelGGL(k_march_count_wave, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch,
+                           tstrip);
     FOC_CHECK_LAUNCH("march_rays_train(count)");
     // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.

@@ -111,6 +111,39 @@ def test_march_rays_train_bit_exact(rm, bound, dt_gamma, perturb):
         assert np.array_equal(r[:, 0], np.arange(N)) and np.array_equal(r[:, 1], np.concatenate([[0], np.cumsum(r[:-1, 2])]))
 
 
+@pytest.mark.parametrize("bound,dt_gamma,max_steps,fill", [(1, 0.0, 1024, 0.5), (2, 1 / 128, 100, 0.5), (2, 1 / 256, 64, 0.9), (4, 1 / 32, 333, 0.1),
+                                                            (1, 0.0, 7, 1.0)])
+def test_march_rays_train_random_occupancy_bit_exact(rm, bound, dt_gamma, max_steps, fill):
+    """The wave-per-ray marcher replays the serial loop's control flow on bit masks: a random occupancy grid (cells flip every step or
+    two), the step cap reached inside a block of 64 lattice points, axis-parallel rays (1/d = inf) and rays that miss the box."""
+    from focnerf_amd.backend import _raymarching as be
+    N = 1024
+    s, n_ref, f_ref, noises = _march_case(bound, N, dt_gamma, True, seed=11)
+    C, H = s["cascade"], 128
+    g = torch.Generator().manual_seed(5)
+    bits = (torch.rand(C * H ** 3 // 8, 8, generator=g) < fill).to(torch.uint8)
+    bits = (bits << torch.arange(8, dtype=torch.uint8)).sum(dim=1).to(torch.uint8)
+    rays_o, rays_d = s["rays_o"].clone(), s["rays_d"].clone()
+    rays_d[:8] = torch.tensor([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.6, -0.8]]).repeat(2, 1)   # zero components
+    rays_o[:8] = torch.tensor([[0.1, -0.2, 0.9 * bound], [0.3, -0.9 * bound, 0.1], [0.9 * bound, 0.2, -0.1], [0.0, -0.5 * bound, 0.6 * bound]]).repeat(2, 1)
+    rays_o[8:12] += 10 * bound                                                                                       # miss the box
+    n_ref, f_ref = oracle.near_far_from_aabb(rays_o.numpy(), rays_d.numpy(), s["aabb"].numpy(), 0.2)
+    M = N * max_steps
+    xr, dr, lr, rr, cr = oracle.march_rays_train(rays_o.numpy(), rays_d.numpy(), bits.numpy(), s["bound"], dt_gamma, max_steps, C, H, M, n_ref, f_ref,
+                                                 noises.numpy())
+    assert rr[:, 2].max() == max_steps or fill < 0.9, "some ray should run into the step cap"
+    dev = "cuda"
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    be.march_rays_train(rays_o.cuda(), rays_d.cuda(), bits.cuda(), s["bound"], dt_gamma, max_steps, N, C, H, M, torch.from_numpy(n_ref).cuda(),
+                        torch.from_numpy(f_ref).cuda(), xyzs, dirs, deltas, rays, counter, noises.cuda())
+    assert np.array_equal(to_np(counter), cr)
+    assert np.array_equal(to_np(rays), rr)
+    for got, ref, nm in [(xyzs, xr, "xyzs"), (dirs, dr, "dirs"), (deltas, lr, "deltas")]:
+        assert np.array_equal(to_np(got).view(np.uint32), ref.view(np.uint32)), f"{nm} differ"
+
+
 def test_march_rays_train_wrapper_semantics(rm):
     """mean_count / align / force_all_rays sizing rules of raymarching.py:196-229."""
     N = 1024
