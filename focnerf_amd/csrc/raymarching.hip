@@ -667,8 +667,12 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     hipStream_t st = (hipStream_t)stream;
     float *tstrip = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + rm_strip_offset(N));
-    static int serial = -1;                                // FOC_MARCH_SERIAL=1: one ray per lane (A/B runs and the parity test of the two)
-    if (serial < 0) { const char *e = getenv("FOC_MARCH_SERIAL"); serial = e ? atoi(e) : 0; }
+    // A wave per ray repeats the lattice recurrence on 64 lanes: about 4x the instructions of a ray per lane, in exchange for a chain
+    // of dependent lookups 64x shorter. That pays while the lane-per-ray kernel is latency-bound (0.134 ms however few the rays); from
+    // ~11 k rays on the wave kernel's instruction count (~25 cycles x N on 1024 SIMDs) exceeds that. FOC_MARCH_SERIAL=1 / 0 forces one.
+    static int forced = -2;
+    if (forced == -2) { const char *e = getenv("FOC_MARCH_SERIAL"); forced = e ? (atoi(e) ? 1 : 0) : -1; }
+    const bool serial = forced >= 0 ? forced == 1 : N > 8192u;
     if (serial)
         hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     else

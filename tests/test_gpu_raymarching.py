@@ -82,11 +82,18 @@ def _march_case(bound, N, dt_gamma, perturb, seed, max_steps=1024):
     return s, n_ref, f_ref, noises
 
 
-@pytest.mark.parametrize("bound,dt_gamma,perturb", [(1, 0.0, False), (2, 1 / 128, False), (2, 1 / 128, True), (4, 1 / 64, True)])
-def test_march_rays_train_bit_exact(rm, bound, dt_gamma, perturb):
+@pytest.mark.parametrize("bound,dt_gamma,perturb,repeat", [(1, 0.0, False, 1), (2, 1 / 128, False, 1), (2, 1 / 128, True, 1), (4, 1 / 64, True, 1),
+                                                           (2, 1 / 128, True, 5)])
+def test_march_rays_train_bit_exact(rm, bound, dt_gamma, perturb, repeat):
+    """`repeat` > 1: more than 8192 rays, which the library marches with one ray per lane instead of one per wave."""
     from focnerf_amd.backend import _raymarching as be
     N, max_steps = 2048, 1024
     s, n_ref, f_ref, noises = _march_case(bound, N, dt_gamma, perturb, seed=3)
+    if repeat > 1:
+        s["rays_o"], s["rays_d"] = s["rays_o"].repeat(repeat, 1), s["rays_d"].repeat(repeat, 1)
+        n_ref, f_ref = np.tile(n_ref, repeat), np.tile(f_ref, repeat)
+        N *= repeat
+        noises = torch.rand(N, generator=torch.Generator().manual_seed(21))
     C, H = s["cascade"], 128
     # sizing pass on the oracle, then a tight M and a too-small M (dropped rays)
     _, _, _, rays0, cnt0 = oracle.march_rays_train(s["rays_o"].numpy(), s["rays_d"].numpy(), s["bits"].numpy(), s["bound"], dt_gamma, max_steps,
