@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
     if (num_steps == 0 || offset + num_steps > M) return;
     const float g0 = grad_image[index * 3], g1 = grad_image[index * 3 + 1], g2 = grad_image[index * 3 + 2];
-    const float gws = grad_weights_sum[index];
+    const float gws = grad_weights_sum ? grad_weights_sum[index] : 0.0f;
     const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
     const float ws_term = gws * (1 - weights_sum[index]);
     float T_carry = 1.0f;
@@ -706,8 +706,7 @@ int foc_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                       float *grad_rgbs, void *stream) {
     if (N == 0) return FOC_OK;
-    FOC_REQUIRE(grad_weights_sum && grad_image && rays && weights_sum && image, FOC_E_INVALID,
-                "composite_rays_train_backward: null pointer");
+    FOC_REQUIRE(grad_image && rays && weights_sum && image, FOC_E_INVALID, "composite_rays_train_backward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), FOC_E_INVALID,
                 "composite_rays_train_backward: null buffer with M > 0");
     hipLaunchKernelGGL(k_composite_train_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream,

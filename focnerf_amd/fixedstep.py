@@ -68,6 +68,7 @@ class _density_head(Function):
         ctx.dims = (N, T, float(density_scale))
         ctx.width = width
         ctx.mark_non_differentiable(sigma)
+        ctx.set_materialize_grads(False)
         return weights, ws, depth, sigma, cin
 
     @staticmethod
@@ -168,6 +169,7 @@ class _render_tail(Function):
         ctx.flags = (noise is not None, bg_ray is not None)
         ctx.dims = (N, T, float(density_scale), float(thresh), float(bg_scalar), int(num_layers), int(activation))
         ctx.mark_non_differentiable(sigma, weights, c)
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as five freshly zero-filled tensors (25 us)
         return image, ws, depth, sigma, weights, c
 
     @staticmethod

@@ -131,6 +131,7 @@ class CompositeTrain(AmpOp):
         _kernels.composite_rays_train_forward(sigmas, rgbs, deltas, rays, m, n, T_thresh, weights_sum, depth, image)
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image)
         ctx.sizes = (m, n, T_thresh)
+        ctx.set_materialize_grads(False)          # an output the loss does not read arrives as None, not as a zero-filled tensor
         return weights_sum, depth, image
 
     @staticmethod
@@ -138,8 +139,11 @@ class CompositeTrain(AmpOp):
         sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
         m, n, T_thresh = ctx.sizes
         d_sigmas, d_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
-        _kernels.composite_rays_train_backward(d_weights_sum.contiguous(), d_image.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image,
-                                               m, n, T_thresh, d_sigmas, d_rgbs)
+        if d_weights_sum is None and d_image is None:
+            return d_sigmas, d_rgbs, None, None, None
+        d_image = torch.zeros_like(image) if d_image is None else d_image.contiguous()
+        d_weights_sum = None if d_weights_sum is None else d_weights_sum.contiguous()
+        _kernels.composite_rays_train_backward(d_weights_sum, d_image, sigmas, rgbs, deltas, rays, weights_sum, image, m, n, T_thresh, d_sigmas, d_rgbs)
         return d_sigmas, d_rgbs, None, None, None
 
 

@@ -98,7 +98,8 @@ int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, con
 
 /* raymarching.cu:601-693  composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs,
  *       deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs)
- * grad_sigmas/grad_rgbs must be pre-zeroed by the caller (raymarching.py:283-284). */
+ * grad_sigmas/grad_rgbs must be pre-zeroed by the caller (raymarching.py:283-284). grad_weights_sum may be NULL (= all zero: the loss
+ * does not read weights_sum). */
 int foc_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
                                       const float *sigmas, const float *rgbs, const float *deltas,
                                       const int32_t *rays, const float *weights_sum, const float *image,

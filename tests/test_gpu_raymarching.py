@@ -239,6 +239,29 @@ def test_composite_autograd_matches_torch_reference(rm):
     np.testing.assert_allclose(to_np(rgb_t.grad), c2.grad.numpy(), atol=2e-4, rtol=1e-3)
 
 
+@pytest.mark.parametrize("use", ["image", "weights_sum", "depth"])
+def test_composite_autograd_with_unused_outputs(rm, use):
+    """A loss that reads one output only: the others' gradients reach the node as None (no zero tensors are materialised) and the result
+    equals the one obtained with explicit zero gradients; depth has no derivative (raymarching.py:275)."""
+    N = 100
+    rays, sig, rgb, deltas, M = _random_segments(N, 5, max_len=70)
+    args = (torch.from_numpy(deltas).cuda(), torch.from_numpy(rays).cuda(), 1e-4)
+    grads = {}
+    for explicit in (False, True):
+        sig_t = torch.from_numpy(sig).cuda().requires_grad_(True)
+        rgb_t = torch.from_numpy(rgb).cuda().requires_grad_(True)
+        ws, dp, im = rm.composite_rays_train(sig_t, rgb_t, *args)
+        picked = {"image": im.sum(), "weights_sum": ws.sum(), "depth": dp.sum()}[use]
+        loss = picked + (0.0 * ws.sum() + 0.0 * im.sum() if explicit else 0.0)
+        loss.backward()
+        grads[explicit] = (to_np(sig_t.grad), to_np(rgb_t.grad))
+    assert np.array_equal(grads[False][0], grads[True][0]) and np.array_equal(grads[False][1], grads[True][1])
+    if use == "depth":
+        assert not grads[False][0].any() and not grads[False][1].any()
+    else:
+        assert grads[False][0].any()
+
+
 def test_inference_march_and_composite_loop(rm):
     """legacy/nerf/renderer.py:323-372 loop, oracle vs GPU, with an analytic field standing in for the network."""
     N = 3000
