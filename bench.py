@@ -457,6 +457,25 @@ def main():
                                         "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
                                         "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
 
+            # the eager step is ~80 launches for ~1.05 ms of GPU work and Python needs ~1.2 ms to enqueue them: replayed as one HIP graph
+            # (focnerf_amd.graph.GraphedStep, static shapes thanks to the sample budget) it runs at GPU speed
+            try:
+                from focnerf_amd.graph import GraphedStep
+                optg = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+                gstep = GraphedStep(lambda o, d, t: cuda_ray_train_step(m2, optg, sc2, o, d, t), b2[0])
+                for i in range(4):
+                    gstep(*b2[i % 4])
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    gstep(*b2[i % 4])
+                barrier()
+                elg = max_over_ranks(time.perf_counter() - t0)
+                result["occupancy_path"]["graph_replay"] = {"ms_per_step": 1000 * elg / n2, "value": world * per_step * n2 / elg,
+                                                            "note": "same step captured once and replayed as one HIP graph"}
+            except Exception as e:
+                result["occupancy_path"]["graph_replay"] = {"error": repr(e)}
+
             # ---- configs[2] render half: full 800x800 view through the incremental march_rays / composite_rays loop
             m2.eval()
             ro2, rd2 = synthetic.get_rays(poses2[:1], intr, VIEW, VIEW)
