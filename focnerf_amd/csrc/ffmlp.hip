@@ -1220,7 +1220,7 @@ static size_t mlp_bwd_lds(uint32_t in_dim, uint32_t num_layers, bool dx) {
 template <int HIDDEN, bool TRAIN>
 static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
                           void *fwd_buf, void *outputs, int planar, hipStream_t st, const MlpHead *head = nullptr) {
-    constexpr int NB = 2;
+    constexpr int NB = 1;                          // one 32-row tile per wave: 92 registers, 5 waves per SIMD (two tiles: 157 registers, 3 waves; 57 -> 54 us per 2 M rows)
     const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     FOC_REQUIRE(!(planar && TRAIN), FOC_E_INVALID, "ffmlp_forward: planar inputs go with the activation-free forward");
