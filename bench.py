@@ -445,7 +445,7 @@ def main():
                 if i == 15:
                     m2.mean_count = int(m2.step_counter[:16, 0].sum().item() / 16)    # what update_extra_state would set (renderer.py:533)
             barrier()
-            n2 = max(args.steps, 10)
+            n2 = max(3 * args.steps, 30)                  # the eager step is host-bound: more steps, less jitter in the figure
             c0 = 0
             t0 = time.perf_counter()
             for i in range(n2):
