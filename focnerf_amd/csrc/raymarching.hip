@@ -668,11 +668,12 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     hipStream_t st = (hipStream_t)stream;
     float *tstrip = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + rm_strip_offset(N));
     // A wave per ray repeats the lattice recurrence on 64 lanes: about 4x the instructions of a ray per lane, in exchange for a chain
-    // of dependent lookups 64x shorter. That pays while the lane-per-ray kernel is latency-bound (0.134 ms however few the rays); from
-    // ~11 k rays on the wave kernel's instruction count (~25 cycles x N on 1024 SIMDs) exceeds that. FOC_MARCH_SERIAL=1 / 0 forces one.
+    // of dependent lookups 64x shorter. That pays while the lane-per-ray kernel is latency-bound. Measured per call (tools/
+    // time_march_modes.py, wave / lane): 4096 rays 77 / 138 us, 8192 127 / 178, 16384 221 / 267, 32768 417 / 278, 65536 825 / 460.
+    // FOC_MARCH_SERIAL=1 / 0 forces one.
     static int forced = -2;
     if (forced == -2) { const char *e = getenv("FOC_MARCH_SERIAL"); forced = e ? (atoi(e) ? 1 : 0) : -1; }
-    const bool serial = forced >= 0 ? forced == 1 : N > 8192u;
+    const bool serial = forced >= 0 ? forced == 1 : N > 16384u;
     if (serial)
         hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     else

@@ -83,9 +83,9 @@ def _march_case(bound, N, dt_gamma, perturb, seed, max_steps=1024):
 
 
 @pytest.mark.parametrize("bound,dt_gamma,perturb,repeat", [(1, 0.0, False, 1), (2, 1 / 128, False, 1), (2, 1 / 128, True, 1), (4, 1 / 64, True, 1),
-                                                           (2, 1 / 128, True, 5)])
+                                                           (2, 1 / 128, True, 9)])
 def test_march_rays_train_bit_exact(rm, bound, dt_gamma, perturb, repeat):
-    """`repeat` > 1: more than 8192 rays, which the library marches with one ray per lane instead of one per wave."""
+    """`repeat` > 1: more than 16384 rays, which the library marches with one ray per lane instead of one per wave."""
     from focnerf_amd.backend import _raymarching as be
     N, max_steps = 2048, 1024
     s, n_ref, f_ref, noises = _march_case(bound, N, dt_gamma, perturb, seed=3)
