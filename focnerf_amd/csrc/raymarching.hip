@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ ra
 // flow on wave-uniform bit masks: an occupied visited point emits and moves to the next lane, an empty one moves to the first lane
 // whose t is not below its voxel exit (carried into the next 64 points when there is none). Same visits, same emitted t, bit for bit.
 #define RM_MAX_ROUNDS (1u << 22)                           // x 64 lattice points: far beyond any real ray; makes the loop finite whatever the inputs
+template <bool MED3>                                       // dt_min <= dt_max (any real setting): the clamp of the recurrence is one v_med3_f32
 __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                               const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
                               const float *__restrict__ nears, const float *__restrict__ fars,
@@ -259,7 +260,8 @@ __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restric
 #pragma unroll 8
         for (uint32_t j = 0; j < 64; j++) {
             T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
-            t_next += rm_clamp(t_next * p.dt_gamma, p.dt_min, p.dt_max);
+            const float raw = t_next * p.dt_gamma;             // for ordered operands the median IS fminf(hi, fmaxf(lo, x)), bit for bit
+            t_next += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
         }
         const uint64_t in_range = __ballot(T < far);
         uint32_t k = 0;                                    // lane of the lattice point the loop is at
@@ -677,8 +679,8 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     if (serial)
         hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     else
-        hipLaunchKernelGGL(k_march_count_wave, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch,
-                           tstrip);
+        hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_count_wave<true> : k_march_count_wave<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d,
+                           grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     FOC_CHECK_LAUNCH("march_rays_train(count)");
     // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
