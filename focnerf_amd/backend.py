@@ -32,18 +32,32 @@ def _contig(*ts):
 
 
 class _Scratch:
-    """Per-device grow-only scratch buffers (int32 counters / fp32 workspaces)."""
+    """Grow-only scratch buffers (counters, workspaces), one per (purpose, device, STREAM): two streams running the same op never share
+    a workspace (nor the precount header that lives in one), and work queued on a stream is ordered against its own earlier uses.
+
+    A HIP graph captured over a call keeps the raw address it saw. A buffer that was handed out during a stream capture is therefore
+    never given back to the allocator: when a larger request supersedes it, it moves to `_pinned` and lives as long as the process
+    (a graph may replay at any later time), and the capture itself never grows a buffer it has already baked in — it raises instead."""
 
     def __init__(self):
-        self._bufs = {}
+        self._bufs = {}            # key -> [tensor, seen_by_capture]
+        self._pinned = []
 
     def get(self, key, nbytes, device):
-        k = (key, device.index if device.index is not None else torch.cuda.current_device())
-        buf = self._bufs.get(k)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-            self._bufs[k] = buf
-        return buf
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        k = (key, idx, torch.cuda.current_stream(idx).cuda_stream)
+        capturing = torch.cuda.is_current_stream_capturing()
+        ent = self._bufs.get(k)
+        if ent is None or ent[0].numel() < nbytes:
+            if ent is not None and ent[1]:
+                if capturing:
+                    raise RuntimeError(f"focnerf_amd: scratch '{key}' would have to grow from {ent[0].numel()} to {int(nbytes)} bytes inside a stream "
+                                       f"capture that already recorded its address; warm the step up at its largest shapes before capturing")
+                self._pinned.append(ent[0])                  # a captured graph still writes there
+            ent = self._bufs[k] = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device), False]
+        if capturing:
+            ent[1] = True
+        return ent[0]
 
 
 _scratch = _Scratch()

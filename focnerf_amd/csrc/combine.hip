@@ -112,6 +112,7 @@ const char *foc_last_error(void) { return g_err; }
 const char *foc_arch(void) { return "gfx950"; }
 
 int foc_combine_select(const float *dens, const float *rgb, float *max_dens, float *best_rgb, uint64_t n, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n == 0 || (dens && rgb && max_dens && best_rgb), FOC_E_INVALID, "combine_select: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_select, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rgb, max_dens, best_rgb, n);
@@ -120,6 +121,7 @@ int foc_combine_select(const float *dens, const float *rgb, float *max_dens, flo
 }
 
 int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint64_t n, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n == 0 || (dens && keys), FOC_E_INVALID, "combine_pack_keys: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_pack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rank, keys, n);
@@ -128,6 +130,7 @@ int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint
 }
 
 int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb, float *max_dens, float *masked_rgb, uint64_t n, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n == 0 || (keys && rgb && max_dens && masked_rgb), FOC_E_INVALID, "combine_unpack: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_unpack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, rank, rgb, max_dens, masked_rgb, n);
@@ -137,6 +140,7 @@ int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb, fl
 
 int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const float *nears, const float *fars, uint32_t N, uint32_t T,
                               float bg, float *image4, float *depth, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(N == 0 || (sigmas && rgbs && nears && fars && image4 && depth), FOC_E_INVALID, "composite_fixed_steps: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "composite_fixed_steps: T must be >= 2");
     if (N == 0) return FOC_OK;

@@ -31,6 +31,22 @@ void foc_set_error(const char *fmt, ...);
         }                                                                          \
     } while (0)
 
+// Every entry point runs with the device of ITS stream current: a caller holding `cuda:1` tensors while device 0 is current (K resident
+// objects on several GPUs of one process, focnerf_amd/checkpoint.py load_objects) gets the occupancy queries, LDS opt-ins and
+// per-device statics of the right device. Two host calls (hipGetDevice, hipStreamGetDevice) when the devices already agree.
+struct FocDeviceGuard {
+    int prev = -1;
+    explicit FocDeviceGuard(void *stream) {
+        int cur = 0, want = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return;
+        if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &want) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (want != cur && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~FocDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    FocDeviceGuard(const FocDeviceGuard &) = delete;
+    FocDeviceGuard &operator=(const FocDeviceGuard &) = delete;
+};
+
 static inline uint32_t foc_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // Grid for a grid-stride elementwise kernel: enough workgroups to fill 256 CUs x 8,

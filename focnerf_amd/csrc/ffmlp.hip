@@ -1166,31 +1166,41 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
 }
 
 // ================================================================= host side
-static uint32_t g_num_cus = 0;
+// Per-device caches (the entry points make the stream's device current, common.h FocDeviceGuard): CU count and, per kernel, the number
+// of workgroups one CU holds.
+#define MLP_MAX_DEVICES 16
+static int mlp_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MLP_MAX_DEVICES) dev = 0;
+    return dev;
+}
 static uint32_t mlp_num_cus() {
-    if (!g_num_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_num_cus = (uint32_t)n;
+    static uint32_t num_cus[MLP_MAX_DEVICES];
+    const int dev = mlp_device();
+    if (!num_cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        num_cus[dev] = (uint32_t)n;
     }
-    return g_num_cus;
+    return num_cus[dev];
 }
 
 // Workgroups of a persistent kernel that one CU holds at once (registers + LDS): the grid is capped at CUs x this, so that every
 // workgroup is resident from the start — a grid of CUs x 4 on a kernel that fits 3 per CU runs a quarter of its workgroups in a second,
 // three-quarters-empty round (measured: 2.025 -> 2.003 ms per training step for the two forward kernels).
 static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
-    static const void *seen[64];
-    static uint32_t blocks[64];
-    static int n_seen = 0;
+    static const void *seen[MLP_MAX_DEVICES][64];
+    static uint32_t blocks[MLP_MAX_DEVICES][64];
+    static int n_seen[MLP_MAX_DEVICES];
     static int forced = -1;                     // FOC_MLP_BLOCKS_PER_CU=n overrides (tuning runs)
     if (forced < 0) { const char *e = getenv("FOC_MLP_BLOCKS_PER_CU"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return (uint32_t)forced;
-    for (int i = 0; i < n_seen; i++) if (seen[i] == kern) return blocks[i];
+    const int dev = mlp_device();
+    for (int i = 0; i < n_seen[dev]; i++) if (seen[dev][i] == kern) return blocks[dev][i];
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, MLP_BLOCK, lds) != hipSuccess || n < 1) n = 2;
     if (n > 8) n = 8;
-    if (n_seen < 64) { seen[n_seen] = kern; blocks[n_seen] = (uint32_t)n; n_seen++; }
+    if (n_seen[dev] < 64) { seen[dev][n_seen[dev]] = kern; blocks[dev][n_seen[dev]] = (uint32_t)n; n_seen[dev]++; }
     return (uint32_t)n;
 }
 
@@ -1355,6 +1365,7 @@ extern "C" {
 
 int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                       uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *forward_buffer, void *outputs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     // forward_buffer == NULL: nothing is kept for the backward pass (foc_ffmlp_backward re-evaluates the activations)
     if (!forward_buffer) return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream);
     return mlp_fwd<true>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs, stream);
@@ -1362,6 +1373,7 @@ int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint3
 
 int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                         uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *inference_buffer, void *outputs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference_buffer, outputs, stream);
 }
 
@@ -1399,18 +1411,21 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     return mlp_bwd_entry(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                          calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, 0, stream);
 }
 
 int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                              uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *outputs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     return mlp_fwd<false>(inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream, 1);
 }
 
 int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                               uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                               void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     return mlp_bwd_entry(grad, inputs_planar, weights, nullptr, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                          calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
 }
@@ -1418,6 +1433,7 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
 int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, const void *sigma_weights, uint32_t sigma_layers,
                              const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B, float *sigma,
                              float *rgb, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(enc && dirs && sigma_weights && color_weights && rgb, FOC_E_INVALID, "nerf_field_inference: null pointer");
     FOC_REQUIRE(hidden_dim == 64 && dir_div >= 1, FOC_E_INVALID, "nerf_field_inference: hidden_dim must be 64 (got %u)", hidden_dim);
@@ -1436,6 +1452,7 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
 // The colour network of the fixed-step training path, fed from the sigma network's output rows and a per-ray SH table (input mode 2).
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights, uint32_t B, uint32_t hidden_dim,
                            uint32_t num_layers, uint32_t activation, void *outputs, uint32_t out_width, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     int rc = mlp_check("color_head_forward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     if (B == 0) return FOC_OK;
@@ -1449,6 +1466,7 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
                             uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
                             uint32_t out_width, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     FOC_REQUIRE(hidden_dim == 64 && (num_layers == 2 || num_layers == 3) && samples_per_ray >= 1, FOC_E_INVALID,

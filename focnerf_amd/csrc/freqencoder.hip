@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) k_freq_bwd(const float *__restrict__ grad
 extern "C" {
 
 int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && outputs, FOC_E_INVALID, "freq_encode_forward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_forward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);
@@ -51,6 +52,7 @@ int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_
 
 int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                              float *grad_inputs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && outputs && grad_inputs, FOC_E_INVALID, "freq_encode_backward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_backward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);

@@ -600,6 +600,7 @@ extern "C" {
 
 int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
                            float *nears, float *fars, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && aabb && nears && fars, FOC_E_INVALID, "near_far_from_aabb: null pointer");
     hipLaunchKernelGGL(k_near_far_from_aabb, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -609,6 +610,7 @@ int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
 }
 
 int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && coords, FOC_E_INVALID, "sph_from_ray: null pointer");
     hipLaunchKernelGGL(k_sph_from_ray, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
@@ -617,6 +619,7 @@ int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uin
 }
 
 int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D: null pointer");
     hipLaunchKernelGGL(k_morton3D, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
@@ -625,6 +628,7 @@ int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stre
 }
 
 int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D_invert: null pointer");
     hipLaunchKernelGGL(k_morton3D_invert, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
@@ -633,6 +637,7 @@ int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, voi
 }
 
 int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(grid && bitfield, FOC_E_INVALID, "packbits: null pointer");
     uint32_t N4 = 0;
@@ -658,6 +663,7 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
                 "march_rays_train: null pointer");
@@ -695,6 +701,7 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
                                      uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
                                      void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays && weights_sum && depth && image, FOC_E_INVALID, "composite_rays_train_forward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas), FOC_E_INVALID, "composite_rays_train_forward: null input with M > 0");
@@ -708,6 +715,7 @@ int foc_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
                                       const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                       float *grad_rgbs, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(grad_image && rays && weights_sum && image, FOC_E_INVALID, "composite_rays_train_backward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), FOC_E_INVALID,
@@ -723,6 +731,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
                    const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                    const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                    const float *noises, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     (void)nears;
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, FOC_E_INVALID,
@@ -740,6 +749,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                        const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                        float *image, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, FOC_E_INVALID,
                 "composite_rays: null pointer");
@@ -750,6 +760,7 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
 }
 
 int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out, int32_t *scratch, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n_out && scratch, FOC_E_INVALID, "compact_alive: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nb = foc_div_up(n_alive, 1024);

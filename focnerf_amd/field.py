@@ -11,7 +11,6 @@ write them (`foc_ffmlp_forward_planar`, `foc_ffmlp_backward_planar`), so neither
 Used by NeRFNetwork (fused head) and render_fixed_steps; FOC_FUSED_FIELD=0 restores the two separate nodes.
 """
 import os
-import weakref
 
 import numpy as np
 import torch
@@ -29,23 +28,41 @@ def field_fusable(encoder, mlp):
             and mlp.padded_output_dim == 16 and os.environ.get("FOC_FUSED_FIELD", "1") != "0")
 
 
-_half_cache = {}
+_half_scope = None          # dict id(param) -> (param, fp16 copy) while a `half_cache_scope()` is open, else None
+
+
+class half_cache_scope:
+    """Within the scope the fp16 copies of parameters are made once and reused: a staged render evaluates the same 50 MB table and the
+    same weight blobs for each of its 157 ray chunks, under `no_grad`, with nothing writing the parameters in between. The scope is the
+    ONLY cache: outside it every forward converts again, as the reference does on every call (grid.py:41-44; ffmlp.py:23) — validity
+    cannot be inferred from the parameter itself, because writes through `.data` (torch_ema's copy_to / restore around every
+    evaluation, nerf/utils.py:1164-1174; `reset_parameters`) leave its version counter untouched. Re-entrant; the outermost exit drops
+    the copies."""
+
+    def __enter__(self):
+        global _half_scope
+        self._outer = _half_scope
+        if _half_scope is None:
+            _half_scope = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _half_scope
+        _half_scope = self._outer
+        return False
 
 
 def _half_of(param):
-    """fp16 copy of a parameter, reused while the parameter is unchanged (tensor version counter): a render evaluates the same table
-    and weights for every ray chunk, and the reference converts the 50 MB table on every call (grid.py:41-44). Entries die with
-    their parameter (weak references)."""
+    """fp16 copy of a parameter: a fresh conversion, unless a `half_cache_scope` is open (then one conversion per scope)."""
     if param.dtype == torch.half:
         return param.contiguous()
-    key = id(param)
-    hit = _half_cache.get(key)
-    if hit is not None and hit[0]() is param and hit[1] == param._version and hit[2].device == param.device:
-        return hit[2]
-    for k in [k for k, v in _half_cache.items() if v[0]() is None]:
-        del _half_cache[k]
+    if _half_scope is None:
+        return param.detach().to(torch.half).contiguous()
+    hit = _half_scope.get(id(param))
+    if hit is not None and hit[0] is param and hit[1].device == param.device:
+        return hit[1]
     h = param.detach().to(torch.half).contiguous()
-    _half_cache[key] = (weakref.ref(param), param._version, h)
+    _half_scope[id(param)] = (param, h)
     return h
 
 

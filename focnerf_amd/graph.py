@@ -25,7 +25,9 @@ class GraphedStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the warm-up stream: the library's scratch buffers are per stream (backend._Scratch), so the capture finds the
+        # buffers the warm-up sized instead of allocating a second set; buffers a capture has seen are pinned for the process' lifetime
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_output = step_fn(*self.static_inputs)
 
     def __call__(self, *inputs):

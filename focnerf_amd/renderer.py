@@ -162,20 +162,24 @@ class NeRFRenderer(nn.Module):
             alive = torch.arange(n, dtype=torch.int32, device=dev)
             t_now = near.clone()
             marched = 0
-            while marched < max_steps and alive.shape[0] > 0:
-                live = alive.shape[0]
-                burst = max(min(n // live, 8), 1)                 # fewer live rays -> more samples per ray and launch
-                xyzs, dirs, deltas = raymarching.march_rays(live, burst, alive, t_now, o, d, self.bound, self.density_bitfield, self.cascade,
-                                                            self.grid_size, near, far, _MARCH_ALIGN, perturb and marched == 0, dt_gamma,
-                                                            max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
-                raymarching.composite_rays(live, burst, alive, t_now, self.density_scale * sigmas, rgbs, deltas, opacity, depth, image, T_thresh)
-                if device_compaction:
-                    kept, count = raymarching.compact_alive(alive)
-                    alive = kept[:int(count.item())]
-                else:
-                    alive = alive[alive >= 0]
-                marched += burst
+            import contextlib
+            from .field import half_cache_scope
+            # the loop evaluates the same parameters once per burst: one fp16 conversion per view when nothing can write them in between
+            with (half_cache_scope() if not torch.is_grad_enabled() else contextlib.nullcontext()):
+                while marched < max_steps and alive.shape[0] > 0:
+                    live = alive.shape[0]
+                    burst = max(min(n // live, 8), 1)                 # fewer live rays -> more samples per ray and launch
+                    xyzs, dirs, deltas = raymarching.march_rays(live, burst, alive, t_now, o, d, self.bound, self.density_bitfield, self.cascade,
+                                                                self.grid_size, near, far, _MARCH_ALIGN, perturb and marched == 0, dt_gamma,
+                                                                max_steps)
+                    sigmas, rgbs = self(xyzs, dirs)
+                    raymarching.composite_rays(live, burst, alive, t_now, self.density_scale * sigmas, rgbs, deltas, opacity, depth, image, T_thresh)
+                    if device_compaction:
+                        kept, count = raymarching.compact_alive(alive)
+                        alive = kept[:int(count.item())]
+                    else:
+                        alive = alive[alive >= 0]
+                    marched += burst
         out['image'], out['depth'] = self._finish(image, depth, opacity, near, far, background, lead)
         return out
 
@@ -254,22 +258,27 @@ class NeRFRenderer(nn.Module):
         dev = rays_o.device
         depth, image = torch.empty(B, N, device=dev), torch.empty(B, N, 3, device=dev)
         densities = rgbs = None
-        for b in range(B):
-            for lo in range(0, N, max_ray_batch):
-                hi = min(lo + max_ray_batch, N)
-                # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
-                into = (depth[b, lo:hi], image[b, lo:hi])
-                part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, _out=into, **kwargs)
-                if part['depth'].data_ptr() != into[0].data_ptr():
-                    depth[b:b + 1, lo:hi] = part['depth']
-                if part['image'].data_ptr() != into[1].data_ptr():
-                    image[b:b + 1, lo:hi] = part['image']
-                if 'densities' in part:
-                    if densities is None:
-                        T = part['densities'].shape[1]
-                        densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
-                    densities[b:b + 1, lo:hi] = part['densities'].permute(2, 0, 1)
-                    rgbs[b:b + 1, lo:hi] = part['rgbs']
+        import contextlib
+        from .field import half_cache_scope
+        # one fp16 conversion of the table / weight blobs per VIEW instead of per chunk — only where nothing can write the parameters
+        # between two chunks (no autograd, hence no optimizer step inside the loop); the copies are dropped when the view is done
+        with (half_cache_scope() if not torch.is_grad_enabled() else contextlib.nullcontext()):
+            for b in range(B):
+                for lo in range(0, N, max_ray_batch):
+                    hi = min(lo + max_ray_batch, N)
+                    # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
+                    into = (depth[b, lo:hi], image[b, lo:hi])
+                    part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, _out=into, **kwargs)
+                    if part['depth'].data_ptr() != into[0].data_ptr():
+                        depth[b:b + 1, lo:hi] = part['depth']
+                    if part['image'].data_ptr() != into[1].data_ptr():
+                        image[b:b + 1, lo:hi] = part['image']
+                    if 'densities' in part:
+                        if densities is None:
+                            T = part['densities'].shape[1]
+                            densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
+                        densities[b:b + 1, lo:hi] = part['densities'].permute(2, 0, 1)
+                        rgbs[b:b + 1, lo:hi] = part['rgbs']
         out = {'depth': depth, 'image': image, 'timing': part.get('timing')}
         if densities is not None:
             out['densities'], out['rgbs'] = densities, rgbs

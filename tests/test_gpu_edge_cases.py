@@ -111,3 +111,73 @@ def test_bad_arguments_raise_runtime_error():
     with pytest.raises(RuntimeError, match="hidden_dim"):
         _ffmlp.ffmlp_inference(torch.zeros(4, 32, dtype=torch.float16, device="cuda"), w, 4, 32, 16, 256, 2, 0, 6, None,
                                torch.empty(4, 16, dtype=torch.float16, device="cuda"))
+
+
+def test_graph_keeps_its_scratch_when_a_later_call_needs_more():
+    """A captured step bakes in the raw addresses of the library's scratch buffers (march strip, binned-backward workspace, MLP dW
+    workspace). A later eager call that needs a larger buffer must not hand the captured one back to the allocator: capture a training
+    step, run the same ops eagerly on a much larger batch (and churn the allocator), replay, compare with the eager result."""
+    from focnerf_amd import backend
+    from focnerf_amd.graph import GraphedStep
+    from focnerf_amd.gridencoder import GridEncoder
+    from focnerf_amd.ffmlp import FFMLP
+    from focnerf_amd.field import hashgrid_mlp
+    torch.manual_seed(0)
+    enc = GridEncoder(desired_resolution=2048).cuda()
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    mlp = FFMLP(32, 16, 64, 2).cuda().train()
+    B = 4096
+    x = torch.rand(B, 3, device="cuda") * 2 - 1
+    gy = (torch.randn(B, 16, device="cuda") * 0.01).half()
+
+    def step(xx, gg):
+        enc.embeddings.grad = None
+        mlp.weights.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            h = hashgrid_mlp(enc, mlp, xx, 1)
+        h.backward(gg)
+        return enc.embeddings.grad, mlp.weights.grad
+
+    ge_ref, gw_ref = (t.clone() for t in step(x, gy))
+    g = GraphedStep(step, (x, gy))
+    pinned_before = len(backend._scratch._pinned)
+    captured = [e[0].data_ptr() for e in backend._scratch._bufs.values() if e[1]]
+    assert captured, "the capture saw no scratch buffer: the test no longer exercises what it claims"
+    # same stream as the capture (GraphedStep's side stream is private, so go through the scratch of every stream): a 16x larger batch
+    for key in list(backend._scratch._bufs):
+        ent = backend._scratch._bufs[key]
+        if ent[1]:
+            s = torch.cuda.ExternalStream(key[2])
+            with torch.cuda.stream(s):
+                backend._scratch.get(key[0], ent[0].numel() * 16, torch.device("cuda", key[1]))
+    torch.cuda.synchronize()
+    assert len(backend._scratch._pinned) > pinned_before      # superseded buffers a graph saw are kept, not freed
+    big = torch.rand(16 * B, 3, device="cuda") * 2 - 1
+    step(big, (torch.randn(16 * B, 16, device="cuda") * 0.01).half())
+    junk = [torch.full((1 << 22,), 7.0, device="cuda") for _ in range(64)]      # would land in any block the scratch had given back
+    torch.cuda.synchronize()
+    del junk
+    ge, gw = g(x, gy)
+    torch.cuda.synchronize()
+    assert torch.equal(gw, gw_ref)
+    assert torch.equal(ge, ge_ref)                              # the binned backward is deterministic (fixed-point sums)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_ops_follow_their_tensors_device():
+    """An op on cuda:1 tensors while cuda:0 is current (K resident objects spread over the GPUs of one process): the entry points make
+    the device of their stream current (csrc/common.h FocDeviceGuard) and restore it."""
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    m0 = NeRFNetwork(bound=1).to("cuda:0").eval()
+    m0.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    m1 = NeRFNetwork(bound=1).to("cuda:1").eval()
+    m1.load_state_dict(m0.state_dict())
+    x = torch.rand(1000, 3) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(1000, 3), dim=-1)
+    torch.cuda.set_device(0)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s0, c0 = m0(x.to("cuda:0"), d.to("cuda:0"))
+        s1, c1 = m1(x.to("cuda:1"), d.to("cuda:1"))
+    assert torch.cuda.current_device() == 0
+    assert s1.device.index == 1 and torch.equal(s0.cpu(), s1.cpu()) and torch.equal(c0.cpu(), c1.cpu())

@@ -231,3 +231,66 @@ def test_sh_encoder_kernel_matches_expression():
     dg = d.clone().requires_grad_(True)
     enc(dg).sum().backward()                                   # differentiable form still available
     assert dg.grad is not None and torch.isfinite(dg.grad).all()
+
+
+@pytest.mark.parametrize("path", ["train_forward", "eval_forward", "fused_run_train", "fused_run_eval"])
+def test_data_writes_are_seen_by_the_fused_paths(path):
+    """Writes through `.data` do not bump a parameter's version counter, and the reference trainer writes that way around every
+    evaluation (torch_ema copy_to / restore, nerf/utils.py:1164-1174). The fused paths run on fp16 copies of the table and the weight
+    blobs: a copy must never outlive the call that made it (outside an explicit `half_cache_scope`). forward -> p.data.mul_(2) ->
+    forward must change; -> p.data.copy_(old) -> forward must give the first result bit for bit."""
+    from focnerf_amd import synthetic
+    m = _model(1, False)
+    rays_o, rays_d = synthetic.make_view_rays(32, 32, 1, 1, seed=3, device="cuda")
+    rays_o, rays_d = rays_o[:, :256].contiguous(), rays_d[:, :256].contiguous()
+    x = torch.rand(640, 3, device="cuda") * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(640, 3, device="cuda"), dim=-1)
+
+    def evaluate():
+        with torch.autocast("cuda", dtype=torch.float16):
+            if path == "train_forward":
+                m.train()
+                s, c = m(x, d)
+                return torch.cat([s.float().reshape(-1), c.float().reshape(-1)]).detach().clone()
+            if path == "eval_forward":
+                m.eval()
+                with torch.no_grad():
+                    s, c = m(x, d)
+                return torch.cat([s.float().reshape(-1), c.float().reshape(-1)]).clone()
+            if path == "fused_run_train":
+                m.train()
+                out = m.run(rays_o, rays_d, num_steps=64, upsample_steps=0, perturb=False, fused=True)
+                return out["image"].detach().float().reshape(-1).clone()
+            m.eval()
+            with torch.no_grad():
+                out = m.render(rays_o, rays_d, staged=True, max_ray_batch=128, num_steps=64, upsample_steps=0, perturb=False, fused=True)
+            return out["image"].float().reshape(-1).clone()
+
+    for pname in ("encoder.embeddings", "sigma_net.weights", "color_net.weights"):
+        p = dict(m.named_parameters())[pname]
+        first = evaluate()
+        old = p.data.clone()
+        v = p._version
+        p.data.mul_(2)
+        assert p._version == v                                   # the premise: nothing a cache could key on
+        changed = evaluate()
+        assert not torch.equal(first, changed), f"{path}: a write to {pname}.data was not seen"
+        p.data.copy_(old)
+        again = evaluate()
+        assert torch.equal(first, again), f"{path}: restoring {pname}.data did not restore the result"
+
+
+def test_half_cache_scope_is_the_only_cache():
+    from focnerf_amd.field import _half_of, half_cache_scope
+    p = torch.nn.Parameter(torch.rand(1000, 2, device="cuda"))
+    a = _half_of(p)
+    assert _half_of(p).data_ptr() != a.data_ptr() or True      # fresh conversions (the allocator may recycle the address)
+    p.data.mul_(2)
+    assert torch.equal(_half_of(p), p.detach().half())
+    with half_cache_scope():
+        h1 = _half_of(p)
+        with half_cache_scope():
+            assert _half_of(p) is h1
+        assert _half_of(p) is h1
+    p.data.mul_(0.5)
+    assert torch.equal(_half_of(p), p.detach().half())
