@@ -105,7 +105,124 @@ __global__ void __launch_bounds__(256) k_composite_fixed(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------- fused select + composite over K objects' packed fields
+// fields.p[k] -> object k's field4 [N,T] (sigma, r, g, b) on the SAME rays and sample positions, k in checkpoint order. One wave per
+// ray, 64 samples at a time: every lane reads its sample of each object with one 16-byte load, keeps the entry with the strictly larger
+// density (object 0 first, `d > max` for the others: COMBINED.py:247-251, torch.maximum's NaN propagation included) and the composite of
+// image_depth_generation (:141-200) runs on the merged values without the merged field ever being stored: 16 B read per sample and
+// object, 20 B written per ray and background. n_bg backgrounds (the reference composites every view twice, white and black,
+// compute_metrics_both_backgrounds): image4 [n_bg,N,4]. merged4 (optional) [N,T] receives (max density, best rgb) for callers that
+// keep the reference's max_densities / max_rgbs.
+#define FOC_COMBINE_MAX_OBJECTS 16
+struct CombineFields { const float4 *p[FOC_COMBINE_MAX_OBJECTS]; };
+
+__global__ void __launch_bounds__(256) k_combine_select_composite(CombineFields fields, uint32_t K, const float *__restrict__ nears,
+                                                                  const float *__restrict__ fars, uint32_t N, uint32_t T, float bg0, float bg1,
+                                                                  uint32_t n_bg, float *__restrict__ image4, float *__restrict__ depth,
+                                                                  float4 *__restrict__ merged4) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float near = nears[n], far = fars[n];
+    const float span = far - near;
+    const float sample_dist = span / (float)T;
+    const float step = 1.0f / (float)(T - 1);
+    float Tc = 1.0f, r = 0, g = 0, b = 0, a = 0, d = 0, ws = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < T;
+        float alpha = 0, sigma = 0, c0 = 0, c1 = 0, c2 = 0, oz = 0;
+        if (valid) {
+            const uint64_t s = (uint64_t)n * T + i;
+            float4 best = fields.p[0][s];
+            for (uint32_t k = 1; k < K; k++) {
+                const float4 f = fields.p[k][s];
+                const float m = best.x;
+                if (f.x > m) { best.y = f.y; best.z = f.z; best.w = f.w; }
+                best.x = (f.x != f.x || m != m) ? __builtin_nanf("") : (f.x > m ? f.x : m);      // torch.maximum propagates NaN
+            }
+            if (merged4) merged4[s] = best;
+            sigma = best.x; c0 = best.y; c1 = best.z; c2 = best.w;
+            const float l0 = (i < T / 2) ? (step * (float)i) : fmaf(-step, (float)(T - 1 - i), 1.0f);   // device linspace: see fixedstep.hip
+            const float z = near + span * l0;
+            float delta = sample_dist;
+            if (i + 1 < T) {
+                const uint32_t i1 = i + 1;
+                const float l1 = (i1 < T / 2) ? (step * (float)i1) : fmaf(-step, (float)(T - 1 - i1), 1.0f);
+                delta = (near + span * l1) - z;
+            }
+            alpha = 1 - __expf(-delta * sigma);
+            oz = (z - near) / span;
+            oz = oz < 0 ? 0 : (oz > 1 ? 1 : oz);
+        }
+        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+        const float P = wave_incl_prod(om, (int)lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float w = alpha * (Tc * Pex);
+        r = fmaf(w, c0, r); g = fmaf(w, c1, g); b = fmaf(w, c2, b);
+        a = fmaf(w, sigma, a); d = fmaf(w, oz, d); ws += w;
+        Tc *= __shfl(P, 63, 64);
+    }
+    r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); a = wave_sum(a); d = wave_sum(d); ws = wave_sum(ws);
+    if (lane == 0) {
+        for (uint32_t q = 0; q < n_bg; q++) {
+            const float rest = (1 - ws) * (q == 0 ? bg0 : bg1);
+            const float o[4] = {r + rest, g + rest, b + rest, a + rest};
+#pragma unroll
+            for (int k = 0; k < 4; k++) image4[((uint64_t)q * N + n) * 4 + k] = fminf(1.0f, fmaxf(0.0f, o[k]));
+        }
+        depth[n] = d;
+    }
+}
+
+// Pre-merge of the objects that share a rank before the exchange (K objects on fewer GPUs): acc4 <- select(acc4, f4), same rule. The
+// select is associative over the object order, so merging a rank's consecutive objects first and the ranks afterwards equals the
+// reference's one sequential pass.
+__global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restrict__ f4, float4 *__restrict__ acc4, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const float4 f = f4[i];
+        float4 best = acc4[i];
+        const float m = best.x;
+        if (f.x > m) { best.y = f.y; best.z = f.z; best.w = f.w; }
+        best.x = (f.x != f.x || m != m) ? __builtin_nanf("") : (f.x > m ? f.x : m);
+        acc4[i] = best;
+    }
+}
+
 extern "C" {
+
+int foc_combine_select_composite(const float *const *fields4, uint32_t K, const float *nears, const float *fars, uint32_t N, uint32_t T,
+                                 const float *bgs, uint32_t n_bg, float *image4, float *depth, float *merged4, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    FOC_REQUIRE(K >= 1 && K <= FOC_COMBINE_MAX_OBJECTS, FOC_E_INVALID, "combine_select_composite: 1 <= K <= %d objects per call (got %u)",
+                FOC_COMBINE_MAX_OBJECTS, K);
+    FOC_REQUIRE(n_bg >= 1 && n_bg <= 2 && bgs, FOC_E_INVALID, "combine_select_composite: one or two backgrounds");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "combine_select_composite: T must be >= 2");
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(fields4 && nears && fars && image4 && depth, FOC_E_INVALID, "combine_select_composite: null pointer");
+    CombineFields f;
+    for (uint32_t k = 0; k < FOC_COMBINE_MAX_OBJECTS; k++) {
+        f.p[k] = reinterpret_cast<const float4 *>(k < K ? fields4[k] : fields4[0]);
+        FOC_REQUIRE(f.p[k] && ((uintptr_t)f.p[k] & 15) == 0, FOC_E_INVALID, "combine_select_composite: field %u is null or not 16-byte aligned", k);
+    }
+    FOC_REQUIRE(((uintptr_t)merged4 & 15) == 0, FOC_E_INVALID, "combine_select_composite: merged4 must be 16-byte aligned");
+    hipLaunchKernelGGL(k_combine_select_composite, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, f, K, nears, fars, N, T, bgs[0],
+                       n_bg > 1 ? bgs[1] : 0.0f, n_bg, image4, depth, reinterpret_cast<float4 *>(merged4));
+    FOC_CHECK_LAUNCH("combine_select_composite");
+    return FOC_OK;
+}
+
+int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    FOC_REQUIRE(n == 0 || (field4 && acc4), FOC_E_INVALID, "combine_select4: null pointer");
+    FOC_REQUIRE((((uintptr_t)field4 | (uintptr_t)acc4) & 15) == 0, FOC_E_INVALID, "combine_select4: fields must be 16-byte aligned");
+    if (n == 0) return FOC_OK;
+    hipLaunchKernelGGL(k_combine_select4, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(field4),
+                       reinterpret_cast<float4 *>(acc4), n);
+    FOC_CHECK_LAUNCH("combine_select4");
+    return FOC_OK;
+}
 
 int foc_abi_version(void) { return FOC_ABI_VERSION; }
 const char *foc_last_error(void) { return g_err; }

@@ -395,11 +395,15 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
 // sigma [M] fp32 and rgb [M,3] fp32 (foc_nerf_field_inference) -> image [N,3], depth [N], weights_sum [N]; one wave per ray, the
 // transmittance scan of k_fs_head_fwd and the masked sum of k_fs_composite_fwd without the weights / trans arrays in between.
 // rgb_masked (may be NULL): rgb * [w > thresh], the per-sample colour field the reference's run() returns (renderer.py:187).
+// PACK: additionally (or only: image / depth / weights_sum may then be null) writes the object's per-sample field as ONE float4 per sample,
+// field4[s] = (sigma, rgb where w > thresh else 0) — the (`densities`, `rgbs`) pair COMBINED.py merges across objects (:598-618), in the
+// layout the per-ray exchange and the fused select + composite read with one 16-byte access per lane (csrc/combine.hip).
+template <bool PACK>
 __global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict__ sigma_in, const float *__restrict__ rgb_in, const float *__restrict__ nears,
                                                          const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
                                                          float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
                                                          float *__restrict__ image, float *__restrict__ depth, float *__restrict__ weights_sum,
-                                                         float *__restrict__ rgb_masked) {
+                                                         float *__restrict__ rgb_masked, float4 *__restrict__ field4) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -427,11 +431,12 @@ __global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict
             const float c0 = rgb_in[s * 3], c1 = rgb_in[s * 3 + 1], c2 = rgb_in[s * 3 + 2];
             if (on) { r += w * c0; gg += w * c1; b += w * c2; }
             if (rgb_masked) { rgb_masked[s * 3] = on ? c0 : 0.0f; rgb_masked[s * 3 + 1] = on ? c1 : 0.0f; rgb_masked[s * 3 + 2] = on ? c2 : 0.0f; }
+            if (PACK) field4[s] = make_float4(sigma, on ? c0 : 0.0f, on ? c1 : 0.0f, on ? c2 : 0.0f);
         }
         Tc *= __shfl(P, 63, 64);
     }
     ws = wave_sum(ws); dp = wave_sum(dp); r = wave_sum(r); gg = wave_sum(gg); b = wave_sum(b);
-    if (lane == 0) {
+    if (lane == 0 && (!PACK || image)) {
         const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
         image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
         depth[n] = dp;
@@ -540,9 +545,25 @@ int foc_fixed_render_inference(const float *sigma, const float *rgb, const float
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(sigma && rgb && nears && fars && image && depth && weights_sum, FOC_E_INVALID, "fixed_render_inference: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_render_inference: T must be >= 2");
-    hipLaunchKernelGGL(k_fs_render_infer, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
-                       density_scale, thresh, image, depth, weights_sum, rgb_masked);
+    hipLaunchKernelGGL(k_fs_render_infer<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
+                       density_scale, thresh, image, depth, weights_sum, rgb_masked, (float4 *)nullptr);
     FOC_CHECK_LAUNCH("fixed_render_inference");
+    return FOC_OK;
+}
+
+int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
+                         float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
+                         float *field4, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(sigma && rgb && nears && fars && field4, FOC_E_INVALID, "fixed_field_pack: null pointer");
+    FOC_REQUIRE((image && depth && weights_sum) || (!image && !depth && !weights_sum), FOC_E_INVALID,
+                "fixed_field_pack: image, depth and weights_sum go together (all or none)");
+    FOC_REQUIRE(((uintptr_t)field4 & 15) == 0, FOC_E_INVALID, "fixed_field_pack: field4 must be 16-byte aligned");
+    FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_field_pack: T must be >= 2");
+    hipLaunchKernelGGL(k_fs_render_infer<true>, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
+                       density_scale, thresh, image, depth, weights_sum, (float *)nullptr, (float4 *)field4);
+    FOC_CHECK_LAUNCH("fixed_field_pack");
     return FOC_OK;
 }
 

@@ -301,3 +301,33 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         results['densities'] = sigma.view(N, T, 1)
         results['rgbs'] = rgb.view(N, T, 3)
     return results
+
+
+@torch.no_grad()
+def render_field4(model, rays_o, rays_d, num_steps=512, weight_thresh=1e-10, yolo_details=None, out=None):
+    """What the combiner needs from one object for a chunk of rays — COMBINED.py's `run` (:451-534 with upsample_steps=0, perturb off):
+    `densities` [N,T] and `rgbs` [N,T,3] (zero where the object's own compositing weight is <= 1e-10) — PACKED as field4 [N,T,4] fp32
+    (sigma, r, g, b), written into `out` when given. Fused path: sample -> encoder -> whole-field kernel -> weights + mask + pack
+    (foc_fixed_field_pack); other networks go through `model.run(..., return_fields=True)` and are packed with torch ops."""
+    from .field import infer_fusable, field_infer
+    rays_o = rays_o.contiguous().view(-1, 3).float()
+    rays_d = rays_d.contiguous().view(-1, 3).float()
+    N, T = rays_o.shape[0], int(num_steps)
+    dev = rays_o.device
+    if out is None:
+        out = torch.empty(N, T, 4, dtype=torch.float32, device=dev)
+    assert out.shape == (N, T, 4) and out.dtype == torch.float32 and out.is_contiguous()
+    if infer_fusable(model) and not getattr(model, "uses_object_feature", False) and model.bg_radius <= 0:
+        aabb = model.aabb_train if model.training else model.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
+        enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, None, T, model.bound)
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T)
+        check(lib.foc_fixed_field_pack(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), None, None, 1.0, N, T, float(model.density_scale),
+                                       float(weight_thresh), None, None, None, ptr(out), stream_of(sigma)), "fixed_field_pack")
+        return out
+    from .combine import pack_field4
+    with torch.autocast("cuda", dtype=torch.float16):
+        res = model.run(rays_o[None], rays_d[None], yolo_details, num_steps=T, upsample_steps=0, perturb=False, weight_thresh=weight_thresh,
+                        return_fields=True)
+    out.copy_(pack_field4(res['densities'], res['rgbs']))
+    return out

@@ -350,6 +350,19 @@ int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const floa
                               const float *fars, uint32_t N, uint32_t T, float bg,
                               float *image4, float *depth, void *stream);
 
+/* The same select and composite fused over K objects' PACKED fields, the form the one-object-per-GPU exchange moves
+ * (focnerf_amd/combine.py): fields4[k] -> device pointer to object k's [N,T,4] fp32 rows (sigma, r, g, b), k in checkpoint
+ * order (host array of K device pointers, K <= 16; more objects: pre-merge with foc_combine_select4, the rule is
+ * associative over the order). Replaces the object loop of COMBINED.py:598-618 + image_depth_generation :141-200 for one
+ * ray chunk without storing the merged field. bgs: host array of n_bg (1 or 2) background values (the reference composites
+ * white and black, compute_metrics_both_backgrounds); image4 [n_bg,N,4], depth [N]; merged4 [N,T,4] or NULL. */
+int foc_combine_select_composite(const float *const *fields4, uint32_t K, const float *nears, const float *fars,
+                                 uint32_t N, uint32_t T, const float *bgs, uint32_t n_bg, float *image4, float *depth,
+                                 float *merged4, void *stream);
+
+/* acc4 <- select(acc4, field4) on n packed samples (same rule; acc4 holds the earlier objects). */
+int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Fixed-step render path as fused ops. No reference binding: these replace the torch
  * code of nerf/renderer.py:145-221 (== COMBINED.py:451-534) and the glue of nerf/network_ff.py:51-134
@@ -413,6 +426,14 @@ int foc_fixed_render_inference(const float *sigma, const float *rgb, const float
                                const float *noise, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T,
                                float density_scale, float thresh, float *image, float *depth, float *weights_sum,
                                float *rgb_masked, void *stream);
+
+/* foc_fixed_render_inference that also (or only: image, depth and weights_sum may then all be NULL) writes the object's
+ * per-sample field packed as field4 [N,T,4] fp32 = (sigma, rgb where w > thresh else 0): the (`densities`, `rgbs`) pair
+ * of nerf/renderer.py:187 / COMBINED.py:598-600 in the layout foc_combine_select_composite reads. */
+int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *nears, const float *fars,
+                         const float *noise, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T,
+                         float density_scale, float thresh, float *image, float *depth, float *weights_sum,
+                         float *field4, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Per-sample network glue for callers with arbitrary sample lists (the occupancy-grid paths): the torch

@@ -8,6 +8,7 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * nerf.renderer.NeRFRenderer.run            -> run_foc.npz     (FOC fixed-step compositing, mask w > 1e-10)
   * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
   * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
+  * editable.py modify_rays_for_object / get_object_type_from_ckpt / batch_run / run / select / composite (same way), 8 objects, 2 views -> editable.npz
   * gridencoder.GridEncoder / grid_encode and ffmlp.FFMLP / ffmlp_forward (the Python wrappers, on oracle-backed stub backends) -> wrappers.npz
   * raymarching/raymarching.py wrappers (same arrangement; Tensor.cuda patched to the identity for the run) -> raymarching_wrappers.npz
   (legacy/nerf/renderer.py is not importable here: its `from .utils import custom_meshgrid` pulls in
@@ -256,6 +257,107 @@ def combined_fixture(K=4, N=40, T=64):
         out[f"depth_{bg}"] = dep.numpy()
     nears, fars = _near_far(o, d, aabb, 0.2)
     out["nears"], out["fars"] = nears.numpy(), fars.numpy()
+    return out
+
+
+def editable_fixture(N_hw=(5, 8), T=32, chunk=16):
+    """configs[4]: editable.py's per-view object loop (:640-700) on EIGHT objects, two views, with the edited object's ray offset.
+    editable.py cannot be imported (moviepy, ultralytics, lpips, cv2 ... at the top; its logic sits in methods of a class defined inside
+    the `__main__` block), so the methods on the path — modify_rays_for_object (:443-471), get_object_type_from_ckpt (:500-508),
+    batch_run (:215-252), run (:511-…), best_densities_and_colors_v3 (:259-263), image_depth_generation — are located with `ast`,
+    compiled from the reference file where it lies and bound to a stand-in object carrying what they reach for (`self.model`, `self.B/N/H/W`;
+    globals `opt`, `model`, `device`, `raymarching` = this repo's oracle near/far, `F`). The objects are analytic fields; `model` (the
+    script's one network whose weights it reloads per object) is switched to object k where the script calls load_checkpoint.
+    Stored per view: the data rays, every object's modified rays, its raw per-sample field and what `run` returned (densities, rgbs
+    masked by its own weights > 1e-10, the weights themselves), the merged field and both composites."""
+    import ast
+    import textwrap
+    path = os.path.join(REF, "editable.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    names = ("modify_rays_for_object", "get_object_type_from_ckpt", "batch_run", "run", "best_densities_and_colors_v3", "image_depth_generation")
+    wanted = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in wanted:
+            wanted[node.name] = textwrap.dedent(ast.get_source_segment(src, node))
+    assert set(wanted) == set(names), sorted(wanted)
+    H, W = N_hw
+    N = H * W
+    dev = torch.device("cpu")
+    opt = types.SimpleNamespace(num_steps=T, upsample_steps=0, max_ray_batch=chunk, edit_object="bottle", offset_x=0.01, offset_y=0.01, offset_z=0.60)
+    ns = {"torch": torch, "raymarching": rm, "opt": opt, "F": torch.nn.functional, "device": dev, "model": None}
+    for code in wanted.values():
+        exec(compile(code, path, "exec"), ns)
+    Ed = type("Ed", (), {n: ns[n] for n in names})
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    me = Ed()
+    me.model = types.SimpleNamespace(aabb_train=aabb, aabb_infer=aabb, training=False, min_near=0.2)
+    # checkpoint names: the type is the first of ['book','chair','bottle','cup'] that is a SUBSTRING of the path (:500-508)
+    ckpts = ["ws/book_a/ngp.pth", "ws/cup_a/ngp.pth", "ws/bottle_a/ngp.pth", "ws/box_a/ngp.pth", "ws/chair/ngp.pth", "ws/cupboard/ngp.pth",
+             "ws/bottle_b/ngp.pth", "ws/notebook/ngp.pth"]
+    K = len(ckpts)
+    raw_log = {}
+
+    class Toy:
+        def __init__(self, k):
+            g = torch.Generator().manual_seed(100 + k)
+            self.k = k
+            self.c = (torch.rand(3, generator=g) - 0.5) * 0.9
+            self.amp = 20.0 + 10.0 * k
+            self.width = 0.05 + 0.02 * k
+
+        def density(self, x):
+            r2 = ((x - self.c) ** 2).sum(-1)
+            sig = self.amp * torch.exp(-r2 / self.width)
+            sig = torch.where(sig < 0.05, torch.zeros_like(sig), sig)        # empty space: exact zeros, hence ties between objects
+            return {'sigma': sig, 'geo_feat': x[..., :2] * 0.0}
+
+        def color(self, x, d, yolo_details, mask=None, geo_feat=None, **kw):
+            raw = 0.5 + 0.5 * torch.sin(3.0 * x + 0.7 * d + float(self.k))
+            raw_log.setdefault(self.k, []).append(raw.clone())
+            rgbs = torch.zeros(mask.shape[0], 3)
+            rgbs[mask] = raw[mask]
+            return rgbs
+
+    toys = [Toy(k) for k in range(K)]
+    toys[5].c = toys[1].c.clone(); toys[5].amp = toys[1].amp; toys[5].width = toys[1].width   # objects 1 and 5 have the SAME density: exact ties, 1 wins
+    out = dict(K=np.int32(K), T=np.int32(T), chunk=np.int32(chunk), HW=np.array([H, W], np.int32), aabb=aabb.numpy(), min_near=np.float32(0.2),
+               ckpts=np.array(ckpts), edit_object=np.array(opt.edit_object), offset=np.array([opt.offset_x, opt.offset_y, opt.offset_z], np.float64),
+               object_types=np.array([str(me.get_object_type_from_ckpt(c)) for c in ckpts]))
+    for v in range(2):
+        o, d = make_rays(N, 40 + v, 1)
+        data = {"rays_o": o, "rays_d": d}
+        me.B, me.H, me.W, me.N = 1, H, W, N
+        max_d = None
+        mod_o, mod_d, dens_all, rgbs_all, raw_all = [], [], [], [], []
+        for k, ck in enumerate(ckpts):                                        # editable.py:660-700
+            ns["model"] = toys[k]                                             # self.load_checkpoint(self.ckpt)
+            raw_log.clear()
+            mo, md = me.modify_rays_for_object(o, d, None, ck)
+            res = me.batch_run(mo, md, None, **vars(opt))
+            dens, rgbs = res['densities'], res['rgbs']
+            mod_o.append(mo.clone().numpy()); mod_d.append(md.clone().numpy())
+            dens_all.append(dens.numpy().copy()); rgbs_all.append(rgbs.numpy().copy())
+            raw_all.append(torch.cat(raw_log[k], 0).view(N, T, 3).numpy())
+            if max_d is None:
+                max_d, max_rgb = dens, rgbs
+            else:
+                max_d, max_rgb = me.best_densities_and_colors_v3(dens, max_d, rgbs, max_rgb)
+        out.update({f"v{v}_rays_o": o.numpy(), f"v{v}_rays_d": d.numpy(), f"v{v}_mod_o": np.stack(mod_o), f"v{v}_mod_d": np.stack(mod_d),
+                    f"v{v}_densities": np.stack(dens_all)[:, 0], f"v{v}_rgbs": np.stack(rgbs_all)[:, 0], f"v{v}_raw_rgbs": np.stack(raw_all),
+                    f"v{v}_max_densities": max_d.numpy()[0], f"v{v}_max_rgbs": max_rgb.numpy()[0]})
+        for bg in ("white", "black"):
+            img, dep = me.image_depth_generation(data, max_d.clone(), max_rgb.clone(), bg)
+            out[f"v{v}_image_{bg}"] = img.numpy()
+            out[f"v{v}_depth_{bg}"] = dep.numpy()
+        nears, fars = _near_far(o, d, aabb, 0.2)
+        out[f"v{v}_nears"], out[f"v{v}_fars"] = nears.numpy(), fars.numpy()
+        # every object's own near / far (of its modified rays) and compositing weights, to tell borderline mask decisions apart
+        own = []
+        for k in range(K):
+            n_k, f_k = _near_far(torch.from_numpy(mod_o[k]), torch.from_numpy(mod_d[k]), aabb, 0.2)
+            own.append(np.stack([n_k.numpy(), f_k.numpy()]))
+        out[f"v{v}_own_near_far"] = np.stack(own)
     return out
 
 
@@ -511,6 +613,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "run_foc_b2.npz"), **run_reference(foc_renderer, True, bound=2, N=64, T=512, seed=2))
     np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
     np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
+    np.savez_compressed(os.path.join(HERE, "editable.npz"), **editable_fixture())
     np.savez_compressed(os.path.join(HERE, "wrappers.npz"), **wrapper_fixture())
     np.savez_compressed(os.path.join(HERE, "raymarching_wrappers.npz"), **raymarching_wrapper_fixture())
     for f in sorted(os.listdir(HERE)):

@@ -159,7 +159,7 @@ def test_graph_keeps_its_scratch_when_a_later_call_needs_more():
     del junk
     ge, gw = g(x, gy)
     torch.cuda.synchronize()
-    assert torch.equal(gw, gw_ref)
+    torch.testing.assert_close(gw.float(), gw_ref.float(), rtol=2e-2, atol=2e-3)      # dW: fp32 atomics across workgroups, order dependent
     assert torch.equal(ge, ge_ref)                              # the binned backward is deterministic (fixed-point sums)
 
 
