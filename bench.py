@@ -2,16 +2,24 @@
 """bench.py — headline benchmark of the FOCNeRF hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, one OBJECT per rank — weak scaling)
+
+N > 1: one rank per GPU, one OBJECT per rank (weak scaling). Either launched by torch.distributed.run (RANK / WORLD_SIZE in the
+environment), or — `python bench.py --gpus N` on its own — this process starts the N ranks itself (torch.distributed.run as a CHILD
+process, before anything here touches the GPU) and exits with their status.
 
 Workload (BASELINE.json configs[1]): single-object hash-grid + fused-MLP NeRF, fp16 autocast, rays
 drawn from synthetic 800x800 views, FOC's default fixed-step renderer (num_steps=512,
 upsample_steps=0, nerf/renderer.py:126-238): one STEP = 4096 rays x 512 samples = 2 097 152 samples
 through R1 -> G1 -> M1(sigma) -> weights -> M1(colour, masked) -> composite -> loss -> backward
 (M2, G2) -> Adam. `value` = samples completed per second, whole job (sum over ranks), inputs resident
-in HBM. Extra keys: `render` (full 800x800 view, rays/s), `occupancy_path` (config[2]: march +
-composite kernels), `roofline` (dominant kernel, timed with events on the launch stream),
-`cpu_baseline` (the CPU oracle port on a bounded sample, rank 0 / N=1 only).
+in HBM. Extra keys: `combined_render` (EVERY N: K = N objects, one per rank, full 800x800 view — per-rank field evaluation + exchange by
+ray + select/composite + gather, COMBINED.py:592-618 — rays/s, bytes on the wire, share of xGMI and of the field evaluation),
+`render` (full 800x800 view, rays/s), `occupancy_path` (config[2]: march + composite kernels), `roofline` (dominant kernel, timed with
+events on the launch stream), `cpu_baseline` (rank 0 / N=1 only: the CPU oracle port on a bounded sample, and configs[0] — the
+reference's pure-PyTorch network through the fixed-step renderer on the host cores).
+
+`--dry-run-cpu`: no GPU — gloo ranks exercising the launch and the combined-render leg's host/collective logic with CPU ops injected
+from the tests; the training metric is null there (the product has no CPU path).
 """
 import argparse
 import json
@@ -267,6 +275,122 @@ def cpu_baseline(budget_s=10.0, one_core_s=4.0):
                       f"(+ {e1:.1f} s single-core run)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child `python -m torch.distributed.run` (one rank per GPU over
+    RCCL) and return its exit status. Nothing in THIS process has touched the GPU (no HIP call, no torch.cuda query) — the ranks are
+    fresh processes, never an exec of a process that initialised a device."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS):
+    """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (4096-ray chunks, packed
+    per-sample fields), the chunks are exchanged by ray (all-to-all over xGMI), every rank selects + composites its ray slices for both
+    backgrounds, one all-gather per view assembles the images. Timed against the same view with the field evaluation alone.
+    `fused_fn(lo, hi, out)` = this rank's object; `ops` = None (HIP) or injected CPU ops (dry run)."""
+    import torch.distributed as dist
+    from focnerf_amd.combine import ObjectCombiner, HipCombineOps
+    comb = ObjectCombiner(rank=rank, world_size=world, ops=ops or HipCombineOps)
+    n_rays = n_side * n_side
+    nears, fars = model["nears"], model["fars"]
+
+    def one_view():
+        return comb.render_view([fused_fn], n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk)
+
+    def eval_only():
+        buf = torch.empty(chunk, T, 4, dtype=torch.float32, device=device)
+        for lo in range(0, n_rays, chunk):
+            hi = min(lo + chunk, n_rays)
+            fused_fn(lo, hi, buf[: hi - lo])
+
+    img, dep = one_view()                                  # untimed: allocator block sizes, RCCL channel set-up
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(views):
+        img, dep = one_view()
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0) / views
+    sent = comb.bytes_sent
+    eval_only()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(views):
+        eval_only()
+    barrier()
+    el_eval = max_over_ranks(time.perf_counter() - t0) / views
+    links = max(world - 1, 1)
+    out = {"metric": "combined_render_rays_per_sec", "value": n_rays / el, "unit": "rays/s", "objects": world, "object_rays_per_sec": world * n_rays / el,
+           "s_per_view": el, "views": views, "view": f"{n_side}x{n_side}", "samples_per_ray": T, "backgrounds": 2,
+           "field_eval_only_s_per_view": el_eval, "exchange_and_composite_share_of_field_eval": (el - el_eval) / el_eval if el_eval > 0 else None,
+           "bytes_sent_per_view_per_gpu": int(sent),
+           "xgmi": {"achieved_GBps_per_gpu": sent / el / 1e9, "peak_GBps_per_gpu": links * 153.0 if world > 1 else None,
+                    "frac_of_peak": (sent / el / 1e9) / (links * 153.0) if world > 1 else None,
+                    "note": "bytes this rank put on the wire per view / wall time per view; peak = (N-1) point-to-point links x 153 GB/s"},
+           "image_checksum": float(img.double().sum().item()),
+           "path": "per rank: near/far -> sample -> hash-grid -> whole-field kernel -> own weights + mask + pack (16 B/sample); all-to-all by ray per "
+                   "4096-ray chunk, overlapped with the next chunk's evaluation; fused select + composite of the rank's ray slices, both backgrounds; "
+                   "one all-gather per view (COMBINED.py:592-618, 141-200, 247-251)"}
+    return out
+
+
+def dry_run_cpu(args):
+    """CPU / gloo rehearsal of the N-rank launch and of the combined-render leg's host and collective logic (no GPU, no HIP kernel: the
+    per-sample fields are synthetic arrays and the select / composite are the CPU ops the tests inject)."""
+    import numpy as np
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("FOC_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole launch
+        raise SystemExit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_combine_gloo import CpuOps
+    device = torch.device("cpu")
+    n_side, T, chunk = 24, 32, 96
+    rng = np.random.default_rng(7 + rank)
+    n_rays = n_side * n_side
+    f4 = torch.from_numpy(rng.random((n_rays, T, 4)).astype(np.float32))
+    f4[..., 0] *= 20.0
+
+    def fn(lo, hi, out):
+        if out is not None:
+            out.copy_(f4[lo:hi])
+            return out
+        return f4[lo:hi].clone()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+    geom = {"nears": torch.full((n_rays,), 0.5), "fars": torch.full((n_rays,), 2.5)}
+    leg = combined_render_leg(rank, world, device, geom, 1, fn, barrier, max_over_ranks, chunk=chunk, ops=CpuOps, n_side=n_side, T=T)
+    result = {"metric": "train_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+              "config": {"workload": "DRY RUN on CPU/gloo: launch + combined-render collective logic only; the training step has no CPU path"},
+              "combined_render": leg}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,7 +400,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the render / occupancy-path extras")
     ap.add_argument("--no-fused", action="store_true", help="headline step through the torch glue of NeRFRenderer.run instead of csrc/fixedstep.hip")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="no GPU: gloo ranks, combined-render leg on injected CPU ops (launch / collective logic only)")
+    ap.add_argument("--combined-views", type=int, default=2)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -285,7 +416,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # a rank that fails inside a collective leg must not leave the others waiting for the driver's kill: collectives time out
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -312,7 +445,8 @@ def main():
     scaler = torch.amp.GradScaler("cuda")
     poses, intr = make_training_rays(device, bound, 8, seed=rank)
     gen = torch.Generator().manual_seed(1000 + rank)
-    batches = [sample_batch(poses, intr, device, gen) for _ in range(4)]
+    # one distinct ray batch per timed step (and per warm-up step), drawn before the timed region: data loading is not part of the path
+    batches = [sample_batch(poses, intr, device, gen) for _ in range(max(4, min(args.steps + args.warmup, 256)))]
 
     timer = KernelTimer()
     timer.install()
@@ -338,7 +472,7 @@ def main():
     t0 = time.perf_counter()
     step_marks[0].record()
     for i in range(args.steps):
-        train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused, sched=sched)
+        train_step(model, opt, scaler, *batches[(args.warmup + i) % len(batches)], fused=fused, sched=sched)
         step_marks[i + 1].record()
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
@@ -356,6 +490,9 @@ def main():
         "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic", "step_ms": step_stats,
+        "numerics": "fp16 storage, fp32 MFMA accumulation (the reference accumulates in fp16): sample indices / positions bit-exact, hash-grid forward "
+                    "bit-exact vs the oracle, MLP outputs within a few fp16 ulps of the reference-literal fp16 accumulation (so sigma = exp(h0) ~1e-3 "
+                    "relative), composites 1e-4 — tolerances stated per test in tests/",
         "config": {"workload": "configs[1]: single-object hash-grid(L16,C2,2^19)+ffmlp fp16 NeRF, rays from synthetic 800x800 views, "
                                "fixed-step renderer num_steps=512", "rays_per_step": NUM_RAYS, "samples_per_step": samples_per_step,
                    "objects": world, "parallelism": f"one object per GPU x{world}", "optimizer": "Adam(fused) inside the timed step",
@@ -506,33 +643,41 @@ def main():
             result["extras_error"] = repr(e)
 
     if not args.no_extras:
-        # ---- configs[3]/[4]: per-sample multi-object combine, one object per rank (RCCL MAX all-reduce of keys + SUM of the winner's rgb)
+        # ---- configs[3]/[4]: K = N objects, one per rank, a full 800x800 view end to end (field evaluation + exchange + composite + gather)
         model.eval()
         try:
-            from focnerf_amd.combine import ObjectCombiner
             from focnerf_amd import raymarching as rm
-            comb = ObjectCombiner(rank=rank, world_size=world)
-            chunk = 4096
-            co, cd = rays_o[0, :chunk].contiguous(), rays_d[0, :chunk].contiguous()
-            cn, cf = rm.near_far_from_aabb(co, cd, model.aabb_infer, model.min_near)
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-                fld = model.run(co[None], cd[None], num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=fused, return_fields=True)
-            dens, rgbf = fld["densities"].squeeze(-1).float().contiguous(), fld["rgbs"].float().contiguous()
-            for _ in range(2):
-                comb.render_chunk(dens, rgbf, cn, cf, bg=1.0)
-            barrier()
-            t0 = time.perf_counter()
-            nck = 20
-            for _ in range(nck):
-                comb.render_chunk(dens, rgbf, cn, cf, bg=1.0)
-            barrier()
-            elc = max_over_ranks(time.perf_counter() - t0)
-            result["combine"] = {"metric": "combine_rays_per_sec", "value": chunk * nck / elc, "unit": "rays/s", "objects": world,
-                                 "bytes_exchanged_per_chunk": (8 + 12) * chunk * NUM_STEPS if world > 1 else 0,
-                                 "path": "ObjectCombiner.render_chunk: key pack -> all-reduce(MAX) -> unpack -> all-reduce(SUM) -> ray-sliced composite -> all-gather "
-                                         "(field evaluation excluded; 4096-ray x 512-sample chunks)"}
-        except Exception as e:   # the combine extra must never take the headline number down with it
-            result["combine"] = {"error": repr(e)}
+            from focnerf_amd.field import half_cache_scope
+            from focnerf_amd.fixedstep import render_field4
+            vo, vd = rays_o[0].contiguous(), rays_d[0].contiguous()
+            vn, vf = rm.near_far_from_aabb(vo, vd, model.aabb_infer, model.min_near)
+
+            def my_object(lo, hi, out):
+                return render_field4(model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, out=out)
+            with torch.no_grad(), half_cache_scope():
+                result["combined_render"] = combined_render_leg(rank, world, device, {"nears": vn, "fars": vf}, args.combined_views, my_object, barrier,
+                                                                max_over_ranks)
+            if world == 1:
+                # the single-GPU form of the same job: K = 4 objects RESIDENT on one device (COMBINED.py reloads a checkpoint per object per view)
+                others = [build_model(bound, device, cuda_ray=False, seed=100 + k).eval() for k in range(3)]
+                objs = [model] + others
+                from focnerf_amd.combine import ObjectCombiner
+                comb1 = ObjectCombiner(rank=0, world_size=1)
+                fns = [(lambda lo, hi, out, m=m: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, out=out)) for m in objs]
+                with torch.no_grad(), half_cache_scope():
+                    comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
+                    barrier()
+                    t0 = time.perf_counter()
+                    comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
+                    barrier()
+                el4 = time.perf_counter() - t0
+                result["combined_render"]["resident_4_objects_one_gpu"] = {"s_per_view": el4, "rays_per_sec": VIEW * VIEW / el4,
+                                                                           "object_rays_per_sec": 4 * VIEW * VIEW / el4,
+                                                                           "note": "configs[3] on ONE GPU: 4 resident objects, per chunk 4 field evaluations + "
+                                                                                   "one select/composite kernel; the N-GPU job's single-device baseline"}
+        except Exception as e:   # an extra must never take the headline number down with it
+            import traceback
+            result["combined_render"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,35 @@
+"""CPU: `python bench.py --gpus N` starts its N ranks itself (no launcher, WORLD_SIZE unset) and the combined-render leg runs at N > 1.
+Rehearsed over gloo with CPU ops injected (`--dry-run-cpu`): the launch, the rendezvous on 127.0.0.1, the by-ray exchange, the gather and
+the one JSON line of rank 0. The GPU form of the same leg is exercised on the box by bench.py itself (N = 1) and by the driver (N > 1)."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                  # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_prints_one_line_with_the_combined_leg():
+    r = _run(2)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    leg = r["combined_render"]
+    assert "error" not in leg and leg["objects"] == 2 and leg["value"] > 0
+    assert leg["bytes_sent_per_view_per_gpu"] > 0 and leg["xgmi"]["peak_GBps_per_gpu"] == 153.0
+    single = _run(1)
+    assert single["n_gpus"] == 1 and single["combined_render"]["bytes_sent_per_view_per_gpu"] == 0
+
+
+def test_a_failing_rank_fails_the_launch():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FOC_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
