@@ -681,6 +681,13 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+        try:
+            # configs[0] as BASELINE.md §2 defines it: the reference's pure-PyTorch network through the fixed-step renderer, fp32 torch ops on
+            # the host cores (oracle/torch_cpu_nerf.py, pinned to the reference's own network class + run() by tests/golden/cpu_network.npz)
+            from oracle import torch_cpu_nerf
+            result["cpu_baseline"]["configs0_torch_cpu"] = torch_cpu_nerf.time_baseline()
+        except Exception as e:
+            result["cpu_baseline"]["configs0_torch_cpu"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))

@@ -8,6 +8,8 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * nerf.renderer.NeRFRenderer.run            -> run_foc.npz     (FOC fixed-step compositing, mask w > 1e-10)
   * nerf.renderer.NeRFRenderer.mark_untrained_grid / update_extra_state -> grid_maintenance.npz (grid size 32)
   * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
+  * nerf.network.NeRFNetwork (the pure-PyTorch network class) through nerf.renderer.NeRFRenderer.run, on the encoders of
+    oracle/torch_cpu_nerf.py -> cpu_network.npz (pins the CPU baseline of configs[0])
   * editable.py modify_rays_for_object / get_object_type_from_ckpt / batch_run / run / select / composite (same way), 8 objects, 2 views -> editable.npz
   * gridencoder.GridEncoder / grid_encode and ffmlp.FFMLP / ffmlp_forward (the Python wrappers, on oracle-backed stub backends) -> wrappers.npz
   * raymarching/raymarching.py wrappers (same arrangement; Tensor.cuda patched to the identity for the run) -> raymarching_wrappers.npz
@@ -361,6 +363,63 @@ def editable_fixture(N_hw=(5, 8), T=32, chunk=16):
     return out
 
 
+def cpu_network_fixture(N=48, T=64, bound=2):
+    """configs[0]: the reference's pure-PyTorch network CLASS (nerf/network.py:10-210: nn.Linear sigma / colour nets, trunc_exp, sigmoid,
+    masked colour query) driven by the reference's own NeRFRenderer.run (nerf/renderer.py:126-238), on the CPU. What the reference lacks
+    to do that is supplied from oracle/torch_cpu_nerf.py — the thing this fixture pins: `encoding.get_encoder` (the module nerf/network.py:5
+    imports and the tree does not contain; a SMALL hash grid here — 8 levels, 2^12 rows — so that the parameters fit in the fixture) and
+    near_far_from_aabb (CUDA-only in the reference). One adapter: FOC's run() calls `self.color(x, d, yolo_details, mask=...)`
+    (nerf/renderer.py:187) but nerf/network.py's color() has no yolo_details parameter (only network_tcnn.py's has) — the subclass below
+    drops that positional argument and calls the reference method.
+    Stored: parameters, rays, eval-mode image / depth / weights_sum, and a training-mode loss with its parameter gradients."""
+    from oracle import torch_cpu_nerf as tcn
+    small = dict(num_levels=8, base_resolution=8, log2_hashmap_size=12, desired_resolution=128)
+    enc_stub = types.ModuleType("encoding")
+    enc_stub.get_encoder = lambda encoding, **kw: tcn.get_encoder(encoding, **{**kw, **(small if encoding == "hashgrid" else {})})
+    sys.modules["encoding"] = enc_stub
+    import nerf.network as ref_net
+    assert ref_net.__file__.startswith(REF)
+    saved_nf = rm.near_far_from_aabb
+    rm.near_far_from_aabb = lambda o, d, aabb, min_near=0.2: tcn.near_far(o, d, aabb, min_near)
+    try:
+        class Net(ref_net.NeRFNetwork):
+            def color(self, x, d, yolo_details=None, mask=None, geo_feat=None, **kw):
+                return ref_net.NeRFNetwork.color(self, x, d, mask=mask, geo_feat=geo_feat)
+
+        torch.manual_seed(123)
+        m = Net(bound=bound)
+        m.encoder.embeddings.data.uniform_(-0.6, 0.6)
+        o, d = make_rays(N, 77, bound)
+        out = dict(bound=np.float32(bound), T=np.int32(T), rays_o=o.numpy(), rays_d=d.numpy(), encoder_cfg=np.array([small[k] for k in
+                   ("num_levels", "base_resolution", "log2_hashmap_size", "desired_resolution")], np.int32))
+        for k, v in m.state_dict().items():
+            out["param/" + k] = v.detach().numpy().copy()
+        m.eval()
+        with torch.no_grad():
+            ev = m.run(o[None], d[None], None, num_steps=T, upsample_steps=0, bg_color=None, perturb=False)
+        out.update(eval_image=ev["image"][0].numpy(), eval_depth=ev["depth"][0].numpy(), eval_weights_sum=ev["weights_sum"].numpy(),
+                   eval_densities=ev["densities"].squeeze(-1).numpy(), eval_rgbs=ev["rgbs"].numpy())
+        m.train()
+        target = 0.5 + 0.5 * torch.sin(3.0 * d)
+        tr = m.run(o[None], d[None], (torch.ones(1, N, T, dtype=torch.bool), None, None), num_steps=T, upsample_steps=0, bg_color=None, perturb=False)
+        hit = tr["weights_sum"] > -1
+        loss = torch.nn.functional.mse_loss(tr["image"][0][torch.isfinite(tr["depth"][0])], target[torch.isfinite(tr["depth"][0])])
+        loss.backward()
+        out.update(train_target=target.numpy(), train_loss=np.float32(loss.item()), train_outside=np.float32(tr["criterion_outside_mask"].item()),
+                   grad_embeddings=m.encoder.embeddings.grad.numpy().copy())
+        for i, lin in enumerate(m.sigma_net):
+            out[f"grad_sigma_net_{i}"] = lin.weight.grad.numpy().copy()
+        for i, lin in enumerate(m.color_net):
+            out[f"grad_color_net_{i}"] = lin.weight.grad.numpy().copy()
+        nears, fars = tcn.near_far(o, d, m.aabb_infer, m.min_near)
+        n2, f2 = _near_far(o, d, m.aabb_infer, m.min_near)
+        assert torch.equal(nears, n2) and torch.equal(fars, f2)            # torch restatement == C oracle on these rays
+        out["nears"], out["fars"] = nears.numpy(), fars.numpy()
+    finally:
+        rm.near_far_from_aabb = saved_nf
+    return out
+
+
 def wrapper_fixture():
     """The reference's Python operator wrappers (gridencoder/grid.py GridEncoder + grid_encode, ffmlp/ffmlp.py FFMLP + ffmlp_forward)
     driven on the CPU with their pybind11 backends replaced by stubs of the same names that call this repo's oracle. What the fixture
@@ -614,6 +673,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "grid_maintenance.npz"), **grid_maintenance())
     np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
     np.savez_compressed(os.path.join(HERE, "editable.npz"), **editable_fixture())
+    np.savez_compressed(os.path.join(HERE, "cpu_network.npz"), **cpu_network_fixture())
     np.savez_compressed(os.path.join(HERE, "wrappers.npz"), **wrapper_fixture())
     np.savez_compressed(os.path.join(HERE, "raymarching_wrappers.npz"), **raymarching_wrapper_fixture())
     for f in sorted(os.listdir(HERE)):
