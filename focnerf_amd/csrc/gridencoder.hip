@@ -30,6 +30,7 @@
 struct GeLevels {
     float scale[GE_MAX_LEVELS];
     uint32_t resolution[GE_MAX_LEVELS];
+    uint32_t merge_max_res;                    // binned backward: levels up to this resolution merge runs of samples in one cell (count + scatter)
 };
 
 // ---- storage-type helpers -------------------------------------------------------------
@@ -539,10 +540,10 @@ __device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap
 // lanes a run of lanes with equal cells is summed on the lanes (segmented DPP scan, fp32) and only the run's last lane emits
 // records. The count and the scatter kernel derive the run structure from the same values with the same code, so their record
 // counts agree by construction.
-#define GB_MERGE_MAX_RES 700u                  // levels above this resolution are not merged (cells < 2^10 per axis needed for the key)
+#define GB_MERGE_MAX_RES 1000u                 // default; levels above this resolution are not merged (and cells < 2^10 per axis are needed for the key)
 template <int CTRL>
 __device__ __forceinline__ uint32_t gb_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
-struct GbRun { uint32_t f0, f1, f2, f3; bool tail; };       // f_k: "do not add from lane - 2^k" at scan step k
+struct GbRun { uint32_t f0, f1, f2, f3; float k0, k1, k2, k3; bool tail; };       // f_k: "do not add from lane - 2^k" at scan step k; k_k = f_k ? 0 : 1
 __device__ __forceinline__ GbRun gb_run_flags(bool inside, const uint32_t (&pos_grid)[3]) {
     const uint32_t r = threadIdx.x & 15u;
     const uint32_t key = inside ? (pos_grid[0] | (pos_grid[1] << 10) | (pos_grid[2] << 20)) : 0xFFFFFFFFu;
@@ -555,15 +556,67 @@ __device__ __forceinline__ GbRun gb_run_flags(bool inside, const uint32_t (&pos_
     run.f3 = run.f2 | gb_dpp<0x114>(run.f2);
     const uint32_t next_head = gb_dpp<0x101>(head);                         // row_shl:1
     run.tail = inside && (r == 15u || next_head != 0u);
+    run.k0 = run.f0 ? 0.0f : 1.0f; run.k1 = run.f1 ? 0.0f : 1.0f; run.k2 = run.f2 ? 0.0f : 1.0f; run.k3 = run.f3 ? 0.0f : 1.0f;
     return run;
 }
+// One scan step = ONE instruction, v_fmac_f32_dpp: v += k * (v of lane - 2^step), k in {0, 1}. fma(u, 1, v) is the correctly rounded
+// u + v and fma(u, 0, v) is v for every finite u, so finite data give the bits of the select form (add, then v_cndmask: two
+// instructions per step and value, 128 per merged level). A non-finite addend of a neighbouring run turns into NaN here (inf * 0)
+// where the select form would not have looked at it — in a step whose gradients already hold inf / NaN, which the AMP scaler discards
+// whole (FOC_GB_MERGE_SELECT=1 at build time keeps the select form).
 __device__ __forceinline__ float gb_run_sum(float v, const GbRun &run) {
     float u;
+#ifdef FOC_GB_MERGE_SELECT
     u = __uint_as_float(gb_dpp<0x111>(__float_as_uint(v))); v = run.f0 ? v : v + u;
     u = __uint_as_float(gb_dpp<0x112>(__float_as_uint(v))); v = run.f1 ? v : v + u;
     u = __uint_as_float(gb_dpp<0x114>(__float_as_uint(v))); v = run.f2 ? v : v + u;
     u = __uint_as_float(gb_dpp<0x118>(__float_as_uint(v))); v = run.f3 ? v : v + u;
+#else
+    u = __uint_as_float(gb_dpp<0x111>(__float_as_uint(v))); v = fmaf(u, run.k0, v);
+    u = __uint_as_float(gb_dpp<0x112>(__float_as_uint(v))); v = fmaf(u, run.k1, v);
+    u = __uint_as_float(gb_dpp<0x114>(__float_as_uint(v))); v = fmaf(u, run.k2, v);
+    u = __uint_as_float(gb_dpp<0x118>(__float_as_uint(v))); v = fmaf(u, run.k3, v);
+#endif
     return v;
+}
+// The same scan over the 16 values of a (point, level) — 8 corners x 2 channels — with every step ONE v_fmac_f32_dpp per value (the
+// compiler does not fold the DPP move into the fmac: it emits v_mov_b32_dpp + v_fmac, two instructions, like the select form). The 16
+// instructions of a step are independent, so the "VALU write -> DPP read of the same VGPR" hazard (2 wait states on gfx9) only exists
+// at the head of a block: one s_nop there covers it whatever precedes the block.
+#ifndef FOC_GB_MERGE_SELECT
+#define GB_FMAC16(CTRL)                                                                                                                  \
+    asm volatile("s_nop 1\n\t"                                                                                                           \
+                 "v_fmac_f32_dpp %0, %0, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %1, %1, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %2, %2, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %3, %3, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %4, %4, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %5, %5, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %6, %6, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %7, %7, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %8, %8, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %9, %9, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                       \
+                 "v_fmac_f32_dpp %10, %10, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                     \
+                 "v_fmac_f32_dpp %11, %11, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                     \
+                 "v_fmac_f32_dpp %12, %12, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                     \
+                 "v_fmac_f32_dpp %13, %13, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                     \
+                 "v_fmac_f32_dpp %14, %14, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                     \
+                 "v_fmac_f32_dpp %15, %15, %16 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                          \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),   \
+                   "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])                                           \
+                 : "v"(k))
+#endif
+__device__ __forceinline__ void gb_run_sum16(float (&v)[16], const GbRun &run) {
+#ifdef FOC_GB_MERGE_SELECT
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = gb_run_sum(v[i], run);
+#else
+    float k;
+    k = run.k0; GB_FMAC16("row_shr:1");
+    k = run.k1; GB_FMAC16("row_shr:2");
+    k = run.k2; GB_FMAC16("row_shr:4");
+    k = run.k3; GB_FMAC16("row_shr:8");
+#endif
 }
 
 // ---- one-point-per-thread count / scatter -------------------------------------------------------
@@ -629,7 +682,7 @@ __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uin
             uint32_t pg[3]; float pf[3];
             gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
             bool emit = inside;
-            if (resolution <= GB_MERGE_MAX_RES) emit = gb_run_flags(inside, pg).tail;
+            if (resolution <= lv.merge_max_res) emit = gb_run_flags(inside, pg).tail;
             if (emit) {
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
@@ -708,6 +761,12 @@ __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restric
 // inside the LDS staging array is known up front; each record takes its place with one LDS cursor atomic, and the staging array is
 // copied out flat, so a wave stores 512 contiguous bytes. Two barriers per level; the bases of the next level are fetched while the
 // current one is ranked.
+// Workgroup barrier that orders LDS traffic only. `__syncthreads()` is a workgroup-scope release/acquire on ALL memory: the compiler
+// drains vmcnt before it, so every wave would sit at each of the 2 x L barriers until its copy-out stores to the record arrays had been
+// acknowledged by memory (and the prefetched gradient load had landed). The records are consumed by the next kernel, never by this one;
+// only the LDS staging arrays are shared across the barrier.
+__device__ __forceinline__ void gb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
@@ -728,34 +787,18 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
     float x[3] = {0.f, 0.f, 0.f};
     const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
-    // gradient row of this point: fp16 -> one dword (half2) per level, fp32 -> two
+    // gradient of this point, one level at a time: fp16 -> one dword (half2) per level, fp32 -> two. The value of level l + 1 is fetched
+    // while level l is processed ([L,B,C] planes, the reference's layout, gridencoder.cu:283: a coalesced dword per lane; [B, L*C] rows:
+    // the lane's own 64-byte row, one sector). Holding all L values in registers spilled them to scratch at the 64-register budget of two
+    // workgroups per CU: 128 B per point written and read back through the memory system, 0.27 GB per 2 M points.
     constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
-    uint32_t gq[GE_MAX_LEVELS * GW];
-    if (grad_bl) {                                         // [B, L*C]: one 64-byte row per point
-        const uint32_t *gp = reinterpret_cast<const uint32_t *>(grad + (uint64_t)(b < B ? b : 0u) * L * 2);
-        const bool vec = ((L * GW) & 3u) == 0u;
+    const uint32_t bq = b < B ? b : 0u;
+    const uint32_t *gp = grad_bl ? reinterpret_cast<const uint32_t *>(grad) + (uint64_t)bq * L * GW
+                                 : reinterpret_cast<const uint32_t *>(grad) + (uint64_t)bq * GW;
+    const uint64_t gstride = grad_bl ? (uint64_t)GW : (uint64_t)B * GW;
+    uint32_t gnext[GW];
 #pragma unroll
-        for (uint32_t i = 0; i < GE_MAX_LEVELS * GW; i += 4) {
-            uint4 t = make_uint4(0u, 0u, 0u, 0u);
-            if (i < L * GW) {
-                if (vec) t = *reinterpret_cast<const uint4 *>(gp + i);
-                else {
-                    t.x = gp[i];
-                    if (i + 1 < L * GW) t.y = gp[i + 1];
-                    if (i + 2 < L * GW) t.z = gp[i + 2];
-                    if (i + 3 < L * GW) t.w = gp[i + 3];
-                }
-            }
-            gq[i] = t.x; gq[i + 1] = t.y; gq[i + 2] = t.z; gq[i + 3] = t.w;
-        }
-    } else {                                               // [L, B, C] (the reference's layout, gridencoder.cu:283): a plane per level, coalesced
-        const uint32_t *gp = reinterpret_cast<const uint32_t *>(grad) + (uint64_t)(b < B ? b : 0u) * GW;
-#pragma unroll
-        for (uint32_t l = 0; l < GE_MAX_LEVELS; l++) {
-#pragma unroll
-            for (uint32_t w = 0; w < GW; w++) gq[l * GW + w] = l < L ? gp[(uint64_t)l * B * GW + w] : 0u;
-        }
-    }
+    for (uint32_t w = 0; w < GW; w++) gnext[w] = L ? gp[w] : 0u;
     // wave 0 keeps the (base, end) pair of the level about to be processed in registers
     uint32_t nb0 = 0, nb1 = 0;
     auto fetch_bases = [&](uint32_t level) {
@@ -780,13 +823,17 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             if (threadIdx.x == GB_MAX_SEGS - 1) pre[pb][GB_MAX_SEGS] = incl;
             fetch_bases(level + 1);
         }
-        __syncthreads();
+        gb_lds_barrier();
         float g[2];
         if constexpr (sizeof(T) == 2) {
-            g[0] = __half2float(__ushort_as_half((unsigned short)(gq[level] & 0xFFFFu)));
-            g[1] = __half2float(__ushort_as_half((unsigned short)(gq[level] >> 16)));
+            g[0] = __half2float(__ushort_as_half((unsigned short)(gnext[0] & 0xFFFFu)));
+            g[1] = __half2float(__ushort_as_half((unsigned short)(gnext[0] >> 16)));
         } else {
-            g[0] = __uint_as_float(gq[level * 2]); g[1] = __uint_as_float(gq[level * 2 + 1]);
+            g[0] = __uint_as_float(gnext[0]); g[1] = __uint_as_float(gnext[GW - 1]);
+        }
+        if (level + 1 < L) {
+#pragma unroll
+            for (uint32_t w = 0; w < GW; w++) gnext[w] = gp[(uint64_t)(level + 1) * gstride + w];
         }
         if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
         {
@@ -797,12 +844,16 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             gb_cell_weights<3>(pf, ws);
             uint32_t pv0[8], pv1[8];                       // record values: fp16 -> half2 bits in pv0; fp32 -> two floats
             bool emit = inside;
-            if (resolution <= GB_MERGE_MAX_RES) {
+            if (resolution <= lv.merge_max_res) {
                 const GbRun run = gb_run_flags(inside, pg);
                 emit = run.tail;
+                float pv[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { pv[2 * i] = ws[i] * g[0]; pv[2 * i + 1] = ws[i] * g[1]; }
+                gb_run_sum16(pv, run);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const float v0 = gb_run_sum(ws[i] * g[0], run), v1 = gb_run_sum(ws[i] * g[1], run);
+                    const float v0 = pv[2 * i], v1 = pv[2 * i + 1];
                     if constexpr (sizeof(T) == 2) {
                         const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
                         pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
@@ -839,7 +890,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 }
             }
         }
-        __syncthreads();
+        gb_lds_barrier();
         const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
         uint32_t *rec_rows = reinterpret_cast<uint32_t *>(recs);                       // [max_recs] rows, then [max_recs] values (16-byte aligned)
         uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
@@ -873,7 +924,10 @@ __device__ __forceinline__ unsigned long long gb_half_to_fixed(uint32_t h) {
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
                                                              const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
-    __shared__ double acc[GB_SEG * 2];             // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64)
+    // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64), one PLANE per channel: with the two channels
+    // of a row side by side a wave instruction (one channel of 64 random rows) could only ever touch every other pair of banks —
+    // half of the LDS's banks idle, twice the conflict cycles; planes spread a channel's 64 addends over all 64 banks
+    __shared__ double acc[GB_SEG * 2];
     unsigned long long *acci = reinterpret_cast<unsigned long long *>(acc);
     __shared__ uint32_t s_bad[GB_SEG / 32];        // fp16 tables: rows that received an inf/NaN addend (an overflowed AMP step) -> NaN out
     __shared__ uint32_t s_slot, s_lo, s_hi;
@@ -916,8 +970,8 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
                 atomicOr(&s_bad[row >> 5], 1u << (row & 31u));
                 return;
             }
-            atomicAdd(&acci[row * 2], gb_half_to_fixed(hv & 0xFFFFu));
-            atomicAdd(&acci[row * 2 + 1], gb_half_to_fixed(hv >> 16));
+            atomicAdd(&acci[row], gb_half_to_fixed(hv & 0xFFFFu));
+            atomicAdd(&acci[GB_SEG + row], gb_half_to_fixed(hv >> 16));
         };
         while (i0 < hi) {
             const uint32_t i1 = i0 + GB_RTHREADS * UNR;
@@ -948,10 +1002,10 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
             for (uint32_t u = 0; u < UNR; u++) {
                 if (cr[u] != NONE) {
                     const uint32_t r0 = cr[u] & (GB_SEG - 1u), r1 = (cr[u] >> 13) & (GB_SEG - 1u);
-                    atomicAdd(&acc[r0 * 2], (double)cv[u].x);
-                    atomicAdd(&acc[r0 * 2 + 1], (double)cv[u].y);
-                    atomicAdd(&acc[r1 * 2], (double)cv[u].z);
-                    atomicAdd(&acc[r1 * 2 + 1], (double)cv[u].w);
+                    atomicAdd(&acc[r0], (double)cv[u].x);
+                    atomicAdd(&acc[GB_SEG + r0], (double)cv[u].y);
+                    atomicAdd(&acc[r1], (double)cv[u].z);
+                    atomicAdd(&acc[GB_SEG + r1], (double)cv[u].w);
                 }
             }
 #pragma unroll
@@ -969,7 +1023,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     if constexpr (sizeof(T) == 2) {
         typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
         for (uint32_t r = threadIdx.x; r < nrows; r += GB_RTHREADS) {
-            float a = (float)((double)(long long)acci[2 * r] * (1.0 / 16777216.0)), b = (float)((double)(long long)acci[2 * r + 1] * (1.0 / 16777216.0));
+            float a = (float)((double)(long long)acci[r] * (1.0 / 16777216.0)), b = (float)((double)(long long)acci[GB_SEG + r] * (1.0 / 16777216.0));
             if ((s_bad[r >> 5] >> (r & 31u)) & 1u) { a = __builtin_nanf(""); b = __builtin_nanf(""); }
             if (a == 0.0f && b == 0.0f) continue;
             v2h hv; hv[0] = (_Float16)ge_opaque(a); hv[1] = (_Float16)ge_opaque(b);
@@ -977,7 +1031,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
         }
     } else {
         for (uint32_t e = threadIdx.x; e < nrows * 2; e += GB_RTHREADS) {
-            const float a = (float)acc[e];
+            const float a = (float)acc[(e & 1u) * GB_SEG + (e >> 1)];
             if (a != 0.0f) (void)__hip_atomic_fetch_add(dst + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1078,6 +1132,9 @@ static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
         lv.resolution[l] = (uint32_t)ceil((double)sc) + 1;
     }
     for (uint32_t l = L; l < GE_MAX_LEVELS; l++) { lv.scale[l] = 0; lv.resolution[l] = 1; }
+    static int merge_res = -1;                   // FOC_GB_MERGE_MAX_RES: tuning knob (<= 1023: the run key packs 10 bits per axis)
+    if (merge_res < 0) { const char *e = getenv("FOC_GB_MERGE_MAX_RES"); merge_res = e ? atoi(e) : (int)GB_MERGE_MAX_RES; if (merge_res > 1023) merge_res = 1023; if (merge_res < 0) merge_res = 0; }
+    lv.merge_max_res = (uint32_t)merge_res;
     return 0;
 }
 
