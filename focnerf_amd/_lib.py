@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must be imported first: the library then binds to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfocnerf_hip.so")
+# FOCNERF_LIB_PATH: another build of the same library (A/B timing of kernel variants on one box, tools/ab_libs.sh)
+LIB_PATH = os.environ.get("FOCNERF_LIB_PATH") or os.path.join(_HERE, "libfocnerf_hip.so")
 
 c_u8p = ctypes.c_void_p
 c_vp = ctypes.c_void_p

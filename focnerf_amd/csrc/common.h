@@ -78,6 +78,12 @@ static inline hipError_t foc_zero_async(void *p, size_t bytes, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Workgroup barrier that orders LDS traffic only. `__syncthreads()` is a workgroup-scope release/acquire on ALL memory: the compiler
+// drains vmcnt before it, so every wave sits at the barrier until its outstanding global stores have been acknowledged by memory and
+// its prefetched global loads have landed — a software prefetch issued before a barrier buys nothing. Use where the only data shared
+// across the barrier lives in LDS (global stores consumed by a LATER kernel, loads into registers the compiler waits for on use).
+__device__ __forceinline__ void foc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // wave64 reductions / scans via DPP-backed shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

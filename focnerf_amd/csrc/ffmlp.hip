@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     *reinterpret_cast<h8 *>(myA + rr * WA + cc) = v;
                 }
             }
-            __syncthreads();
+            foc_lds_barrier();     // LDS tiles only: the next group's prefetched rows stay in flight, grad_inputs stores are not waited for
             // ---- dW_s: output tile `wave` (MTo x NTi tiles, at most 4 for HIDDEN, in_dim <= 64)
             {
                 const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32;
@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                             }
                         }
             }
-            __syncthreads();       // every wave is done reading sD / sA of this stage
+            foc_lds_barrier();     // every wave is done reading sD / sA of this stage
         }
     }
     // ---- flush the weight-gradient tiles

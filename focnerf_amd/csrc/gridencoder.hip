@@ -761,12 +761,9 @@ __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restric
 // inside the LDS staging array is known up front; each record takes its place with one LDS cursor atomic, and the staging array is
 // copied out flat, so a wave stores 512 contiguous bytes. Two barriers per level; the bases of the next level are fetched while the
 // current one is ranked.
-// Workgroup barrier that orders LDS traffic only. `__syncthreads()` is a workgroup-scope release/acquire on ALL memory: the compiler
-// drains vmcnt before it, so every wave would sit at each of the 2 x L barriers until its copy-out stores to the record arrays had been
-// acknowledged by memory (and the prefetched gradient load had landed). The records are consumed by the next kernel, never by this one;
-// only the LDS staging arrays are shared across the barrier.
-__device__ __forceinline__ void gb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
+// The two barriers per level order LDS traffic only (foc_lds_barrier, common.h): with `__syncthreads()` every wave sat at each of the
+// 2 x L barriers until its copy-out stores to the record arrays had been acknowledged by memory and the prefetched gradient of the next
+// level had landed. The records are consumed by the next kernel, never by this one; only the LDS staging arrays cross the barrier.
 template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
@@ -823,7 +820,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             if (threadIdx.x == GB_MAX_SEGS - 1) pre[pb][GB_MAX_SEGS] = incl;
             fetch_bases(level + 1);
         }
-        gb_lds_barrier();
+        foc_lds_barrier();
         float g[2];
         if constexpr (sizeof(T) == 2) {
             g[0] = __half2float(__ushort_as_half((unsigned short)(gnext[0] & 0xFFFFu)));
@@ -890,7 +887,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 }
             }
         }
-        gb_lds_barrier();
+        foc_lds_barrier();
         const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
         uint32_t *rec_rows = reinterpret_cast<uint32_t *>(recs);                       // [max_recs] rows, then [max_recs] values (16-byte aligned)
         uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
