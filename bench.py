@@ -275,6 +275,12 @@ def cpu_baseline(budget_s=10.0, one_core_s=4.0):
                       f"(+ {e1:.1f} s single-core run)"}
 
 
+def progress(msg):
+    """Progress marker on stderr (rank 0): the one JSON line comes last, and a long silent run looks hung to whoever is watching."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks as a child `python -m torch.distributed.run` (one rank per GPU over
     RCCL) and return its exit status. Nothing in THIS process has touched the GPU (no HIP call, no torch.cuda query) — the ranks are
@@ -486,6 +492,7 @@ def main():
 
     samples_per_step = NUM_RAYS * NUM_STEPS
     value = world * samples_per_step * args.steps / el
+    progress(f"headline: {1000.0 * el / args.steps:.3f} ms/step")
     result = {
         "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
@@ -531,6 +538,7 @@ def main():
     # single-GPU properties (other paths of the same object) are reported at N = 1 only; the multi-rank runs keep to the headline
     # step plus the one exchange step the path has (combine), so that no rank-local failure can leave the others in a collective
     if not args.no_extras and world == 1:
+        progress("single-GPU extras (torch-glue step, renders, occupancy path)")
         try:
             # ---- the same step through the reference caller's torch glue (NeRFRenderer.run) instead of the fused kernels
             if fused:
@@ -644,6 +652,7 @@ def main():
 
     if not args.no_extras:
         # ---- configs[3]/[4]: K = N objects, one per rank, a full 800x800 view end to end (field evaluation + exchange + composite + gather)
+        progress("combined-render leg")
         model.eval()
         try:
             from focnerf_amd import raymarching as rm
@@ -680,7 +689,9 @@ def main():
             result["combined_render"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("cpu baseline: C oracle port")
         result["cpu_baseline"] = cpu_baseline()
+        progress("cpu baseline: configs[0] torch CPU")
         try:
             # configs[0] as BASELINE.md §2 defines it: the reference's pure-PyTorch network through the fixed-step renderer, fp32 torch ops on
             # the host cores (oracle/torch_cpu_nerf.py, pinned to the reference's own network class + run() by tests/golden/cpu_network.npz)

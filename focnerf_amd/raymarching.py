@@ -42,8 +42,10 @@ def _round_up(count, align):
 
 
 def _sample_buffers(m, like):
-    opts = dict(dtype=like.dtype, device=like.device)
-    return torch.zeros(m, 3, **opts), torch.zeros(m, 3, **opts), torch.zeros(m, 2, **opts)
+    """xyzs [m,3], dirs [m,3], deltas [m,2], zero-initialised like the reference's three torch.zeros (raymarching.py:205-207) — as three
+    views of ONE zero-filled block: one fill launch instead of three on a step that is bound by its launch count."""
+    block = torch.zeros(m * 8, dtype=like.dtype, device=like.device)
+    return block[: 3 * m].view(m, 3), block[3 * m: 6 * m].view(m, 3), block[6 * m:].view(m, 2)
 
 
 # ---------------------------------------------------------------- geometry helpers
@@ -138,7 +140,8 @@ class CompositeTrain(AmpOp):
     def grad(ctx, d_weights_sum, _d_depth, d_image):
         sigmas, rgbs, deltas, rays, weights_sum, image = ctx.saved_tensors
         m, n, T_thresh = ctx.sizes
-        d_sigmas, d_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
+        both = torch.zeros(m * 4, dtype=sigmas.dtype, device=sigmas.device)      # one fill for the two zero-initialised gradients (:283-284)
+        d_sigmas, d_rgbs = both[:m], both[m:].view(m, 3)
         if d_weights_sum is None and d_image is None:
             return d_sigmas, d_rgbs, None, None, None
         d_image = torch.zeros_like(image) if d_image is None else d_image.contiguous()

@@ -281,7 +281,16 @@ def time_baseline(render_budget_s=10.0, train_steps=1, train_rays=512, side=400,
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = threads or avail
+    # the box may show every host core in the affinity mask while a cgroup quota grants far fewer (16 on the one-GPU boxes): more
+    # OpenMP threads than granted cores spin against each other and a 10 s sample turns into minutes
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    threads = threads or max(1, min(avail, quota or avail, 16))
     old_threads = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
