@@ -121,7 +121,9 @@ class KernelTimer:
                         units = a[2] if name != "ffmlp_backward" else a[4]
                     self.records.setdefault(name, []).append((s, e, units))      # no tensor references: they would pin every step's buffers
                     if name == "grid_encode_forward_counted":
-                        self.last_counted_args = a                               # ... except the newest call of this one (count_share_ms)
+                        # shapes and scalars only (count_share_ms re-creates the tensors afterwards): holding the step's encoder planes and
+                        # fp16 table here kept 90 MB out of the caching allocator's reach and cost one device allocation in the timed region
+                        self.last_counted_args = (tuple(a[0].shape), a[1].shape, a[1].dtype, a[2]) + tuple(a[4:13])
                     return r
                 return staticmethod(wrapped)
             setattr(cls, name, make(orig, name))
@@ -135,7 +137,14 @@ class KernelTimer:
         from focnerf_amd import backend
         plain = self._orig[(backend._gridencoder, "grid_encode_forward")]
         counted = self._orig[(backend._gridencoder, "grid_encode_forward_counted")]
-        inputs, emb, offsets, outputs, B, D, C, L, S, H, gridtype, ac, interp = a[:13]
+        in_shape, emb_shape, emb_dtype, offsets, B, D, C, L, S, H, gridtype, ac, interp = a
+        dev = offsets.device
+        # ray-ordered positions like the step's own (4096 rays x 512 samples through the unit cube), a table of the same shape
+        t = torch.linspace(0.02, 0.98, NUM_STEPS, device=dev)
+        p0, p1 = torch.rand(B // NUM_STEPS + 1, 1, 3, device=dev), torch.rand(B // NUM_STEPS + 1, 1, 3, device=dev)
+        inputs = (p0 + (p1 - p0) * t[None, :, None]).reshape(-1, 3)[:B].contiguous()
+        emb = (torch.rand(emb_shape, device=dev) - 0.5).to(emb_dtype)
+        outputs = torch.empty(L, B, C, device=dev, dtype=emb_dtype)
 
         def timed(fn):
             fn()
@@ -418,13 +427,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FOC_BENCH_SHARE_GPU") == "1":      # rehearsal of the N-rank path on a one-GPU box (every rank on device 0); never set by the driver
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         import datetime
         # a rank that fails inside a collective leg must not leave the others waiting for the driver's kill: collectives time out
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
+        if os.environ.get("FOC_BENCH_SHARE_GPU") == "1":  # RCCL refuses two ranks on one device: the rehearsal moves the same collectives over gloo
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=240))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
