@@ -25,66 +25,7 @@
 #include <math.h>
 #include <stdlib.h>
 
-#define GE_MAX_LEVELS 32
-
-struct GeLevels {
-    float scale[GE_MAX_LEVELS];
-    uint32_t resolution[GE_MAX_LEVELS];
-    uint32_t merge_max_res;                    // binned backward: levels up to this resolution merge runs of samples in one cell (count + scatter)
-};
-
-// ---- storage-type helpers -------------------------------------------------------------
-// Keeps an fp32 value materialised in a VGPR. Without it LLVM folds `(half)fma(a,b,c)` into
-// v_fma_mixlo_f16, which rounds the exact fma ONCE to fp16; the reference (and the oracle) round to
-// fp32 first and then to fp16, and the two differ on fp32 values that sit on an fp16 tie.
-__device__ __forceinline__ float ge_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
-
-template <typename T> struct GeT;
-template <> struct GeT<float> {
-    static __device__ __forceinline__ float ld(const float *p) { return *p; }
-    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
-};
-template <> struct GeT<__half> {
-    static __device__ __forceinline__ float ld(const __half *p) { return __half2float(*p); }
-    static __device__ __forceinline__ void st(__half *p, float v) { *p = __float2half_rn(ge_opaque(v)); }
-};
-
-template <typename T, uint32_t C> struct GeVec;
-// loads C consecutive table entries as floats with the widest aligned access
-template <uint32_t C> struct GeVec<float, C> {
-    static __device__ __forceinline__ void ld(const float *p, float (&v)[C]) {
-        if constexpr (C == 1) v[0] = p[0];
-        else if constexpr (C == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
-        else {
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 4) { const float4 t = *reinterpret_cast<const float4 *>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w; }
-        }
-    }
-    static __device__ __forceinline__ void st(float *p, const float (&v)[C]) {
-        if constexpr (C == 1) p[0] = v[0];
-        else if constexpr (C == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
-        else {
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 4) *reinterpret_cast<float4 *>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-        }
-    }
-};
-template <uint32_t C> struct GeVec<__half, C> {
-    static __device__ __forceinline__ void ld(const __half *p, float (&v)[C]) {
-        if constexpr (C == 1) v[0] = __half2float(p[0]);
-        else {
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 2) { const float2 t = __half22float2(*reinterpret_cast<const __half2 *>(p + i)); v[i] = t.x; v[i + 1] = t.y; }
-        }
-    }
-    static __device__ __forceinline__ void st(__half *p, const float (&v)[C]) {
-        if constexpr (C == 1) p[0] = __float2half_rn(ge_opaque(v[0]));
-        else {
-#pragma unroll
-            for (uint32_t i = 0; i < C; i += 2) *reinterpret_cast<__half2 *>(p + i) = __halves2half2(__float2half_rn(ge_opaque(v[i])), __float2half_rn(ge_opaque(v[i + 1])));
-        }
-    }
-};
+#include "ge_common.h"
 
 // ---- index math (gridencoder.cu:50-84) -------------------------------------------------
 template <uint32_t D>
@@ -356,49 +297,6 @@ __global__ void __launch_bounds__(256) k_grid_fwd_bl(const float *__restrict__ i
 }
 
 // ---- backward ---------------------------------------------------------------------------
-template <typename T> struct GeAtomic;
-template <> struct GeAtomic<float> {
-    template <uint32_t C> static __device__ __forceinline__ void add(float *p, const float (&v)[C]) {
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++)
-            if (v[c] != 0.0f) (void)__hip_atomic_fetch_add(p + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-};
-template <> struct GeAtomic<__half> {
-    template <uint32_t C> static __device__ __forceinline__ void add(__half *p, const float (&v)[C]) {
-        if constexpr (C == 1) {
-            // C == 1 under fp16 is never produced by the reference wrapper (grid.py:43: half only when C % 2 == 0);
-            // handled with a CAS loop on the containing dword for completeness.
-            const __half hv = __float2half_rn(ge_opaque(v[0]));
-            if (__half2float(hv) == 0.0f) return;
-            uint32_t *w = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
-            const bool hi = (reinterpret_cast<uintptr_t>(p) & 2) != 0;
-            uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), assumed;
-            do {
-                assumed = old;
-                const uint16_t cur = hi ? (uint16_t)(assumed >> 16) : (uint16_t)(assumed & 0xFFFFu);
-                const __half sum = __float2half_rn(__half2float(__ushort_as_half(cur)) + __half2float(hv));
-                const uint32_t nv = hi ? ((assumed & 0x0000FFFFu) | ((uint32_t)__half_as_ushort(sum) << 16))
-                                       : ((assumed & 0xFFFF0000u) | (uint32_t)__half_as_ushort(sum));
-                old = assumed;
-                __hip_atomic_compare_exchange_strong(w, &old, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while (old != assumed);
-        } else {
-            typedef _Float16 __attribute__((ext_vector_type(2))) v2h;
-#pragma unroll
-            for (uint32_t c = 0; c < C; c += 2) {
-                // the reference rounds each addend to half before the packed atomic (gridencoder.cu:329)
-                v2h hv;
-                hv[0] = (_Float16)ge_opaque(v[c]);
-                hv[1] = (_Float16)ge_opaque(v[c + 1]);
-                if ((float)hv[0] == 0.0f && (float)hv[1] == 0.0f) continue;
-                (void)__builtin_amdgcn_global_atomic_fadd_v2f16(
-                    (__attribute__((address_space(1))) v2h *)(p + c), hv);
-            }
-        }
-    }
-};
-
 template <typename T, uint32_t D, uint32_t C>
 __device__ __forceinline__ void ge_backward_one(const float (&x)[D], const float (&g)[C], T *__restrict__ grad_table,
                                                 uint32_t hashmap_size, float scale, uint32_t resolution,
@@ -1198,7 +1096,9 @@ static int ge_forward_d(uint32_t D, uint32_t C, const float *inputs, const void 
     switch (D) {
         case 2: return ge_forward_c<T, 2>(C, inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
         case 3: return ge_forward_c<T, 3>(C, inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
-        default: foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D); return FOC_E_INVALID;
+        case 4: case 5:                                    // gridencoder.cu:393-398: runtime-D kernels (gridencoder_nd.hip)
+            return ge_nd_forward(sizeof(T) == 2 ? FOC_F16 : FOC_F32, D, C, inputs, emb, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, bl, st);
+        default: foc_set_error("GridEncoding: D must be 2, 3, 4 or 5 (got %u)", D); return FOC_E_INVALID;
     }
 }
 
@@ -1407,7 +1307,9 @@ int foc_grid_encode_backward(const void *grad, const float *inputs, const void *
             case 3: return ge_backward_c<__half, 3>(C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
         }
     }
-    foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D);
+    if (D == 4 || D == 5)                                      // gridencoder.cu:437-442
+        return ge_nd_backward(dtype, D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, bl, st);
+    foc_set_error("GridEncoding: D must be 2, 3, 4 or 5 (got %u)", D);
     return FOC_E_INVALID;
 }
 
@@ -1542,7 +1444,8 @@ int foc_grad_total_variation(const void *inputs, const void *embeddings, void *g
             case 3: return ge_tv_c<__half, 3>(C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);
         }
     }
-    foc_set_error("GridEncoding: D must be 2 or 3 (got %u)", D);
+    if (D == 4 || D == 5) return ge_nd_tv(dtype, D, C, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st);      // gridencoder.cu:633-638
+    foc_set_error("GridEncoding: D must be 2, 3, 4 or 5 (got %u)", D);
     return FOC_E_INVALID;
 }
 

@@ -46,7 +46,13 @@ CASES = [
     (3, 4, 8, 16, 15, 512, 1, False, 0),        # tiled
     (3, 8, 4, 8, 14, 128, 0, True, 1),          # align_corners + smoothstep
     (2, 2, 12, 16, 17, 2048, 0, False, 1),
+    # D = 4, 5 (gridencoder.cu:393-398: the reference dispatches D in {2,3,4,5}): runtime-D kernels, csrc/gridencoder_nd.hip
+    (4, 2, 8, 8, 14, 64, 0, False, 0),
+    (4, 4, 5, 4, 12, 20, 1, True, 1),           # tiled, align_corners, smoothstep
+    (5, 2, 6, 4, 13, 24, 0, False, 0),
+    (5, 1, 4, 4, 12, 12, 0, False, 1),
 ]
+CASES_BWD = CASES[:5] + CASES[6:]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -83,7 +89,7 @@ def test_forward_bit_exact(case, dtype):
         assert_half_close(to_np(out), lit, ulps=1.0, atol=(1 << D) * 0.5 * 2.0 ** -10, what="vs reference-literal half accumulation")
 
 
-@pytest.mark.parametrize("case", CASES[:5])
+@pytest.mark.parametrize("case", CASES_BWD)
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 @pytest.mark.parametrize("atomic", ["0", "1"])      # 0: partition + LDS accumulation (D=3,C=2), 1: scattered-atomic kernel
 def test_backward(case, dtype, atomic, monkeypatch):
@@ -233,6 +239,33 @@ def test_grad_total_variation():
     ref = oracle.grad_total_variation(((x + 1) / 2).cpu().numpy(), to_np(enc.embeddings), np.zeros_like(to_np(enc.embeddings)),
                                       to_np(enc.offsets), 1e-2, 3, 2, 8, S, 16)
     np.testing.assert_allclose(to_np(enc.embeddings.grad), ref, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("D", [4, 5])
+def test_module_and_total_variation_in_four_and_five_dimensions(D):
+    """GridEncoder with input_dim 4 / 5 (the reference builds them for space-time grids): module forward + autograd and
+    grad_total_variation against the oracle."""
+    from focnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(D)
+    enc = GridEncoder(input_dim=D, num_levels=6, base_resolution=4, desired_resolution=32, log2_hashmap_size=13).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = (torch.rand(3000, D, device="cuda") * 2 - 1).requires_grad_(True)
+    y = enc(x, bound=1)
+    assert y.shape == (3000, 12)
+    S = float(np.log2(enc.per_level_scale))
+    xn = to_np((x.detach() + 1) / 2)
+    ref, ref_dy = oracle.grid_encode_forward(xn, to_np(enc.embeddings), to_np(enc.offsets), D, 2, 6, S, 4, True)
+    assert np.array_equal(to_np(y), np.transpose(ref, (1, 0, 2)).reshape(3000, 12))
+    gy = torch.randn(3000, 12, device="cuda") * 0.1
+    y.backward(gy)
+    g_lbc = np.ascontiguousarray(np.transpose(to_np(gy).reshape(3000, 6, 2), (1, 0, 2)))
+    ge_ref, gi_ref = oracle.grid_encode_backward(g_lbc, xn, to_np(enc.offsets), enc.embeddings.shape[0], D, 2, 6, S, 4, ref_dy)
+    np.testing.assert_allclose(to_np(enc.embeddings.grad), ge_ref, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(to_np(x.grad), gi_ref / 2, atol=1e-3, rtol=1e-3)      # d/dx of (x + bound) / (2 bound)
+    enc.embeddings.grad = torch.zeros_like(enc.embeddings)
+    enc.grad_total_variation(weight=1e-2, inputs=x.detach(), bound=1)
+    tv = oracle.grad_total_variation(xn, to_np(enc.embeddings), np.zeros_like(to_np(enc.embeddings)), to_np(enc.offsets), 1e-2, D, 2, 6, S, 4)
+    np.testing.assert_allclose(to_np(enc.embeddings.grad), tv, atol=1e-6, rtol=1e-4)
 
 
 def test_full_batch_properties():
