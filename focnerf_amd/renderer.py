@@ -24,6 +24,32 @@ from . import densitygrid, raymarching
 _MARCH_ALIGN = 128          # sample lists are padded to multiples of this many rows (the MLP batch granularity of the reference)
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF resampling of a piecewise-constant density (nerf/renderer.py:13-46, legacy/nerf/renderer.py:12-46): `bins` [N, M+1]
+    interval edges, `weights` [N, M] -> `n_samples` positions per row, at the centres of equal-probability strata (`det`) or at uniform
+    random quantiles. Torch ops in the reference's order (cumsum, searchsorted right=True, gather, linear interpolation inside the
+    interval, intervals of mass < 1e-5 treated as unit mass)."""
+    weights = weights + 1e-5
+    cdf = torch.cumsum(weights / torch.sum(weights, -1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0. + 0.5 / n_samples, 1. - 0.5 / n_samples, steps=n_samples).to(weights.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples]).to(weights.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    pair = torch.stack([below, above], -1)
+    shape = [pair.shape[0], pair.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, pair)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, pair)
+    mass = cdf_g[..., 1] - cdf_g[..., 0]
+    mass = torch.where(mass < 1e-5, torch.ones_like(mass), mass)
+    return bins_g[..., 0] + (u - cdf_g[..., 0]) / mass * (bins_g[..., 1] - bins_g[..., 0])
+
+
 def _flat_rays(rays_o, rays_d):
     lead = tuple(rays_o.shape[:-1])
     return rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), lead
@@ -87,8 +113,6 @@ class NeRFRenderer(nn.Module):
         in training it yields `criterion_outside_mask`, the norm of the densities outside the mask (:163-165).
         Result: depth, image, weights_sum, criterion_outside_mask, timing (host seconds before / after the colour query) and, with
         `return_fields` (default: only in eval mode), densities [N,T,1] and rgbs [N,T,3]."""
-        if upsample_steps != 0:
-            raise NotImplementedError("hierarchical resampling (upsample_steps > 0) is not part of the FOC configuration")
         want_fields = (not self.training) if return_fields is None else return_fields
         started = time.time()
         o, d, lead = _flat_rays(rays_o, rays_d)
@@ -108,6 +132,29 @@ class NeRFRenderer(nn.Module):
         outside = None
         if self.training and yolo_details is not None:
             outside = torch.norm(sigma[~yolo_details[0].squeeze(0)] - 0)
+        if upsample_steps > 0:
+            # hierarchical resampling, legacy/nerf/renderer.py:169-202 (COMBINED.py:485-514 carries the same branch; FOC's own run() dropped
+            # it and FOC runs upsample_steps = 0): weights of the coarse pass -> `upsample_steps` more samples per ray where they are large
+            # (sample_pdf; deterministic outside training), density at the new points only, both sets merged in depth order
+            t_new = int(upsample_steps)
+            with torch.no_grad():
+                step0 = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
+                alpha0 = 1 - torch.exp(-step0 * self.density_scale * sigma)
+                w0 = alpha0 * torch.cumprod(torch.cat([torch.ones_like(alpha0[..., :1]), 1 - alpha0 + 1e-15], dim=-1), dim=-1)[..., :-1]
+                mid = z[..., :-1] + 0.5 * step0[..., :-1]
+                z_new = sample_pdf(mid, w0[:, 1:-1], t_new, det=not self.training).detach()
+                points_new = o.unsqueeze(-2) + d.unsqueeze(-2) * z_new.unsqueeze(-1)
+                points_new = torch.min(torch.max(points_new, box[:3]), box[3:])
+            field_new = self.density(points_new.reshape(-1, 3))
+            z, order = torch.sort(torch.cat([z, z_new], dim=1), dim=1)
+            points = torch.gather(torch.cat([points, points_new], dim=1), 1, order.unsqueeze(-1).expand(n, T + t_new, 3))
+            merged = {}
+            for k in field:
+                both = torch.cat([field[k].view(n, T, -1), field_new[k].view(n, t_new, -1)], dim=1)
+                merged[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+            field = merged
+            T = T + t_new
+            sigma = field['sigma'].view(n, T)
 
         step = torch.cat([z[..., 1:] - z[..., :-1], spacing * torch.ones_like(z[..., :1])], dim=-1)
         alpha = 1 - torch.exp(-step * self.density_scale * sigma)

@@ -10,6 +10,7 @@ What is imported from the reference (nothing is copied into this repo; the fixtu
   * COMBINED.py best_densities_and_colors_v3 / image_depth_generation (compiled from the file with ast; not importable) -> combined.npz
   * nerf.network.NeRFNetwork (the pure-PyTorch network class) through nerf.renderer.NeRFRenderer.run, on the encoders of
     oracle/torch_cpu_nerf.py -> cpu_network.npz (pins the CPU baseline of configs[0])
+  * nerf.renderer.sample_pdf and the legacy renderer's run() with upsample_steps > 0 (compiled from the file with ast) -> upsample.npz
   * editable.py modify_rays_for_object / get_object_type_from_ckpt / batch_run / run / select / composite (same way), 8 objects, 2 views -> editable.npz
   * gridencoder.GridEncoder / grid_encode and ffmlp.FFMLP / ffmlp_forward (the Python wrappers, on oracle-backed stub backends) -> wrappers.npz
   * raymarching/raymarching.py wrappers (same arrangement; Tensor.cuda patched to the identity for the run) -> raymarching_wrappers.npz
@@ -420,6 +421,55 @@ def cpu_network_fixture(N=48, T=64, bound=2):
     return out
 
 
+def upsample_fixture(N=40, T=48, t=32, bound=1):
+    """Hierarchical resampling (upsample_steps > 0): `sample_pdf` as the FOC renderer module defines it (nerf/renderer.py:13-46, imported)
+    and the legacy renderer's `run` (legacy/nerf/renderer.py:125-254), whose module cannot be imported (its `from .utils import ...`
+    pulls in imageio, cv2, mcubes, lpips, ...): the method is located with `ast`, compiled from the reference file where it lies and run
+    with the names it reaches for — `raymarching` (near/far = this repo's oracle), `sample_pdf` (the imported one), `torch` — on an
+    analytic field, in eval mode (deterministic strata)."""
+    import ast
+    import textwrap
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    bins = torch.sort(torch.rand(25, 20, generator=g) * 3, dim=-1).values
+    w = torch.rand(25, 19, generator=g) ** 3
+    w[3] = 0.0                                                      # an empty ray: uniform after the +1e-5
+    w[4, :10] = 0.0
+    out.update(pdf_bins=bins.numpy(), pdf_weights=w.numpy(), pdf_samples_det=foc_renderer.sample_pdf(bins, w, 16, det=True).numpy())
+    path = os.path.join(REF, "legacy", "nerf", "renderer.py")
+    src = open(path).read()
+    run_src = None
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name == "run":
+            run_src = textwrap.dedent(ast.get_source_segment(src, node))
+            break
+    assert run_src is not None and "sample_pdf" in run_src
+    ns = {"torch": torch, "raymarching": rm, "sample_pdf": foc_renderer.sample_pdf}
+    exec(compile(run_src, path, "exec"), ns)
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32)
+
+    class Toy:
+        aabb_train = aabb_infer = aabb
+        training, min_near, density_scale, bg_radius = False, 0.2, 1, -1
+
+        def density(self, x):
+            return {'sigma': sigma_field(x), 'geo_feat': x[..., :2] * 0.5}
+
+        def color(self, x, d, mask=None, geo_feat=None, **kw):
+            rgbs = torch.zeros(mask.shape[0], 3)
+            rgbs[mask] = color_field(x[mask], d[mask]) * (0.5 + geo_feat[mask][..., :1].abs().clamp(max=0.5))
+            return rgbs
+    o, d = make_rays(N, 55, bound)
+    with torch.no_grad():
+        res = ns["run"](Toy(), o[None], d[None], num_steps=T, upsample_steps=t, bg_color=None, perturb=False)
+        res0 = ns["run"](Toy(), o[None], d[None], num_steps=T, upsample_steps=0, bg_color=None, perturb=False)
+    nears, fars = _near_far(o, d, aabb, 0.2)
+    out.update(rays_o=o.numpy(), rays_d=d.numpy(), aabb=aabb.numpy(), T=np.int32(T), t=np.int32(t), nears=nears.numpy(), fars=fars.numpy(),
+               image=res["image"][0].numpy(), depth=res["depth"][0].numpy(), weights_sum=res["weights_sum"].numpy(),
+               image_coarse=res0["image"][0].numpy(), depth_coarse=res0["depth"][0].numpy())
+    return out
+
+
 def wrapper_fixture():
     """The reference's Python operator wrappers (gridencoder/grid.py GridEncoder + grid_encode, ffmlp/ffmlp.py FFMLP + ffmlp_forward)
     driven on the CPU with their pybind11 backends replaced by stubs of the same names that call this repo's oracle. What the fixture
@@ -674,6 +724,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "combined.npz"), **combined_fixture())
     np.savez_compressed(os.path.join(HERE, "editable.npz"), **editable_fixture())
     np.savez_compressed(os.path.join(HERE, "cpu_network.npz"), **cpu_network_fixture())
+    np.savez_compressed(os.path.join(HERE, "upsample.npz"), **upsample_fixture())
     np.savez_compressed(os.path.join(HERE, "wrappers.npz"), **wrapper_fixture())
     np.savez_compressed(os.path.join(HERE, "raymarching_wrappers.npz"), **raymarching_wrapper_fixture())
     for f in sorted(os.listdir(HERE)):
