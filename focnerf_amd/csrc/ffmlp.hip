@@ -53,12 +53,13 @@ __device__ __forceinline__ h8 ld_frag(const _Float16 *lds, uint32_t frag, uint32
 // Build the B fragment of k-chunk (2*mt_prev + s) from accumulator tile `acc` (optionally ReLU'd).
 template <bool RELU>
 __device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     h8 r;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        _Float16 v = (_Float16)acc[8 * s + j];
-        if (RELU) v = v > (_Float16)0 ? v : (_Float16)0;
-        r[j] = v;
+    for (int j = 0; j < 8; j += 2) {
+        h2 p = {(_Float16)acc[8 * s + j], (_Float16)acc[8 * s + j + 1]};       // one v_cvt_pk_f16_f32 (round to nearest even)
+        if (RELU) p = __builtin_elementwise_max(p, h2{(_Float16)0, (_Float16)0});  // one v_pk_max_f16 for the pair: max(x, 0), NaN -> 0 like `x > 0 ? x : 0`
+        r[j] = p[0]; r[j + 1] = p[1];
     }
     return r;
 }
@@ -565,11 +566,17 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
 // where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
 // and input rows are fetched while the current group is processed.
-template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE>
+template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE, bool RELU_CT>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
-                                                             uint32_t B, uint32_t in_dim, int relu, uint32_t lds_w_halfs, MlpHead hd) {
+                                                             uint32_t B, uint32_t in_dim, int relu_rt, uint32_t lds_w_halfs, MlpHead hd) {
+    // RELU_CT: the activation as a compile-time fact (every NeRF network is ReLU): with the runtime flag the compiler evaluated BOTH forms of
+    // every activation / gate and selected per register (224 v_cndmask per 128 rows); `false` keeps the runtime flag (activation 'none')
+    const int relu = RELU_CT ? 1 : relu_rt;
+    f16v FZ;                                               // constant zero C operand: folds into the first MFMA of a chain as the inline constant 0
+#pragma unroll
+    for (int e = 0; e < 16; e++) FZ[e] = 0.0f;
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
     constexpr bool planar = IMODE == 1;
     static_assert(IMODE != 2 || RECOMP, "input mode 2 has no stored-activation form");
@@ -668,19 +675,13 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
-#pragma unroll
             for (int kc = 0; kc < KS0M; kc++) {
-                if ((uint32_t)kc < KS0) {
+                if (kc == 0 || (uint32_t)kc < KS0) {             // in_dim >= 16: k-chunk 0 always exists and starts the chain from the constant 0
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const h8 a = ld_frag(ldsF, mt * KS0 + kc, lane);
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], acc[mt][nb]);
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
                     }
                 }
             }
@@ -694,18 +695,12 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                 if (l + 1 < NL) {
                     const uint32_t fbase = MT * KS0 + l * MT * KC;
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                            for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
-#pragma unroll
                     for (int kc = 0; kc < KC; kc++)
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {
                             const h8 a = ld_frag(ldsF, fbase + mt * KC + kc, lane);
 #pragma unroll
-                            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, fa[l][kc][nb], acc[mt][nb]);
+                            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, fa[l][kc][nb], kc == 0 ? FZ : acc[mt][nb]);
                         }
                 }
             }
@@ -861,41 +856,26 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                 for (int mt = 0; mt < MT; mt++) {
                     const h8 a = ld_frag(lds, mt, lane);
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        f16v z;
-#pragma unroll
-                        for (int e = 0; e < 16; e++) z[e] = 0.0f;
-                        acc[mt][nb] = mfma16(a, bg[nb], z);
-                    }
+                    for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bg[nb], FZ);
                 }
             } else if (s < NL) {
                 const uint32_t fbase = f_hidden + (NL - 1 - s) * MT * KC;     // hidden matrix fl-1 with fl = NL - s
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const h8 a = ld_frag(lds, fbase + mt * KC + kc, lane);
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
                     }
             } else if (with_dx) {
                 for (uint32_t mt0 = 0; mt0 < MT0; mt0++) {
                     f16v x[NB];
 #pragma unroll
-                    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-                        for (int e = 0; e < 16; e++) x[nb][e] = 0.0f;
-#pragma unroll
                     for (int kc = 0; kc < KC; kc++) {
                         const h8 a = ld_frag(lds, f_dx + mt0 * KC + kc, lane);
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], x[nb]);
+                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : x[nb]);
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
@@ -1003,10 +983,14 @@ __device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h
     for (int j = 0; j < 8; j++) out[j] = (_Float16)o[j];
 }
 
-template <int NLS, int NLC, bool PLANAR>
+template <int NLS, int NLC, bool PLANAR, bool RELU_CT>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
                                                           const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
-                                                          int relu, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
+                                                          int relu_rt, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
+    const int relu = RELU_CT ? 1 : relu_rt;            // ReLU as a compile-time fact (see k_mlp_bwd_fused); `false` keeps the runtime flag
+    f16v FZ;                                           // constant zero C operand: the first MFMA of every chain takes the inline constant 0
+#pragma unroll
+    for (int e = 0; e < 16; e++) FZ[e] = 0.0f;
     constexpr int HIDDEN = 64, MT = 2, KC = 4, NB = 2, IN = 32, KS0 = 2;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     // sigma net: the forward image of k_mlp_fwd; colour net behind it: layer 0 custom (see above), hidden and output as usual
@@ -1050,10 +1034,6 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t n_tiles = (B + 32 * NB - 1) / (32 * NB);
-    auto zero = [](f16v &a) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) a[e] = 0.0f;
-    };
     // one hidden stack: acc (pre-activation of layer 0) -> pre-activation of the output layer input; returns the B fragments of the last hidden layer
     auto hidden_stack = [&](f16v (&acc)[MT][NB], h8 (&bf)[KC][NB], const _Float16 *img, uint32_t f_hidden, int nl) {
 #pragma unroll 1
@@ -1065,16 +1045,12 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             if (l < nl) {
                 const uint32_t fbase = f_hidden + (l - 1) * MT * KC;
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
-#pragma unroll
                 for (int kc = 0; kc < KC; kc++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const h8 a = ld_frag(img, fbase + mt * KC + kc, lane);
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], acc[mt][nb]);
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
                     }
             }
         }
@@ -1084,10 +1060,6 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
         f16v acc[MT][NB];
         h8 bf[KC][NB];
         // ---- sigma net
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
 #pragma unroll
         for (int kc = 0; kc < KS0; kc++) {
             h8 b[NB];
@@ -1100,18 +1072,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             for (int mt = 0; mt < MT; mt++) {
                 const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[nb], acc[mt][nb]);
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[nb], kc == 0 ? FZ : acc[mt][nb]);
             }
         }
         hidden_stack(acc, bf, lds, MT * KS0, NLS);
         f16v o[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) zero(o[nb]);
-#pragma unroll
         for (int kc = 0; kc < KC; kc++) {
             const h8 a = ld_frag(lds, MT * KS0 + (NLS - 1) * MT * KC + kc, lane);
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
+            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : o[nb]);
         }
         // ---- head: sigma from neuron 0 (lane half 0, element 0), SH on the lane, geometry features = the output fragment itself
         h8 geo[NB], sh[NB];
@@ -1126,14 +1096,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
         }
         // ---- colour net
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) zero(acc[mt][nb]);
-#pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const h8 a0 = ld_frag(ldsC, mt * KS0 + 0, lane);
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], acc[mt][nb]);
+            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], FZ);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
@@ -1143,12 +1109,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
         }
         hidden_stack(acc, bf, ldsC, MT * KS0, NLC);
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) zero(o[nb]);
-#pragma unroll
         for (int kc = 0; kc < KC; kc++) {
             const h8 a = ld_frag(ldsC, MT * KS0 + (NLC - 1) * MT * KC + kc, lane);
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], o[nb]);
+            for (int nb = 0; nb < NB; nb++) o[nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : o[nb]);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
@@ -1279,9 +1243,11 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
-    auto kern = recomp ? (planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0>)
-                       : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0>;
-    if constexpr (HIDDEN == 64 && NL <= 3) { if (head) kern = k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2>; }
+    // the re-evaluating forms exist twice: ReLU as a compile-time fact (what every NeRF network uses) and with the runtime flag
+    auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
+                                 : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, false>))
+                       : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0, false>;
+    if constexpr (HIDDEN == 64 && NL <= 3) { if (head) kern = relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>; }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
@@ -1350,7 +1316,8 @@ template <int NLS, int NLC>
 static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
                              float *sigma, float *rgb, hipStream_t st) {
     const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024;
-    auto kern = planar ? k_nerf_infer<NLS, NLC, true> : k_nerf_infer<NLS, NLC, false>;
+    auto kern = planar ? (relu ? k_nerf_infer<NLS, NLC, true, true> : k_nerf_infer<NLS, NLC, true, false>)
+                       : (relu ? k_nerf_infer<NLS, NLC, false, true> : k_nerf_infer<NLS, NLC, false, false>);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     uint32_t grid = foc_div_up(foc_div_up(B, 64), MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);

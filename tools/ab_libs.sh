@@ -9,7 +9,7 @@ for rep in $(seq $REPS); do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']
-print('$(basename $lib)', 'ms/step %.4f' % d['ms_per_step'], 'median %.4f' % d['step_ms']['median'], {n: k[n]['avg_ms'] for n in k if 'grid' in n})
+print('$(basename $lib)', 'ms/step %.4f' % d['ms_per_step'], 'median %.4f' % d['step_ms']['median'], {n: k[n]['avg_ms'] for n in k if 'grid' in n or 'ffmlp' in n})
 "
   done
 done
