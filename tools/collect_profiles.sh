@@ -6,7 +6,7 @@
 # (written under gpurun_out/profiles/, copy them into profiles/ afterwards).
 # usage: tools/collect_profiles.sh r01
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -23,3 +23,5 @@ for pair in occupancy_train:prof_occupancy.py render_fixed:time_render_fixed.py 
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$R/tools/$script" > "$OUT/$name.log" 2>&1
   cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${name}_kernel_stats.csv"
 done
+# the raw traces (hundreds of MB) stay on the box: gpurun copies back at most 64 MiB of gpurun_out/
+rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/occupancy_train" "$OUT/render_fixed" "$OUT/render_occupancy"

@@ -18,3 +18,4 @@ pass b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS S
 pass c SQ_WAIT_INST_LDS SQ_INSTS_GDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_LDS_ATOMIC_RETURN SQ_THREAD_CYCLES_VALU
 pass d TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 python3 "$R/tools/summarize_sq.py" "$OUT" "$TAG"
+rm -rf "$OUT"/sq_a "$OUT"/sq_b "$OUT"/sq_c "$OUT"/sq_d      # raw counter dumps stay on the box (gpurun copies back at most 64 MiB)

@@ -15,3 +15,4 @@ for r in rows[:14]:
     print(f'{r["Name"][:70]:70s} calls {int(r["Calls"]):5d} avg_us {float(r["AverageNs"])/1e3:9.1f} pct {float(r["Percentage"]):5.1f}')
 PY
 tail -1 "$OUT/stats.log" | cut -c1-300
+rm -rf "$OUT/stats"
