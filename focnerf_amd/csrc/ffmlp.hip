@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
                                                       float *__restrict__ ws, uint32_t B, uint32_t in_dim, uint32_t num_layers) {
     constexpr int LDP = 8;   // row padding (halfs) to spread the strided 2-byte reads over banks
     __shared__ __attribute__((aligned(16))) _Float16 sD[DW_CHUNK][(HIDDEN < 32 ? 32 : HIDDEN) + LDP];   // >= 32 columns: transposed reads span a whole 32-row tile
-    __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][128 + LDP];
+    __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][(HIDDEN > 128 ? HIDDEN : 128) + LDP];
 
     const uint32_t j = blockIdx.y;
     const _Float16 *Dp; const _Float16 *Ap; uint32_t OUT, IN; uint64_t ws_off;
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t MTo = (OUT + 31) / 32, NTi = (IN + 31) / 32, n_out_tiles = MTo * NTi;
-    // up to 4 tiles per wave covers OUT, IN <= 128 (16 tiles / 4 waves)
+    // up to 4 tiles per wave and workgroup: 16 tiles cover OUT, IN <= 128; hidden 256 (64 tiles) deals them over blockIdx.z
     f16v acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint32_t tile = wave + t * MLP_WAVES;
+            const uint32_t tile = wave + t * MLP_WAVES + 16 * blockIdx.z;
             if (tile < n_out_tiles) {
                 const uint32_t mt = tile / NTi, nt = tile % NTi;
                 const uint32_t o = 32 * mt + r, i = 32 * nt + r;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
     // accumulate partial tiles: lane holds column i = 32*nt + r, rows o = 32*mt + acc_row(reg, h)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const uint32_t tile = wave + t * MLP_WAVES;
+        const uint32_t tile = wave + t * MLP_WAVES + 16 * blockIdx.z;
         if (tile < n_out_tiles) {
             const uint32_t mt = tile / NTi, nt = tile % NTi;
             const uint32_t i = 32 * nt + r;
@@ -1168,11 +1168,18 @@ static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
     return (uint32_t)n;
 }
 
+// hidden_dim 256 (ffmlp_wide.hip): layer-by-layer kernels with one matrix resident in LDS
+int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu, void *buffer,
+                     void *outputs, hipStream_t st);
+int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu,
+                                  void *bwd_buf, void *grad_inputs, hipStream_t st);
+
 static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                      uint32_t activation, uint32_t output_activation) {
-    FOC_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128, FOC_E_INVALID,
-                "%s: hidden_dim should in [16, 32, 64, 128] (got %u; 256 is not built)", who, hidden_dim);   // ffmlp.cu:658
-    FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 128, FOC_E_INVALID, "%s: input_dim must be 16*m, m in [1,8] (got %u)", who, input_dim);
+    FOC_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128 || hidden_dim == 256, FOC_E_INVALID,
+                "%s: hidden_dim should in [16, 32, 64, 128, 256] (got %u)", who, hidden_dim);                 // ffmlp.cu:658
+    FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= (hidden_dim == 256 ? 256u : 128u), FOC_E_INVALID,
+                "%s: input_dim must be a multiple of 16 up to %u (got %u)", who, hidden_dim == 256 ? 256u : 128u, input_dim);
     FOC_REQUIRE(output_dim <= 16, FOC_E_INVALID, "%s: output_dim must be <= 16 (got %u)", who, output_dim);
     FOC_REQUIRE(num_layers >= 2 && num_layers <= 16, FOC_E_INVALID, "%s: num_layers must be in [2,16] (got %u)", who, num_layers);
     FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "%s: hidden activation must be relu(0) or none(6) (got %u)", who, activation);
@@ -1227,6 +1234,9 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
         case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
         case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
         case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
+        case 256:                                       // one matrix fills the LDS: layer by layer (ffmlp_wide.hip)
+            FOC_REQUIRE(!planar, FOC_E_INVALID, "%s: planar inputs are served up to hidden_dim 128", who);
+            return mlp_wide_forward(TRAIN, inputs, weights, B, input_dim, 256, num_layers, relu, buffer, outputs, st);
     }
     return FOC_E_INVALID;
 }
@@ -1264,6 +1274,27 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     return FOC_OK;
 }
 
+// weight gradients of every layer from the stored activations and activation gradients: split-K over the batch into the fp32 workspace, one rounding
+template <int HIDDEN>
+static int mlp_dw_launch(const void *grad, const void *inputs, const void *fwd_buf, const void *bwd_buf, uint32_t B, uint32_t in_dim, uint32_t num_layers,
+                         void *grad_weights, float *ws, hipStream_t st) {
+    const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
+    if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
+    uint32_t gx = foc_div_up(B, DW_CHUNK);
+    static int wgs_per_cu = 0;                   // split-K workgroups per CU over all layers (FOC_DW_WGS_PER_CU overrides, for tuning)
+    if (!wgs_per_cu) { const char *e = getenv("FOC_DW_WGS_PER_CU"); wgs_per_cu = e ? atoi(e) : 8; if (wgs_per_cu < 1) wgs_per_cu = 1; }
+    constexpr uint32_t GZ = HIDDEN > 128 ? (uint32_t)((HIDDEN / 32) * (HIDDEN / 32) + 15) / 16 : 1u;      // 16 output tiles per workgroup
+    const uint32_t capx = foc_div_up(mlp_num_cus() * (uint32_t)wgs_per_cu, (num_layers + 1) * GZ);
+    if (gx > capx) gx = capx;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((k_mlp_dw<HIDDEN>), dim3(gx, num_layers + 1, GZ), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
+                       (const _Float16 *)fwd_buf, (const _Float16 *)bwd_buf, ws, B, in_dim, num_layers);
+    FOC_CHECK_LAUNCH("ffmlp_backward(weights)");
+    hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
+    FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
+    return FOC_OK;
+}
+
 template <int HIDDEN>
 static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim,
                           uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
@@ -1295,21 +1326,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)weights, (const _Float16 *)fwd_buf,
                        (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, B, in_dim, num_layers, relu);
     FOC_CHECK_LAUNCH("ffmlp_backward(activations)");
-    // weight gradients
-    const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
-    if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
-    uint32_t gx = foc_div_up(B, DW_CHUNK);
-    static int wgs_per_cu = 0;                   // split-K workgroups per CU over all layers (FOC_DW_WGS_PER_CU overrides, for tuning)
-    if (!wgs_per_cu) { const char *e = getenv("FOC_DW_WGS_PER_CU"); wgs_per_cu = e ? atoi(e) : 8; if (wgs_per_cu < 1) wgs_per_cu = 1; }
-    const uint32_t capx = foc_div_up(mlp_num_cus() * (uint32_t)wgs_per_cu, num_layers + 1);
-    if (gx > capx) gx = capx;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_mlp_dw<HIDDEN>), dim3(gx, num_layers + 1), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
-                       (const _Float16 *)fwd_buf, (const _Float16 *)bwd_buf, ws, B, in_dim, num_layers);
-    FOC_CHECK_LAUNCH("ffmlp_backward(weights)");
-    hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
-    FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
-    return FOC_OK;
+    return mlp_dw_launch<HIDDEN>(grad, inputs, fwd_buf, bwd_buf, B, in_dim, num_layers, grad_weights, ws, st);
 }
 
 template <int NLS, int NLC>
@@ -1371,6 +1388,13 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
         case 32: return mlp_bwd_launch<32>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
         case 64: return mlp_bwd_launch<64>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
         case 128: return mlp_bwd_launch<128>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, relu, backward_buffer, gi, grad_weights, (float *)workspace, planar, st);
+        case 256: {
+            FOC_REQUIRE(backward_buffer && forward_buffer, FOC_E_INVALID, "ffmlp_backward: hidden_dim 256 runs layer by layer and needs forward_buffer and backward_buffer");
+            FOC_REQUIRE(!planar, FOC_E_INVALID, "ffmlp_backward: planar inputs are served up to hidden_dim 64");
+            rc = mlp_wide_backward_activations(grad, weights, forward_buffer, B, input_dim, 256, num_layers, relu, backward_buffer, gi, st);
+            if (rc) return rc;
+            return mlp_dw_launch<256>(grad, inputs, forward_buffer, backward_buffer, B, input_dim, num_layers, grad_weights, (float *)workspace, st);
+        }
     }
     return FOC_E_INVALID;
 }

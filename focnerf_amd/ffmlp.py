@@ -24,7 +24,7 @@ from .backend import _ffmlp as _kernels
 
 ACTIVATIONS = {'relu': 0, 'exponential': 1, 'sine': 2, 'sigmoid': 3, 'squareplus': 4, 'softplus': 5}
 NO_ACTIVATION = 6
-SUPPORTED_HIDDEN = (16, 32, 64, 128, 256)       # what the reference accepts (256 is not built here: the kernels reject it)
+SUPPORTED_HIDDEN = (16, 32, 64, 128, 256)       # what the reference accepts (ffmlp.py:112; 256 runs layer by layer, csrc/ffmlp_wide.hip)
 
 
 def convert_activation(name):
@@ -54,8 +54,9 @@ class FusedMLP(AmpOp):
         net = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation)
         y = x.new_empty(n, output_dim)
         if inference:
-            # activations stay in registers: no [B, hidden] scratch (the reference allocates one, ffmlp.py:41)
-            _kernels.ffmlp_inference(x, blob, n, *net, None, y)
+            # activations stay in registers: no [B, hidden] scratch (the reference allocates one, ffmlp.py:41) — except at hidden 256, where one
+            # matrix fills the LDS and the layers run one launch each, in place in that buffer
+            _kernels.ffmlp_inference(x, blob, n, *net, x.new_empty(n, hidden_dim) if hidden_dim > 128 else None, y)
             return y
         kept = x.new_empty(num_layers, n, hidden_dim) if _keeps_activations(input_dim, hidden_dim, num_layers) else None
         _kernels.ffmlp_forward(x, blob, n, *net, kept, y)

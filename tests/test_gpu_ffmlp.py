@@ -36,11 +36,14 @@ def _run_forward(x, W, I, Hd, nl, act, train):
         fb = torch.empty(nl, B, Hd, dtype=torch.float16, device="cuda")
         be.ffmlp_forward(xt, Wt, B, I, 16, Hd, nl, act, 6, fb, out)
         return to_np(out), to_np(fb)
-    be.ffmlp_inference(xt, Wt, B, I, 16, Hd, nl, act, 6, None, out)
+    # hidden 256 runs layer by layer, in place in the [B, hidden] buffer the reference allocates for every width (ffmlp.py:41)
+    scratch = torch.empty(B, Hd, dtype=torch.float16, device="cuda") if Hd > 128 else None
+    be.ffmlp_inference(xt, Wt, B, I, 16, Hd, nl, act, 6, scratch, out)
     return to_np(out)
 
 
-SHAPES = [(32, 64, 2), (32, 64, 3), (16, 16, 2), (48, 32, 4), (64, 128, 2), (128, 128, 3), (16, 64, 5)]
+SHAPES = [(32, 64, 2), (32, 64, 3), (16, 16, 2), (48, 32, 4), (64, 128, 2), (128, 128, 3), (16, 64, 5),
+          (32, 256, 2), (256, 256, 3), (48, 256, 4)]          # hidden 256 (ffmlp.cu:652-658): csrc/ffmlp_wide.hip
 
 
 @pytest.mark.parametrize("I,Hd,nl", SHAPES)
@@ -112,7 +115,7 @@ def test_backward_exact_on_integer_data(I, Hd, nl, act):
     assert torch.equal(gw, gw2)
 
 
-@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (64, 128, 2)])
+@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (64, 128, 2), (32, 256, 3)])
 def test_backward_random(I, Hd, nl):
     be = _be()
     rng = np.random.default_rng(99 + I + Hd + nl)
@@ -280,3 +283,26 @@ def test_module_recompute_env(monkeypatch):
     assert torch.equal(grads["1"][2], grads["0"][2])
     assert torch.equal(grads["1"][0], grads["0"][0])
     assert torch.allclose(grads["1"][1], grads["0"][1], rtol=2e-3, atol=1e-4)
+
+
+def test_hidden_256_module_trains_and_infers():
+    """FFMLP(hidden_dim=256) through autograd: stored activations (the layer-by-layer path has no re-evaluating form), ragged batch, inference
+    equal to the training forward, null-buffer calls rejected with the library's message."""
+    from focnerf_amd.ffmlp import FFMLP
+    net = FFMLP(32, 3, 256, 2).cuda()
+    assert net.weights.numel() == 256 * (32 + 256 + 16)
+    x = torch.randn(333, 32, device="cuda", requires_grad=True)
+    net.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(x)
+    ref = oracle.ffmlp_forward(to_np(x.detach().half()), to_np(net.weights.detach().half()), 32, 256, 2, 0, training=False)
+    assert_half_close(to_np(y), ref[:, :3], ulps=8, atol=4e-3, what="hidden 256 module forward")
+    y.float().pow(2).sum().backward()
+    assert torch.isfinite(net.weights.grad).all() and net.weights.grad.abs().sum() > 0 and x.grad.shape == (333, 32)
+    net.eval()
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        assert torch.equal(net(x), y.detach())
+    be = _be()
+    xh, w = x.detach().half(), net.weights.detach().half()
+    with pytest.raises(RuntimeError, match="inference_buffer"):
+        be.ffmlp_inference(xh, w, 333, 32, 16, 256, 2, 0, 6, None, torch.empty(333, 16, dtype=torch.float16, device="cuda"))
