@@ -99,8 +99,8 @@ def test_bad_arguments_raise_runtime_error():
     emb = torch.rand(64, 2, device="cuda")
     off = torch.tensor([0, 64], dtype=torch.int32, device="cuda")
     out = torch.empty(1, 4, 2, device="cuda")
-    with pytest.raises(RuntimeError, match="D must be 2 or 3"):
-        _gridencoder.grid_encode_forward(torch.rand(4, 4, device="cuda"), emb, off, out, 4, 4, 2, 1, 0.0, 8, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="D must be 2, 3, 4 or 5"):
+        _gridencoder.grid_encode_forward(torch.rand(4, 6, device="cuda"), emb, off, out, 4, 6, 2, 1, 0.0, 8, None, 0, False, 0)
     with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
         _gridencoder.grid_encode_forward(x, torch.rand(64, 3, device="cuda"), off, torch.empty(1, 4, 3, device="cuda"), 4, 3, 3, 1, 0.0, 8, None, 0, False, 0)
     with pytest.raises(RuntimeError):
@@ -109,7 +109,7 @@ def test_bad_arguments_raise_runtime_error():
         FFMLP(30, 3, 64, 2)                                                                                     # ffmlp.py:84
     w = torch.zeros(64 * (32 + 64 + 16), dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError, match="hidden_dim"):
-        _ffmlp.ffmlp_inference(torch.zeros(4, 32, dtype=torch.float16, device="cuda"), w, 4, 32, 16, 256, 2, 0, 6, None,
+        _ffmlp.ffmlp_inference(torch.zeros(4, 32, dtype=torch.float16, device="cuda"), w, 4, 32, 16, 512, 2, 0, 6, None,
                                torch.empty(4, 16, dtype=torch.float16, device="cuda"))
 
 
