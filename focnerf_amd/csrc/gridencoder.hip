@@ -856,28 +856,50 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
         const uint2 *vv = reinterpret_cast<const uint2 *>(rec_vals);
         uint32_t cr[UNR], nr[UNR]; uint2 cv[UNR], nv[UNR];
         uint32_t i0 = lo + threadIdx.x;
+        // records past the chunk's end read as "row 0 += 0": no validity branch in the loop
 #pragma unroll
-        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rec_rows[i] : NONE; cv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
+        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rec_rows[i] : 0u; cv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
         // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT (and order
-        // independent); ds_add_u64 is also the fastest LDS atomic measured (1062 vs 602 G records/s for f64)
-        auto add = [&](uint32_t row, uint32_t hv) {
+        // independent); ds_add_u64 is also the fastest LDS atomic that can hold it (tools/bench_lds_atomic.hip: 1335 G two-channel records/s on
+        // planes, ds_add_f64 600, ds_add_f32 100, ds_pk_add_f16 200). The kernel ran at a third of that rate: its VALU was 59 % busy with the
+        // conversion (a 64-bit shift, a 64-bit negate and four selects per value, behind a per-value inf/NaN branch). Now:
+        //   * half -> 2^24-scaled int64 in 8 plain instructions, no select, no branch, sign and subnormals included: s = 16 f is exact,
+        //     H = floor(s) < 2^21, L = (s - H) 2^20 < 2^20 are exact fp32 integers, value = H 2^20 + L: lo word (H << 20) | L, hi word H >> 12;
+        //   * ONE inf/NaN test per record on its four halves ((x & 0x7C00) + 0x0400 carries into bit 15 only for an all-ones exponent);
+        //     such a record (an overflowed AMP step) takes the slow path that marks its rows.
+        auto fixed = [](float f, uint32_t &wlo, uint32_t &whi) {
+            const float sc = f * 16.0f;
+            const float H = floorf(sc);
+            const float L = (sc - H) * 1048576.0f;
+            const int32_t Hi = (int32_t)H;
+            wlo = ((uint32_t)Hi << 20) | (uint32_t)L;
+            whi = (uint32_t)(Hi >> 12);
+        };
+        auto add_fast = [&](uint32_t row, uint32_t hv) {
+            const __half2 h2 = *reinterpret_cast<const __half2 *>(&hv);
+            uint32_t l0, h0, l1, h1;
+            fixed(__low2float(h2), l0, h0);
+            fixed(__high2float(h2), l1, h1);
+            atomicAdd(&acci[row], ((unsigned long long)h0 << 32) | l0);
+            atomicAdd(&acci[GB_SEG + row], ((unsigned long long)h1 << 32) | l1);
+        };
+        auto add_slow = [&](uint32_t row, uint32_t hv) {
             if ((hv & 0x7C00u) == 0x7C00u || (hv & 0x7C000000u) == 0x7C000000u) {       // inf / NaN: the reference's half2 atomics would leave inf/NaN in the row
                 atomicOr(&s_bad[row >> 5], 1u << (row & 31u));
                 return;
             }
-            atomicAdd(&acci[row], gb_half_to_fixed(hv & 0xFFFFu));
-            atomicAdd(&acci[GB_SEG + row], gb_half_to_fixed(hv >> 16));
+            add_fast(row, hv);
         };
         while (i0 < hi) {
             const uint32_t i1 = i0 + GB_RTHREADS * UNR;
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rec_rows[i] : NONE; nv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
+            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rec_rows[i] : 0u; nv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) {
-                if (cr[u] != NONE) {
-                    add(cr[u] & (GB_SEG - 1u), cv[u].x);
-                    add((cr[u] >> 13) & (GB_SEG - 1u), cv[u].y);
-                }
+                const uint32_t r0 = cr[u] & (GB_SEG - 1u), r1 = (cr[u] >> 13) & (GB_SEG - 1u);
+                const uint32_t nonfinite = (((cv[u].x & 0x7C007C00u) + 0x04000400u) | ((cv[u].y & 0x7C007C00u) + 0x04000400u)) & 0x80008000u;
+                if (__builtin_expect(nonfinite == 0u, 1)) { add_fast(r0, cv[u].x); add_fast(r1, cv[u].y); }
+                else { add_slow(r0, cv[u].x); add_slow(r1, cv[u].y); }
             }
 #pragma unroll
             for (uint32_t u = 0; u < UNR; u++) { cr[u] = nr[u]; cv[u] = nv[u]; }

@@ -19,6 +19,13 @@ __global__ void __launch_bounds__(512) k(const uint32_t* idx, float* out, int it
     else if (MODE == 1) { atomicAdd((int*)&acc[2 * a], 1); atomicAdd((int*)&acc[2 * a + 1], 2); }
     else if (MODE == 3) { atomicAdd((unsigned long long*)&accd[2 * a], 3ull); atomicAdd((unsigned long long*)&accd[2 * a + 1], 5ull); }
     else if (MODE == 4) { atomicAdd(&accd[2 * a], 1.0); atomicAdd(&accd[2 * a + 1], 2.0); }
+    else if (MODE == 5) {        // one packed half2 add per record (both channels): ds_pk_add_f16
+      typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+      v2h v = {(_Float16)1.0f, (_Float16)2.0f};
+      (void)__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) v2h *)&acc[a], v);
+    }
+    else if (MODE == 6) { atomicAdd((unsigned long long*)&accd[a], 3ull); atomicAdd((unsigned long long*)&accd[8192 + a], 5ull); }   // planar u64
+    else if (MODE == 7) { atomicAdd((int*)&acc[a], 1); }                                                                                  // one u32 add per record
   }
   __syncthreads();
   float s = 0; for (int i = threadIdx.x; i < 32768; i += 512) s += acc[i];
@@ -40,6 +47,7 @@ int main() {
   const uint32_t masks[] = {8191u, 63u, 7u, 0u};
   for (uint32_t m : masks) {
     run<0>("2 x ds_add_f32", d, o, m); run<1>("2 x ds_add_u32", d, o, m); run<3>("2 x ds_add_u64", d, o, m); run<4>("2 x ds_add_f64", d, o, m);
+    run<5>("1 x ds_pk_add_f16", d, o, m); run<6>("2 x ds_add_u64 planar", d, o, m); run<7>("1 x ds_add_u32", d, o, m);
   }
   return 0;
 }
