@@ -750,7 +750,8 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 for (int i = 0; i < 8; i++) {
                     const float v0 = pv[2 * i], v1 = pv[2 * i + 1];
                     if constexpr (sizeof(T) == 2) {
-                        const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                        typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
+                        const gb_h2 hv = {(_Float16)ge_opaque(v0), (_Float16)ge_opaque(v1)};        // one v_cvt_pk_f16_f32 (round to nearest even) per pair
                         pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
                     } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
                 }
@@ -759,7 +760,8 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 for (int i = 0; i < 8; i++) {
                     const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
                     if constexpr (sizeof(T) == 2) {
-                        const __half2 hv = __halves2half2(__float2half_rn(ge_opaque(v0)), __float2half_rn(ge_opaque(v1)));
+                        typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
+                        const gb_h2 hv = {(_Float16)ge_opaque(v0), (_Float16)ge_opaque(v1)};        // one v_cvt_pk_f16_f32 (round to nearest even) per pair
                         pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
                     } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
                 }
