@@ -74,13 +74,14 @@ __device__ __forceinline__ bool ge_load_point(const float *__restrict__ inputs, 
 // size) taken once on wave-uniform values and the per-axis terms shared between the corners: (p+1)*k = p*k + k in uint32, so every
 // row is two adds or two xors instead of ge_index's per-corner multiplies and branches. Bit-identical to ge_index per corner (corner idx: bit d set = +1 along axis d).
 __device__ __forceinline__ void ge_rows3(const uint32_t (&pos_grid)[3], uint32_t hashmap_size, uint32_t resolution, uint32_t gridtype,
-                                              bool align_corners, uint32_t (&rows)[8]) {
+                                              bool align_corners, uint32_t (&rows)[8], bool *is_hashed = nullptr) {
     const uint32_t r1 = align_corners ? resolution : resolution + 1u;
     uint32_t stride = 1u, st[3];
     bool part[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) { part[d] = stride <= hashmap_size; st[d] = part[d] ? stride : 0u; if (part[d]) stride *= r1; }
     const bool hashed = gridtype == 0u && stride > hashmap_size;
+    if (is_hashed) *is_hashed = hashed;
     uint32_t t[3][2];
     if (hashed) {
         constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
@@ -395,8 +396,9 @@ __device__ __forceinline__ void gb_cell(const float (&x)[D], float scale, bool a
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         pos[d] = fmaf(x[d], scale, align_corners ? 0.0f : 0.5f);
-        pos_grid[d] = (uint32_t)floorf(pos[d]);
-        pos[d] -= (float)pos_grid[d];
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= fl;                               // == (float)pos_grid[d] for every in-range point (0 <= fl < 2^24): one conversion less per axis
         if (interp == 1) { const float v = pos[d]; pos[d] = v * v * fmaf(-2.0f, v, 3.0f); }
     }
 }
@@ -421,6 +423,15 @@ __device__ __forceinline__ void gb_cell_weights(const float (&pos)[D], float (&w
         ws[idx] = w;
     }
 }
+// D = 3, two channels: the 8 trilinear weights and the 16 products pv[2 i + c] = ws[i] * g[c], corner i = bit d set -> +1 along axis d.
+__device__ __forceinline__ void gb_weighted_grads(const float (&pf)[3], float g0, float g1, float (&pv)[16]) {
+    // (packed fp32 multiplies, v_pk_mul_f32, were measured slower here: 14 packed + the moves that pair their operands vs 28 plain multiplies)
+    float ws[8];
+    gb_cell_weights<3>(pf, ws);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { pv[2 * i] = ws[i] * g0; pv[2 * i + 1] = ws[i] * g1; }
+}
+
 // corner rows + weights of one (point, level)
 template <uint32_t D>
 __device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t gridtype,
@@ -584,13 +595,20 @@ __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uin
             if (emit) {
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
-                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
-                // one record per pair of corners along x (they share their segment unless they straddle an 8192-row boundary: then one each)
+                bool hashed;
+                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows, &hashed);
+                // one record per pair of corners along x (they share their segment unless they straddle an 8192-row boundary: then one each).
+                // On a hashed level (wave-uniform) the pair's rows differ in the bits x ^ (x + 1) < 2^13 only (resolution < 8191, gb_check): never.
+                if (hashed) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
-                    atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u);
-                    if (s0 != s1) atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u);
+                    for (int j = 0; j < 4; j++) atomicAdd(&hist[level * GB_MAX_SEGS + (rows[2 * j] >> GB_SEG_SHIFT)], 1u);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t s0 = rows[2 * j] >> GB_SEG_SHIFT, s1 = rows[2 * j + 1] >> GB_SEG_SHIFT;
+                        atomicAdd(&hist[level * GB_MAX_SEGS + s0], 1u);
+                        if (s0 != s1) atomicAdd(&hist[level * GB_MAX_SEGS + s1], 1u);
+                    }
                 }
             }
         }
@@ -735,41 +753,29 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             const uint32_t resolution = lv.resolution[level];
             uint32_t pg[3]; float pf[3];
             gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
-            float ws[8];
-            gb_cell_weights<3>(pf, ws);
             uint32_t pv0[8], pv1[8];                       // record values: fp16 -> half2 bits in pv0; fp32 -> two floats
             bool emit = inside;
+            float pv[16];
+            gb_weighted_grads(pf, g[0], g[1], pv);
             if (resolution <= lv.merge_max_res) {
                 const GbRun run = gb_run_flags(inside, pg);
                 emit = run.tail;
-                float pv[16];
-#pragma unroll
-                for (int i = 0; i < 8; i++) { pv[2 * i] = ws[i] * g[0]; pv[2 * i + 1] = ws[i] * g[1]; }
                 gb_run_sum16(pv, run);
+            }
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float v0 = pv[2 * i], v1 = pv[2 * i + 1];
-                    if constexpr (sizeof(T) == 2) {
-                        typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
-                        const gb_h2 hv = {(_Float16)ge_opaque(v0), (_Float16)ge_opaque(v1)};        // one v_cvt_pk_f16_f32 (round to nearest even) per pair
-                        pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
-                    } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float v0 = ws[i] * g[0], v1 = ws[i] * g[1];
-                    if constexpr (sizeof(T) == 2) {
-                        typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
-                        const gb_h2 hv = {(_Float16)ge_opaque(v0), (_Float16)ge_opaque(v1)};        // one v_cvt_pk_f16_f32 (round to nearest even) per pair
-                        pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
-                    } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
-                }
+            for (int i = 0; i < 8; i++) {
+                const float v0 = pv[2 * i], v1 = pv[2 * i + 1];
+                if constexpr (sizeof(T) == 2) {
+                    typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
+                    const gb_h2 hv = {(_Float16)ge_opaque(v0), (_Float16)ge_opaque(v1)};        // one v_cvt_pk_f16_f32 (round to nearest even) per pair
+                    pv0[i] = *reinterpret_cast<const uint32_t *>(&hv);
+                } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
             }
             if (emit) {
                 const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
                 uint32_t rows[8];
-                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows);
+                bool hashed;
+                ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows, &hashed);
                 auto place = [&](uint32_t seg, uint32_t r0, uint32_t r1, int i0, int i1) {      // i1 < 0: corner 1 carries nothing
                     const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
                     if (pos >= NREC) return;               // cannot happen when count and scatter agree
@@ -778,12 +784,17 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                     s_val[VW][pos] = i1 >= 0 ? pv0[i1 >= 0 ? i1 : 0] : 0u;
                     if constexpr (sizeof(T) != 2) { s_val[1][pos] = pv1[i0]; s_val[VW + 1][pos] = i1 >= 0 ? pv1[i1 >= 0 ? i1 : 0] : 0u; }
                 };
+                if (hashed) {                              // wave-uniform: a hashed level's pairs never straddle a segment boundary (see the count pass)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t r0 = rows[2 * j], r1 = rows[2 * j + 1];
-                    const uint32_t s0 = r0 >> GB_SEG_SHIFT, s1 = r1 >> GB_SEG_SHIFT;
-                    if (s0 == s1) place(s0, r0, r1, 2 * j, 2 * j + 1);
-                    else { place(s0, r0, r0, 2 * j, -1); place(s1, r1, r1, 2 * j + 1, -1); }
+                    for (int j = 0; j < 4; j++) place(rows[2 * j] >> GB_SEG_SHIFT, rows[2 * j], rows[2 * j + 1], 2 * j, 2 * j + 1);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t r0 = rows[2 * j], r1 = rows[2 * j + 1];
+                        const uint32_t s0 = r0 >> GB_SEG_SHIFT, s1 = r1 >> GB_SEG_SHIFT;
+                        if (s0 == s1) place(s0, r0, r1, 2 * j, 2 * j + 1);
+                        else { place(s0, r0, r0, 2 * j, -1); place(s1, r1, r1, 2 * j + 1, -1); }
+                    }
                 }
             }
         }
@@ -795,7 +806,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             const uint32_t rw = s_rows[j];
             const uint32_t at = gb[pb][rw >> 26] + j;
             if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
-            rec_rows[at] = rw & 0x3FFFFFFu;
+            rec_rows[at] = rw;                             // bits 26.. (the staging segment) ride along: the reduce reads two 13-bit rows and nothing else
             if constexpr (sizeof(T) == 2) reinterpret_cast<uint2 *>(rec_vals)[at] = make_uint2(s_val[0][j], s_val[1][j]);
             else reinterpret_cast<uint4 *>(rec_vals)[at] = make_uint4(s_val[0][j], s_val[1][j], s_val[2][j], s_val[3][j]);
         }
