@@ -512,11 +512,11 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
                 const int q = (lane & 15) >> 2, p = lane & 3, cg = 16 * ((lane >> 4) & 1);
 #pragma unroll
                 for (int ks = 0; ks < DW_CHUNK / 16; ks++) {
-                    const int k0 = 16 * ks + 8 * h + q;
+                    const int k0 = 16 * ks + 4 * q + h;      // batch rows {0,4,8,12} + h (+2 for the second read): see k_mlp_bwd_fused
                     const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0][32 * mt + cg + 4 * p]);
-                    const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0 + 4][32 * mt + cg + 4 * p]);
+                    const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sD[k0 + 2][32 * mt + cg + 4 * p]);
                     const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0][32 * nt + cg + 4 * p]);
-                    const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0 + 4][32 * nt + cg + 4 * p]);
+                    const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)&sA[k0 + 2][32 * nt + cg + 4 * p]);
                     // assemble the fragments at dword granularity (hipcc 7.2 mis-folds per-element extracts of the
                     // builtin's v4i16 result: it reuses element 0 for every lane element)
                     const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
@@ -830,11 +830,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                         const _Float16 *tD = sD + wv * RW * WD, *tA = sA + wv * RW * WA;
 #pragma unroll
                         for (int ks = 0; ks < RW / 16; ks++) {
-                            const int k0 = 16 * ks + 8 * h + q;
+                            // Which batch row plays k = 8 h + j of the MFMA is free as long as both operands agree (the sum over k has no order).
+                            // Rows 16 ks + 4 q + h (j = q) and + 2 (j = 4 + q): the four rows one 32-lane LDS group reads are 4 apart, and with the
+                            // tiles' 36-dword row stride 4 rows are 16 banks apart — each q gets its own quarter of the 64 banks. Consecutive rows
+                            // (stride 36 dwords: bank offsets 0, 36, 8, 44) overlapped pairwise: a 2-way conflict on half of these reads, the
+                            // bulk of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE, LDS 48 % busy).
+                            const int k0 = 16 * ks + 4 * q + h;
                             const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * p));
-                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 4) * WD + 32 * mt + cg + 4 * p));
+                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 2) * WD + 32 * mt + cg + 4 * p));
                             const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * p));
-                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 4) * WA + 32 * nt + cg + 4 * p));
+                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 2) * WA + 32 * nt + cg + 4 * p));
                             const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
                             const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
                             u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
