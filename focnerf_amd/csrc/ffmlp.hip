@@ -990,7 +990,7 @@ __device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h
 
 template <int NLS, int NLC, bool PLANAR, bool RELU_CT>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
-                                                          const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
+                                                          uint32_t dir_block, uint32_t n_dirs, const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
                                                           int relu_rt, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
     const int relu = RELU_CT ? 1 : relu_rt;            // ReLU as a compile-time fact (see k_mlp_bwd_fused); `false` keeps the runtime flag
     f16v FZ;                                           // constant zero C operand: the first MFMA of every chain takes the inline constant 0
@@ -1096,7 +1096,13 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             const uint64_t row = row0 + nb * 32 + c;
             const uint64_t rl = min(row, (uint64_t)B - 1);
             if (h == 0 && row < B && sigma_out) sigma_out[row] = expf((float)geo[nb][0]);
-            const float *dp = dirs + (rl / dir_div) * 3;
+            // row -> direction: dir_div consecutive rows per direction, or (dir_block > 0) the block-interleaved sample order of
+            // csrc/fixedstep.hip (fs_block_row): dir_block rays x dir_div depths per block, the ray index fastest
+            // (32-bit arithmetic: B is a uint32_t, and a 64-bit division is ~150 instructions per lane)
+            const uint32_t r32 = (uint32_t)rl;
+            uint32_t di = r32 / dir_div;
+            if (dir_block) di = min((r32 / (dir_block * dir_div)) * dir_block + r32 % dir_block, n_dirs - 1);
+            const float *dp = dirs + (uint64_t)di * 3;
             nf_sh16_half(dp[0], dp[1], dp[2], h, sh[nb]);
         }
         // ---- colour net
@@ -1335,7 +1341,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
 }
 
 template <int NLS, int NLC>
-static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
+static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
                              float *sigma, float *rgb, hipStream_t st) {
     const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024;
     auto kern = planar ? (relu ? k_nerf_infer<NLS, NLC, true, true> : k_nerf_infer<NLS, NLC, true, false>)
@@ -1344,8 +1350,8 @@ static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_di
     uint32_t grid = foc_div_up(foc_div_up(B, 64), MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)enc, dirs, dir_div, (const _Float16 *)w_sigma, (const _Float16 *)w_color, B, relu,
-                       sigma, rgb);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)enc, dirs, dir_div, dir_block, n_dirs, (const _Float16 *)w_sigma,
+                       (const _Float16 *)w_color, B, relu, sigma, rgb);
     FOC_CHECK_LAUNCH("nerf_field_inference");
     return FOC_OK;
 }
@@ -1426,21 +1432,24 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
                          calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
 }
 
-int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, const void *sigma_weights, uint32_t sigma_layers,
+int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs,
+                             const void *sigma_weights, uint32_t sigma_layers,
                              const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B, float *sigma,
                              float *rgb, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(enc && dirs && sigma_weights && color_weights && rgb, FOC_E_INVALID, "nerf_field_inference: null pointer");
     FOC_REQUIRE(hidden_dim == 64 && dir_div >= 1, FOC_E_INVALID, "nerf_field_inference: hidden_dim must be 64 (got %u)", hidden_dim);
+    FOC_REQUIRE(dir_block == 0 || n_dirs >= 1, FOC_E_INVALID, "nerf_field_inference: the block-interleaved row order needs the number of directions");
+    FOC_REQUIRE((uint64_t)dir_block * dir_div < (1ull << 32), FOC_E_INVALID, "nerf_field_inference: dir_block * dir_div must fit 32 bits");
     FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "nerf_field_inference: hidden activation must be relu(0) or none(6)");
     const int relu = activation == 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t key = sigma_layers * 10 + color_layers;
     switch (key) {
-        case 22: return nerf_infer_launch<2, 2>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
-        case 23: return nerf_infer_launch<2, 3>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
-        case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 22: return nerf_infer_launch<2, 2>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 23: return nerf_infer_launch<2, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
         default: foc_set_error("nerf_field_inference: layer counts (%u, %u) are not built (2/2, 2/3, 3/3)", sigma_layers, color_layers); return FOC_E_INVALID;
     }
 }

@@ -20,6 +20,12 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 struct FsGeom { float near, far, span, sample_dist, step; };
 
+// Block-interleaved sample order of the inference path (k_fs_sample): rows of 64 consecutive rays interleaved by depth.
+#define FS_RAY_BLOCK 64u
+__host__ __device__ __forceinline__ uint64_t fs_block_row(uint32_t n, uint32_t i, uint32_t T) {
+    return (uint64_t)(n / FS_RAY_BLOCK) * FS_RAY_BLOCK * T + (uint64_t)i * FS_RAY_BLOCK + n % FS_RAY_BLOCK;
+}
+
 __device__ __forceinline__ FsGeom fs_geom(const float *__restrict__ nears, const float *__restrict__ fars, uint32_t n, uint32_t T) {
     FsGeom g;
     g.near = nears[n]; g.far = fars[n];
@@ -63,20 +69,34 @@ __device__ __forceinline__ void fs_sh16(float x, float y, float z, float (&o)[16
 __global__ void __launch_bounds__(256) k_fs_sample(const float *__restrict__ rays_o, const float *__restrict__ rays_d, const float *__restrict__ nears,
                                                    const float *__restrict__ fars, const float *__restrict__ aabb, const float *__restrict__ noise,
                                                    uint32_t N, uint32_t T, float bound, float *__restrict__ xyzs, float *__restrict__ enc_in,
-                                                   _Float16 *__restrict__ ray_sh) {
-    const uint64_t total = (uint64_t)N * T;
+                                                   _Float16 *__restrict__ ray_sh, uint32_t ray_block) {
+    // ray_block == 0: sample (n, i) stands at row n*T + i. ray_block == FS_RAY_BLOCK: the rows of FS_RAY_BLOCK consecutive rays are
+    // interleaved, row = (n / 64)*64*T + i*64 + n % 64 (fs_block_row), the last block padded with copies of ray N-1 — the lanes of a wave
+    // of the kernels downstream are then 64 NEIGHBOURING RAYS AT ONE DEPTH instead of 64 depths of one ray, and the level-major encoder
+    // forward finds most of a wave's corner rows in a few cache lines (0.34 -> 0.17 ms per 2 M samples of an 800 x 800 view).
+    const uint64_t total = ray_block ? (uint64_t)((N + FS_RAY_BLOCK - 1) / FS_RAY_BLOCK) * FS_RAY_BLOCK * T : (uint64_t)N * T;
     const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
     const float two_b = 2 * bound;
     for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (uint64_t)gridDim.x * 256) {
-        const uint32_t n = (uint32_t)(s / T), i = (uint32_t)(s - (uint64_t)n * T);
+        uint32_t n, i;
+        bool own = true;                                   // false for the padding rows of the last block
+        if (ray_block) {
+            const uint32_t blk = (uint32_t)(s / ((uint64_t)FS_RAY_BLOCK * T)), in = (uint32_t)(s - (uint64_t)blk * FS_RAY_BLOCK * T);
+            i = in / FS_RAY_BLOCK;
+            n = blk * FS_RAY_BLOCK + in % FS_RAY_BLOCK;
+            own = n < N;
+            n = own ? n : N - 1;
+        } else {
+            n = (uint32_t)(s / T); i = (uint32_t)(s - (uint64_t)n * T);
+        }
         const FsGeom g = fs_geom(nears, fars, n, T);
-        const float z = fs_z(g, i, T, noise, s);
+        const float z = fs_z(g, i, T, noise, (uint64_t)n * T + i);     // the noise array is ray-major in both orders
         // torch: rays_o + rays_d * z (two kernels, two roundings), then min(max(., aabb_lo), aabb_hi)
         float x = rays_o[n * 3] + rays_d[n * 3] * z, y = rays_o[n * 3 + 1] + rays_d[n * 3 + 1] * z, w = rays_o[n * 3 + 2] + rays_d[n * 3 + 2] * z;
         x = fminf(fmaxf(x, a0), a3); y = fminf(fmaxf(y, a1), a4); w = fminf(fmaxf(w, a2), a5);
         if (xyzs) { xyzs[s * 3] = x; xyzs[s * 3 + 1] = y; xyzs[s * 3 + 2] = w; }
         if (enc_in) { enc_in[s * 3] = (x + bound) / two_b; enc_in[s * 3 + 1] = (y + bound) / two_b; enc_in[s * 3 + 2] = (w + bound) / two_b; }
-        if (ray_sh && i == 0) {                            // the ray's SH row as it stands in the colour-net input (fp16), once per ray
+        if (ray_sh && i == 0 && own) {                     // the ray's SH row as it stands in the colour-net input (fp16), once per ray
             float sh[16];
             fs_sh16(rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], sh);
             h8 lo, hi;
@@ -398,6 +418,50 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
 // PACK: additionally (or only: image / depth / weights_sum may then be null) writes the object's per-sample field as ONE float4 per sample,
 // field4[s] = (sigma, rgb where w > thresh else 0) — the (`densities`, `rgbs`) pair COMBINED.py merges across objects (:598-618), in the
 // layout the per-ray exchange and the fused select + composite read with one 16-byte access per lane (csrc/combine.hip).
+struct FsRayAcc { float Tc, ws, dp, r, g, b; };
+
+// 64 samples of ray n, sample i on the lane (sigma / c0..c2 are that sample's values; unread where i >= T): weights by wave scan, the
+// masked sums on the lane, the per-sample outputs written ray-major.
+template <bool PACK>
+__device__ __forceinline__ void fs_infer_tile(FsRayAcc &a, const FsGeom &g, uint32_t n, uint32_t i, uint32_t lane, uint32_t T, float sigma, float c0, float c1,
+                                              float c2, const float *__restrict__ noise, float density_scale, float thresh, float *__restrict__ rgb_masked,
+                                              float4 *__restrict__ field4, float *__restrict__ sigma_rm) {
+    const bool valid = i < T;
+    const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+    const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+    float delta = g.sample_dist;
+    if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+    const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
+    const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
+    const float P = wave_incl_prod(om, (int)lane);
+    float Pex = __shfl_up(P, 1, 64);
+    if (lane == 0) Pex = 1.0f;
+    const float w = alpha * (a.Tc * Pex);
+    if (valid) {
+        float oz = (z - g.near) / g.span;
+        oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
+        a.ws += w; a.dp += w * oz;
+        const bool on = w > thresh;
+        if (on) { a.r += w * c0; a.g += w * c1; a.b += w * c2; }
+        if (rgb_masked) { rgb_masked[s * 3] = on ? c0 : 0.0f; rgb_masked[s * 3 + 1] = on ? c1 : 0.0f; rgb_masked[s * 3 + 2] = on ? c2 : 0.0f; }
+        if (PACK) field4[s] = make_float4(sigma, on ? c0 : 0.0f, on ? c1 : 0.0f, on ? c2 : 0.0f);
+        if (sigma_rm) sigma_rm[s] = sigma;
+    }
+    a.Tc *= __shfl(P, 63, 64);
+}
+
+template <bool PACK>
+__device__ __forceinline__ void fs_infer_finish(FsRayAcc &a, uint32_t n, uint32_t lane, const float *__restrict__ bg_ray, float bg_scalar,
+                                                float *__restrict__ image, float *__restrict__ depth, float *__restrict__ weights_sum) {
+    const float ws = wave_sum(a.ws), dp = wave_sum(a.dp), r = wave_sum(a.r), gg = wave_sum(a.g), b = wave_sum(a.b);
+    if (lane == 0 && (!PACK || image)) {
+        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
+        image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
+        depth[n] = dp;
+        weights_sum[n] = ws;
+    }
+}
+
 template <bool PACK>
 __global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict__ sigma_in, const float *__restrict__ rgb_in, const float *__restrict__ nears,
                                                          const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
@@ -408,53 +472,75 @@ __global__ void __launch_bounds__(256) k_fs_render_infer(const float *__restrict
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const FsGeom g = fs_geom(nears, fars, n, T);
-    float Tc = 1.0f, ws = 0, dp = 0, r = 0, gg = 0, b = 0;
+    FsRayAcc a = {1.0f, 0, 0, 0, 0, 0};
     for (uint32_t base = 0; base < T; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < T;
         const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
         const float sigma = sigma_in[s];
-        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
-        float delta = g.sample_dist;
-        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
-        const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
-        const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
-        const float P = wave_incl_prod(om, (int)lane);
-        float Pex = __shfl_up(P, 1, 64);
-        if (lane == 0) Pex = 1.0f;
-        const float w = alpha * (Tc * Pex);
-        if (valid) {
-            float oz = (z - g.near) / g.span;
-            oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
-            ws += w; dp += w * oz;
-            const bool on = w > thresh;
-            const float c0 = rgb_in[s * 3], c1 = rgb_in[s * 3 + 1], c2 = rgb_in[s * 3 + 2];
-            if (on) { r += w * c0; gg += w * c1; b += w * c2; }
-            if (rgb_masked) { rgb_masked[s * 3] = on ? c0 : 0.0f; rgb_masked[s * 3 + 1] = on ? c1 : 0.0f; rgb_masked[s * 3 + 2] = on ? c2 : 0.0f; }
-            if (PACK) field4[s] = make_float4(sigma, on ? c0 : 0.0f, on ? c1 : 0.0f, on ? c2 : 0.0f);
-        }
-        Tc *= __shfl(P, 63, 64);
+        float c0 = 0, c1 = 0, c2 = 0;
+        if (valid) { c0 = rgb_in[s * 3]; c1 = rgb_in[s * 3 + 1]; c2 = rgb_in[s * 3 + 2]; }
+        fs_infer_tile<PACK>(a, g, n, i, lane, T, sigma, c0, c1, c2, noise, density_scale, thresh, rgb_masked, field4, nullptr);
     }
-    ws = wave_sum(ws); dp = wave_sum(dp); r = wave_sum(r); gg = wave_sum(gg); b = wave_sum(b);
-    if (lane == 0 && (!PACK || image)) {
-        const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
-        image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
-        depth[n] = dp;
-        weights_sum[n] = ws;
+    fs_infer_finish<PACK>(a, n, lane, bg_ray, bg_scalar, image, depth, weights_sum);
+}
+
+// The same pass over sigma / rgb in the block-interleaved order (fs_block_row): a workgroup of 16 waves takes 16 rays (a quarter of a
+// 64-ray block: 64 B of every sigma row and 192 B of every rgb row), stages 64 depths of them through LDS with 16-byte loads (the next
+// tile's loads are in flight while this one is consumed) and each wave runs the per-ray pass above on one ray, reading its samples
+// transposed out of LDS (odd row strides: no bank conflicts). Per-sample outputs leave ray-major; sigma_rm (may be NULL) = the
+// densities in ray-major order for callers that return them.
+#define FS_BLK_RAYS 16u
+template <bool PACK>
+__global__ void __launch_bounds__(1024) k_fs_render_infer_blk(const float *__restrict__ sigma_in, const float *__restrict__ rgb_in, const float *__restrict__ nears,
+                                                              const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
+                                                              float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
+                                                              float *__restrict__ image, float *__restrict__ depth, float *__restrict__ weights_sum,
+                                                              float *__restrict__ rgb_masked, float4 *__restrict__ field4, float *__restrict__ sigma_rm) {
+    __shared__ float tile_s[64][FS_BLK_RAYS + 1];
+    __shared__ float tile_c[64][FS_BLK_RAYS * 3 + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n0 = blockIdx.x * FS_BLK_RAYS;                         // first ray of the workgroup; its rows start at fs_block_row(n0, i, T)
+    const uint64_t row0 = fs_block_row(n0, 0, T);
+    // loads of one tile: threads 0..255 -> (depth, 16-byte part) of the sigma rows, threads 256..1023 -> of the rgb rows
+    const bool is_s = tid < 256;
+    const uint32_t li = is_s ? tid : tid - 256;
+    const uint32_t l_step = is_s ? li >> 2 : li / 12, l_part = is_s ? (li & 3) : li % 12;
+    const float *src = is_s ? sigma_in + row0 + l_part * 4 : rgb_in + row0 * 3 + l_part * 4;
+    const uint32_t src_ld = is_s ? FS_RAY_BLOCK : FS_RAY_BLOCK * 3;
+    float *dst = is_s ? &tile_s[l_step][l_part * 4] : &tile_c[l_step][l_part * 4];
+    float4 nx = make_float4(0, 0, 0, 0);
+    if (l_step < T) nx = *reinterpret_cast<const float4 *>(src + (uint64_t)l_step * src_ld);
+    const uint32_t n = n0 + wv;
+    const bool own = n < N;                                               // wave-uniform
+    const FsGeom g = fs_geom(nears, fars, own ? n : N - 1, T);
+    FsRayAcc a = {1.0f, 0, 0, 0, 0, 0};
+    for (uint32_t base = 0; base < T; base += 64) {
+        dst[0] = nx.x; dst[1] = nx.y; dst[2] = nx.z; dst[3] = nx.w;
+        __syncthreads();
+        if (base + 64 + l_step < T) nx = *reinterpret_cast<const float4 *>(src + (uint64_t)(base + 64 + l_step) * src_ld);
+        if (own)
+            fs_infer_tile<PACK>(a, g, n, base + lane, lane, T, tile_s[lane][wv], tile_c[lane][wv * 3], tile_c[lane][wv * 3 + 1], tile_c[lane][wv * 3 + 2],
+                                noise, density_scale, thresh, rgb_masked, field4, sigma_rm);
+        __syncthreads();
     }
+    if (own) fs_infer_finish<PACK>(a, n, lane, bg_ray, bg_scalar, image, depth, weights_sum);
 }
 
 // ================================================================= host entry points
 extern "C" {
 
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
-                     uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *ray_sh, void *stream) {
+                     uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *ray_sh, uint32_t ray_block, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && nears && fars && aabb && (xyzs || enc_in), FOC_E_INVALID, "fixed_sample: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_sample: T must be >= 2");
-    hipLaunchKernelGGL(k_fs_sample, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars, aabb,
-                       noise, N, T, bound, xyzs, enc_in, (_Float16 *)ray_sh);
+    FOC_REQUIRE(ray_block == 0 || ray_block == FS_RAY_BLOCK, FOC_E_INVALID, "fixed_sample: ray_block must be 0 (ray-major) or %u (got %u)", FS_RAY_BLOCK, ray_block);
+    const uint64_t rows = ray_block ? (uint64_t)foc_div_up(N, FS_RAY_BLOCK) * FS_RAY_BLOCK * T : (uint64_t)N * T;
+    hipLaunchKernelGGL(k_fs_sample, dim3(foc_grid_1d(rows, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, nears, fars, aabb,
+                       noise, N, T, bound, xyzs, enc_in, (_Float16 *)ray_sh, ray_block);
     FOC_CHECK_LAUNCH("fixed_sample");
     return FOC_OK;
 }
@@ -540,11 +626,20 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
 
 int foc_fixed_render_inference(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
                                float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
-                               float *rgb_masked, void *stream) {
+                               float *rgb_masked, uint32_t ray_block, float *sigma_raymajor, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(sigma && rgb && nears && fars && image && depth && weights_sum, FOC_E_INVALID, "fixed_render_inference: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_render_inference: T must be >= 2");
+    FOC_REQUIRE(ray_block == 0 || ray_block == FS_RAY_BLOCK, FOC_E_INVALID, "fixed_render_inference: ray_block must be 0 or %u (got %u)", FS_RAY_BLOCK, ray_block);
+    FOC_REQUIRE(ray_block || !sigma_raymajor, FOC_E_INVALID, "fixed_render_inference: sigma_raymajor is the un-blocked copy of a blocked sigma (ray_block == 0: sigma already is ray-major)");
+    if (ray_block) {
+        FOC_REQUIRE((((uintptr_t)sigma | (uintptr_t)rgb) & 15) == 0, FOC_E_INVALID, "fixed_render_inference: blocked sigma / rgb must be 16-byte aligned");
+        hipLaunchKernelGGL(k_fs_render_infer_blk<false>, dim3(foc_div_up(N, FS_BLK_RAYS)), dim3(1024), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar,
+                           N, T, density_scale, thresh, image, depth, weights_sum, rgb_masked, (float4 *)nullptr, sigma_raymajor);
+        FOC_CHECK_LAUNCH("fixed_render_inference");
+        return FOC_OK;
+    }
     hipLaunchKernelGGL(k_fs_render_infer<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
                        density_scale, thresh, image, depth, weights_sum, rgb_masked, (float4 *)nullptr);
     FOC_CHECK_LAUNCH("fixed_render_inference");
@@ -553,7 +648,7 @@ int foc_fixed_render_inference(const float *sigma, const float *rgb, const float
 
 int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
                          float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
-                         float *field4, void *stream) {
+                         float *field4, uint32_t ray_block, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(sigma && rgb && nears && fars && field4, FOC_E_INVALID, "fixed_field_pack: null pointer");
@@ -561,6 +656,14 @@ int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *near
                 "fixed_field_pack: image, depth and weights_sum go together (all or none)");
     FOC_REQUIRE(((uintptr_t)field4 & 15) == 0, FOC_E_INVALID, "fixed_field_pack: field4 must be 16-byte aligned");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_field_pack: T must be >= 2");
+    FOC_REQUIRE(ray_block == 0 || ray_block == FS_RAY_BLOCK, FOC_E_INVALID, "fixed_field_pack: ray_block must be 0 or %u (got %u)", FS_RAY_BLOCK, ray_block);
+    if (ray_block) {
+        FOC_REQUIRE((((uintptr_t)sigma | (uintptr_t)rgb) & 15) == 0, FOC_E_INVALID, "fixed_field_pack: blocked sigma / rgb must be 16-byte aligned");
+        hipLaunchKernelGGL(k_fs_render_infer_blk<true>, dim3(foc_div_up(N, FS_BLK_RAYS)), dim3(1024), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar,
+                           N, T, density_scale, thresh, image, depth, weights_sum, (float *)nullptr, (float4 *)field4, (float *)nullptr);
+        FOC_CHECK_LAUNCH("fixed_field_pack");
+        return FOC_OK;
+    }
     hipLaunchKernelGGL(k_fs_render_infer<true>, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
                        density_scale, thresh, image, depth, weights_sum, (float *)nullptr, (float4 *)field4);
     FOC_CHECK_LAUNCH("fixed_field_pack");

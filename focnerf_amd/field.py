@@ -60,9 +60,16 @@ def _half_of(param):
         return param.detach().to(torch.half).contiguous()
     hit = _half_scope.get(id(param))
     if hit is not None and hit[0] is param and hit[1].device == param.device:
+        if hit[2] is not None and torch.cuda.current_stream(param.device) != hit[3]:
+            torch.cuda.current_stream(param.device).wait_event(hit[2])      # made on another stream (staged render: chunks alternate streams)
         return hit[1]
     h = param.detach().to(torch.half).contiguous()
-    _half_scope[id(param)] = (param, h)
+    ev = st = None
+    if h.is_cuda:
+        st = torch.cuda.current_stream(h.device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+    _half_scope[id(param)] = (param, h, ev, st)
     return h
 
 
@@ -119,8 +126,9 @@ def infer_fusable(model):
 
 
 @torch.no_grad()
-def field_infer(model, xn, dirs, dir_div=1):
-    """xn [M,3] fp32 in [0,1] (already normalised), dirs [M / dir_div, 3] -> sigma [M] fp32, rgb [M,3] fp32 (no autograd)."""
+def field_infer(model, xn, dirs, dir_div=1, dir_block=0):
+    """xn [M,3] fp32 in [0,1] (already normalised), dirs [M / dir_div, 3] -> sigma [M] fp32, rgb [M,3] fp32 (no autograd).
+    dir_block = 64: the rows stand in the block-interleaved order of `fixedstep.fixed_sample(..., ray_block=64)`."""
     from ._lib import lib, ptr, stream_of, check
     enc, sn, cn = model.encoder, model.sigma_net, model.color_net
     xn = xn.contiguous().float()
@@ -133,7 +141,7 @@ def field_infer(model, xn, dirs, dir_div=1):
                                      enc.gridtype_id, enc.align_corners, enc.interp_id)
     sigma = torch.empty(M, dtype=torch.float32, device=xn.device)
     rgb = torch.empty(M, 3, dtype=torch.float32, device=xn.device)
-    check(lib.foc_nerf_field_inference(ptr(planes), 1, ptr(dirs), int(dir_div), ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, 64, sn.activation, M,
+    check(lib.foc_nerf_field_inference(ptr(planes), 1, ptr(dirs), int(dir_div), int(dir_block), dirs.shape[0], ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, 64, sn.activation, M,
                                        ptr(sigma), ptr(rgb), stream_of(xn)), "nerf_field_inference")
     return sigma, rgb
 

@@ -19,14 +19,30 @@ from ._lib import lib, ptr, stream_of, check
 from .gridencoder import grid_encode
 
 
-def fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, bound, want_xyzs=False, want_ray_sh=False):
+RAY_BLOCK = 64      # block-interleaved sample order of the inference path (csrc/fixedstep.hip, fs_block_row)
+
+
+def ray_block_default():
+    """Sample order of the fused inference path: 64-ray blocks unless FOC_RAY_BLOCK=0 (ray-major, the round-1 order)."""
+    import os
+    return RAY_BLOCK if os.environ.get("FOC_RAY_BLOCK", str(RAY_BLOCK)) != "0" else 0
+
+
+def blocked_rows(N, T, ray_block):
+    """Rows of the per-sample arrays of N rays x T samples in the given order (the last 64-ray block is padded)."""
+    return N * T if not ray_block else -(-N // ray_block) * ray_block * T
+
+
+def fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, bound, want_xyzs=False, want_ray_sh=False, ray_block=0):
+    """ray_block = 64: rows in the block-interleaved order (include/focnerf.h), `blocked_rows(N, T, 64)` of them."""
     N = rays_o.shape[0]
     dev = rays_o.device
-    enc_in = torch.empty(N * T, 3, dtype=torch.float32, device=dev)
-    xyzs = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if want_xyzs else None
+    rows = blocked_rows(N, T, ray_block)
+    enc_in = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+    xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev) if want_xyzs else None
     ray_sh = torch.empty(N, 16, dtype=torch.float16, device=dev) if want_ray_sh else None
     check(lib.foc_fixed_sample(ptr(rays_o), ptr(rays_d), ptr(nears), ptr(fars), ptr(aabb), ptr(noise), N, T, float(bound), ptr(xyzs), ptr(enc_in),
-                               ptr(ray_sh), stream_of(rays_o)), "fixed_sample")
+                               ptr(ray_sh), int(ray_block), stream_of(rays_o)), "fixed_sample")
     if want_ray_sh:
         return enc_in, xyzs, ray_sh
     return enc_in, xyzs
@@ -225,13 +241,16 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
     nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
     noise = torch.rand(N * T, dtype=torch.float32, device=dev) if perturb else None
     want_tail = (tail_fusable(model) and model.training and torch.is_grad_enabled())
-    enc_in, _, ray_sh = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, want_ray_sh=True) if want_tail else \
-        fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound) + (None,)
-
     from .field import infer_fusable, field_infer
-    if not torch.is_grad_enabled() and infer_fusable(model) and not getattr(model, "uses_object_feature", False):
-        # inference: sample -> encoder planes -> whole-field kernel -> weights + mask + composite kernel
-        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T)
+    fused_infer = not torch.is_grad_enabled() and infer_fusable(model) and not getattr(model, "uses_object_feature", False)
+    rb = ray_block_default() if fused_infer else 0
+    enc_in, _, ray_sh = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, want_ray_sh=True) if want_tail else \
+        fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, ray_block=rb) + (None,)
+
+    if fused_infer:
+        # inference: sample -> encoder planes -> whole-field kernel -> weights + mask + composite kernel; between the kernels the samples
+        # stand in 64-ray blocks (neighbouring rays at one depth on the lanes of a wave: the encoder's gathers share cache lines)
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb)
         bg_ray, bg_scalar = _background(bg_color, N, dev)
         # `_out` = (depth [N], image [N,3]) fp32 contiguous views of the caller's whole-view buffers (NeRFRenderer.render, staged)
         direct = (_out is not None and _out[0].dtype == torch.float32 and _out[1].dtype == torch.float32 and _out[0].is_contiguous()
@@ -239,15 +258,23 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         depth, image = (_out[0].view(N), _out[1].view(N, 3)) if direct else (torch.empty(N, dtype=torch.float32, device=dev),
                                                                               torch.empty(N, 3, dtype=torch.float32, device=dev))
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
-        rgb_masked = torch.empty(N * T, 3, dtype=torch.float32, device=dev) if return_fields else None
+        rgb_masked = densities = None
+        if return_fields:
+            # the whole-view field buffers of a staged render (`_out[2:]` = densities [N,T], rgbs [N,T,3] views): written in place
+            if direct and len(_out) == 4 and all(t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in _out[2:]) \
+                    and _out[2].numel() == N * T and _out[3].numel() == 3 * N * T and rb:
+                densities, rgb_masked = _out[2].view(N * T), _out[3].view(N * T, 3)
+            else:
+                rgb_masked = torch.empty(N * T, 3, dtype=torch.float32, device=dev)
+                densities = torch.empty(N * T, dtype=torch.float32, device=dev) if rb else None
         check(lib.foc_fixed_render_inference(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T,
                                              float(model.density_scale), float(weight_thresh), ptr(image), ptr(depth), ptr(weights_sum), ptr(rgb_masked),
-                                             stream_of(sigma)), "fixed_render_inference")
+                                             rb, ptr(densities), stream_of(sigma)), "fixed_render_inference")
         t_mid = time.time()
         results = {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum, 'criterion_outside_mask': None,
                    'timing': [t_mid - t_start, time.time() - t_mid]}
         if return_fields:
-            results['densities'] = sigma.view(N, T, 1)
+            results['densities'] = (densities if rb else sigma).view(N, T, 1)
             results['rgbs'] = rgb_masked.view(N, T, 3)
         return results
 
@@ -320,10 +347,11 @@ def render_field4(model, rays_o, rays_d, num_steps=512, weight_thresh=1e-10, yol
     if infer_fusable(model) and not getattr(model, "uses_object_feature", False) and model.bg_radius <= 0:
         aabb = model.aabb_train if model.training else model.aabb_infer
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
-        enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, None, T, model.bound)
-        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T)
+        rb = ray_block_default()
+        enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, None, T, model.bound, ray_block=rb)
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb)
         check(lib.foc_fixed_field_pack(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), None, None, 1.0, N, T, float(model.density_scale),
-                                       float(weight_thresh), None, None, None, ptr(out), stream_of(sigma)), "fixed_field_pack")
+                                       float(weight_thresh), None, None, None, ptr(out), rb, stream_of(sigma)), "fixed_field_pack")
         return out
     from .combine import pack_field4
     with torch.autocast("cuda", dtype=torch.float16):

@@ -14,6 +14,7 @@ What differs from the reference caller:
     renderer), and `return_fields` controls whether the per-sample fields COMBINED.py merges are returned.
 """
 import math
+import os
 import time
 
 import torch
@@ -48,6 +49,17 @@ def sample_pdf(bins, weights, n_samples, det=False):
     mass = cdf_g[..., 1] - cdf_g[..., 0]
     mass = torch.where(mass < 1e-5, torch.ones_like(mass), mass)
     return bins_g[..., 0] + (u - cdf_g[..., 0]) / mass * (bins_g[..., 1] - bins_g[..., 0])
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    """n side streams per device for the staged render (made once: stream creation is not free, and scratch buffers are keyed by stream)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _SIDE_STREAMS[key]
 
 
 def _flat_rays(rays_o, rays_d):
@@ -311,28 +323,61 @@ class NeRFRenderer(nn.Module):
         dev = rays_o.device
         depth, image = torch.empty(B, N, device=dev), torch.empty(B, N, 3, device=dev)
         densities = rgbs = None
+        want_fields = kwargs.get("return_fields")
+        if (not self.training) if want_fields is None else want_fields:
+            T = int(kwargs.get("num_steps", 512)) + int(kwargs.get("upsample_steps", 0))
+            densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
         import contextlib
         from .field import half_cache_scope
         # one fp16 conversion of the table / weight blobs per VIEW instead of per chunk — only where nothing can write the parameters
         # between two chunks (no autograd, hence no optimizer step inside the loop); the copies are dropped when the view is done
+        # Chunks are independent of each other while the kernels of one chunk form a chain: under no_grad the chunks alternate between
+        # two side streams, so that the launch gaps and the narrow kernels (near/far, sampling, compositing) of one chunk run under the
+        # wide kernels of the next (FOC_RENDER_STREAMS=1: everything on the caller's stream).
+        n_streams = int(os.environ.get("FOC_RENDER_STREAMS", "2")) if (not torch.is_grad_enabled() and dev.type == "cuda") else 1
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         with (half_cache_scope() if not torch.is_grad_enabled() else contextlib.nullcontext()):
+            sides = []
+            if n_streams > 1:
+                self._warm_half_cache()                                       # the fp16 copies are made on the caller's stream, before the fork
+                sides = _side_streams(dev, n_streams)
+                for st in sides:
+                    st.wait_stream(main)
+            chunk = 0
             for b in range(B):
                 for lo in range(0, N, max_ray_batch):
                     hi = min(lo + max_ray_batch, N)
                     # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
-                    into = (depth[b, lo:hi], image[b, lo:hi])
-                    part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, _out=into, **kwargs)
-                    if part['depth'].data_ptr() != into[0].data_ptr():
-                        depth[b:b + 1, lo:hi] = part['depth']
-                    if part['image'].data_ptr() != into[1].data_ptr():
-                        image[b:b + 1, lo:hi] = part['image']
-                    if 'densities' in part:
-                        if densities is None:
-                            T = part['densities'].shape[1]
-                            densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
-                        densities[b:b + 1, lo:hi] = part['densities'].permute(2, 0, 1)
-                        rgbs[b:b + 1, lo:hi] = part['rgbs']
+                    into = (depth[b, lo:hi], image[b, lo:hi]) + ((densities[b, lo:hi], rgbs[b, lo:hi]) if densities is not None else ())
+                    with (torch.cuda.stream(sides[chunk % n_streams]) if sides else contextlib.nullcontext()):
+                        part = self._render_chunk(rays_o, rays_d, b, lo, hi, yolo_details, into, kwargs)
+                    chunk += 1
+            for st in sides:
+                main.wait_stream(st)
         out = {'depth': depth, 'image': image, 'timing': part.get('timing')}
-        if densities is not None:
+        if densities is not None and 'densities' in part:
             out['densities'], out['rgbs'] = densities, rgbs
         return out
+
+    def _render_chunk(self, rays_o, rays_d, b, lo, hi, yolo_details, into, kwargs):
+        """One chunk of a staged render: `run` on rays [lo, hi) of view b; whatever it did not write in place goes into `into` =
+        (depth, image[, densities, rgbs]) views of the whole-view buffers."""
+        part = self.run(rays_o[b:b + 1, lo:hi], rays_d[b:b + 1, lo:hi], yolo_details, _out=into, **kwargs)
+        if part['depth'].data_ptr() != into[0].data_ptr():
+            into[0].copy_(part['depth'].view(into[0].shape))
+        if part['image'].data_ptr() != into[1].data_ptr():
+            into[1].copy_(part['image'].view(into[1].shape))
+        if 'densities' in part and len(into) == 4:
+            if part['densities'].data_ptr() != into[2].data_ptr():
+                into[2].copy_(part['densities'].view(into[2].shape))
+            if part['rgbs'].data_ptr() != into[3].data_ptr():
+                into[3].copy_(part['rgbs'].view(into[3].shape))
+        return part
+
+    def _warm_half_cache(self):
+        from .field import _half_of
+        for mod in (getattr(self, "encoder", None), getattr(self, "sigma_net", None), getattr(self, "color_net", None)):
+            for name in ("embeddings", "weights"):
+                p = getattr(mod, name, None) if mod is not None else None
+                if torch.is_tensor(p):
+                    _half_of(p)

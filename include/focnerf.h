@@ -296,9 +296,12 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
  * direction, colour network, sigmoid. dirs [B / dir_div, 3] fp32: sample s uses direction s / dir_div (dir_div = 1 for
  * per-sample directions, = samples per ray when they are per ray). sigma [B] fp32 (may be NULL), rgb [B,3] fp32 (values
  * rounded to fp16 like the half sigmoid). Same bits as foc_ffmlp_inference -> foc_sample_head_forward -> foc_ffmlp_inference
- * -> foc_rgb_head_forward; hidden_dim 64, (sigma_layers, color_layers) in {(2,2), (2,3), (3,3)}. */
+ * -> foc_rgb_head_forward; hidden_dim 64, (sigma_layers, color_layers) in {(2,2), (2,3), (3,3)}.
+ * dir_block > 0: the rows stand in the block-interleaved sample order of foc_fixed_sample (ray_block = dir_block, dir_div =
+ * samples per ray): row r uses direction min((r / (dir_block*dir_div))*dir_block + r % dir_block, n_dirs - 1). dir_block = 0:
+ * n_dirs is not read. */
 int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div,
-                             const void *sigma_weights, uint32_t sigma_layers, const void *color_weights,
+                             uint32_t dir_block, uint32_t n_dirs, const void *sigma_weights, uint32_t sigma_layers, const void *color_weights,
                              uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B,
                              float *sigma, float *rgb, void *stream);
 
@@ -367,14 +370,20 @@ int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stre
  * Fixed-step render path as fused ops. No reference binding: these replace the torch
  * code of nerf/renderer.py:145-221 (== COMBINED.py:451-534) and the glue of nerf/network_ff.py:51-134
  * between the encoder and the two MLPs. M = N*T samples, ray-major. `noise` ([M] uniform(0,1), the
- * reference's torch.rand for perturb) may be NULL.
+ * reference's torch.rand for perturb, always ray-major) may be NULL.
+ *
+ * Sample order of the inference entry points (`ray_block`): 0 = ray-major, sample i of ray n at row n*T + i.
+ * 64 = block-interleaved: row (n/64)*64*T + i*64 + n%64, ceil(N/64)*64*T rows, the last block padded with copies
+ * of ray N-1 — 64 neighbouring rays at one depth are 64 consecutive rows, which is what makes the level-major
+ * encoder forward fast on a rendered view (its wave then finds its corner rows in a few cache lines). What
+ * leaves the path for the caller (image, depth, field4, rgb_masked, sigma_raymajor) is ray-major either way.
  * ------------------------------------------------------------------------- */
 
 /* z = near + (far-near)*linspace(0,1,T)[i] (+ (noise-0.5)*(far-near)/T); xyz = clip(o + d z, aabb) -> xyzs [M,3]
  * and/or enc_in [M,3] = (xyz + bound)/(2 bound), the GridEncoder's normalised input (grid.py:149). */
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars,
                      const float *aabb, const float *noise, uint32_t N, uint32_t T, float bound,
-                     float *xyzs, float *enc_in, void *ray_sh, void *stream);
+                     float *xyzs, float *enc_in, void *ray_sh, uint32_t ray_block, void *stream);
 /* ray_sh [N,16] fp16 or NULL: the degree-4 SH values of each ray's direction, rounded to fp16 as they stand in columns 0..15 of
  * the colour-net input (for foc_color_head_forward). */
 
@@ -421,11 +430,13 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
 /* Inference tail of the fixed-step renderer in one pass: sigma [M] fp32, rgb [M,3] fp32 (e.g. from
  * foc_nerf_field_inference) -> weights (alpha * cumprod), image [N,3] = sum w rgb [w > thresh] + (1 - sum w) bg,
  * depth [N], weights_sum [N]; rgb_masked [M,3] (may be NULL) = rgb where w > thresh else 0, the `rgbs` field of
- * nerf/renderer.py:187. */
+ * nerf/renderer.py:187. ray_block = 64: sigma / rgb stand in the block-interleaved order (16-byte aligned,
+ * ceil(N/64)*64*T rows); sigma_raymajor [M] (may be NULL) then receives the densities in ray-major order, the
+ * `densities` field. Same bits either way. */
 int foc_fixed_render_inference(const float *sigma, const float *rgb, const float *nears, const float *fars,
                                const float *noise, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T,
                                float density_scale, float thresh, float *image, float *depth, float *weights_sum,
-                               float *rgb_masked, void *stream);
+                               float *rgb_masked, uint32_t ray_block, float *sigma_raymajor, void *stream);
 
 /* foc_fixed_render_inference that also (or only: image, depth and weights_sum may then all be NULL) writes the object's
  * per-sample field packed as field4 [N,T,4] fp32 = (sigma, rgb where w > thresh else 0): the (`densities`, `rgbs`) pair
@@ -433,7 +444,7 @@ int foc_fixed_render_inference(const float *sigma, const float *rgb, const float
 int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *nears, const float *fars,
                          const float *noise, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T,
                          float density_scale, float thresh, float *image, float *depth, float *weights_sum,
-                         float *field4, void *stream);
+                         float *field4, uint32_t ray_block, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Per-sample network glue for callers with arbitrary sample lists (the occupancy-grid paths): the torch

@@ -167,7 +167,7 @@ def test_configs4_editable_fixture_on_the_device():
             raw = torch.from_numpy(fx[f"v{v}_raw_rgbs"][k]).cuda().reshape(-1, 3).contiguous()
             f4 = torch.empty(N, T, 4, device="cuda")
             check(lib.foc_fixed_field_pack(ptr(sig), ptr(raw), ptr(n_k), ptr(f_k), None, None, 1.0, N, T, 1.0, 1e-10, None, None, None, ptr(f4),
-                                           stream_of(sig)), "fixed_field_pack")
+                                           0, stream_of(sig)), "fixed_field_pack")
             got = to_np(f4)
             assert np.array_equal(got[..., 0], fx[f"v{v}_densities"][k])
             want = fx[f"v{v}_rgbs"][k]

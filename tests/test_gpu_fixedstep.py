@@ -84,6 +84,46 @@ def test_fused_fields_match_oracle_composite():
     np.testing.assert_allclose(to_np(res["image"][0])[~hit], 1.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("hw,T,perturb,bg", [(32, 512, False, "scalar"), (33, 100, True, "ray"), (9, 65, False, "scalar"), (1, 2, False, "scalar"),
+                                             (8, 64, True, "scalar")])
+def test_blocked_sample_order_is_bitwise_the_ray_major_path(hw, T, perturb, bg, monkeypatch):
+    """The inference path orders its samples in 64-ray blocks between its kernels (fixed_sample -> encoder -> whole-field kernel ->
+    composite; include/focnerf.h `ray_block`): a different walk order of the same per-sample arithmetic. Everything the caller sees —
+    image, depth, weights_sum, `densities`, `rgbs`, the packed field4 — is bit for bit what the ray-major order (FOC_RAY_BLOCK=0) gives,
+    for ray counts that are no multiple of 64 or 16 (padded last block), depth counts that are no multiple of 64, perturbed depths
+    (the noise array stays ray-major) and per-ray backgrounds."""
+    from focnerf_amd.fixedstep import render_fixed_steps, render_field4, fixed_sample
+    from focnerf_amd import raymarching
+    m = _model(1, 11).eval()
+    o, d = _rays(1, hw, 6)
+    N = hw * hw
+    bgc = 1.0 if bg == "scalar" else torch.rand(N, 3, device="cuda")
+    out = {}
+    for rb in ("0", "64"):
+        monkeypatch.setenv("FOC_RAY_BLOCK", rb)
+        torch.manual_seed(3)
+        with torch.no_grad():
+            res = render_fixed_steps(m, o, d, num_steps=T, bg_color=bgc, perturb=perturb, return_fields=True)
+            f4 = render_field4(m, o[0], d[0], num_steps=T)
+        out[rb] = (res, f4)
+    a, b = out["0"], out["64"]
+    for k in ("image", "weights_sum", "densities", "rgbs"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert torch.equal(torch.nan_to_num(a[0]["depth"]), torch.nan_to_num(b[0]["depth"]))
+    assert torch.equal(a[1], b[1])
+    assert a[0]["densities"].shape == (N, T, 1) and a[1].shape == (N, T, 4)
+    # the sample kernel itself: the blocked rows are the ray-major rows permuted, padding = the last ray
+    aabb = m.aabb_infer
+    nears, fars = raymarching.near_far_from_aabb(o[0], d[0], aabb, m.min_near)
+    noise = torch.rand(N * T, device="cuda") if perturb else None
+    rm, _ = fixed_sample(o[0], d[0], nears, fars, aabb, noise, T, m.bound)
+    bl, _ = fixed_sample(o[0], d[0], nears, fars, aabb, noise, T, m.bound, ray_block=64)
+    nb = -(-N // 64)
+    n = torch.arange(nb * 64, device="cuda").clamp(max=N - 1).view(nb, 1, 64)
+    rows = (n * T + torch.arange(T, device="cuda").view(1, T, 1)).reshape(-1)
+    assert bl.shape == (nb * 64 * T, 3) and torch.equal(torch.nan_to_num(bl), torch.nan_to_num(rm[rows]))
+
+
 def test_sample_positions_bit_exact_vs_torch():
     """fixed_sample reproduces the reference's z_vals / xyz arithmetic bit for bit (incl. torch.linspace's fill order)."""
     from focnerf_amd.fixedstep import fixed_sample

@@ -18,6 +18,13 @@ def _cuda(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def blocked_rows_of(N, T, block=64):
+    """Ray-major row of every row of the block-interleaved order (include/focnerf.h: row (n/64)*64*T + i*64 + n%64, padding = ray N-1)."""
+    nb = -(-N // block)
+    n = torch.arange(nb * block).clamp(max=N - 1).view(nb, 1, block)
+    return (n * T + torch.arange(T).view(1, T, 1)).reshape(-1)
+
+
 @pytest.mark.parametrize("name", ["run_foc.npz", "run_foc_b2.npz"])
 def test_reference_run_fixture_through_the_inference_kernel(name):
     """foc_fixed_render_inference (k_fs_render_infer: weights by wave scan, mask w > 1e-10, composite, depth) on the sigma / rgb the
@@ -33,7 +40,7 @@ def test_reference_run_fixture_through_the_inference_kernel(name):
     image, depth, ws = torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
     masked = torch.empty(N * T, 3, device="cuda")
     check(lib.foc_fixed_render_inference(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), None, None, 1.0, N, T, 1.0, 1e-10, ptr(image), ptr(depth), ptr(ws),
-                                         ptr(masked), stream_of(sigma)), "fixed_render_inference")
+                                         ptr(masked), 0, None, stream_of(sigma)), "fixed_render_inference")
     hit = g["nears"] < 1e30
     assert hit.sum() > 0.7 * N and (~hit).sum() > 0
     np.testing.assert_allclose(to_np(image), g["image"], rtol=0, atol=1e-4)
@@ -52,9 +59,22 @@ def test_reference_run_fixture_through_the_inference_kernel(name):
     f4 = torch.empty(N, T, 4, device="cuda")
     image2, depth2, ws2 = torch.empty_like(image), torch.empty_like(depth), torch.empty_like(ws)
     check(lib.foc_fixed_field_pack(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), None, None, 1.0, N, T, 1.0, 1e-10, ptr(image2), ptr(depth2), ptr(ws2),
-                                   ptr(f4), stream_of(sigma)), "fixed_field_pack")
+                                   ptr(f4), 0, stream_of(sigma)), "fixed_field_pack")
     assert torch.equal(image, image2) and torch.equal(ws, ws2) and torch.equal(torch.nan_to_num(depth), torch.nan_to_num(depth2))
     assert torch.equal(f4[..., 0].reshape(-1), sigma) and torch.equal(f4[..., 1:].reshape(-1, 3), masked)
+    # the block-interleaved sample order of the render path (64 rays x T depths per block, last block padded): same kernel body per ray,
+    # staged through LDS — identical bits, per-sample outputs ray-major again
+    rows = blocked_rows_of(N, T).cuda()
+    sig_b, rgb_b = sigma[rows].contiguous(), rgb[rows].contiguous()
+    image3, depth3, ws3, masked3, sig_rm = torch.empty_like(image), torch.empty_like(depth), torch.empty_like(ws), torch.empty_like(masked), torch.empty_like(sigma)
+    check(lib.foc_fixed_render_inference(ptr(sig_b), ptr(rgb_b), ptr(nears), ptr(fars), None, None, 1.0, N, T, 1.0, 1e-10, ptr(image3), ptr(depth3), ptr(ws3),
+                                         ptr(masked3), 64, ptr(sig_rm), stream_of(sigma)), "fixed_render_inference")
+    assert torch.equal(image, image3) and torch.equal(ws, ws3) and torch.equal(torch.nan_to_num(depth), torch.nan_to_num(depth3))
+    assert torch.equal(masked, masked3) and torch.equal(sig_rm, sigma)
+    f4b = torch.empty_like(f4)
+    check(lib.foc_fixed_field_pack(ptr(sig_b), ptr(rgb_b), ptr(nears), ptr(fars), None, None, 1.0, N, T, 1.0, 1e-10, None, None, None, ptr(f4b), 64,
+                                   stream_of(sigma)), "fixed_field_pack")
+    assert torch.equal(f4, f4b)
     # and the combiner's composite (image_depth_generation is a copy of run()'s compositing, COMBINED.py:141-200)
     from focnerf_amd.combine import composite_fixed_steps
     img4, dep4 = composite_fixed_steps(_cuda(g["sigmas"]), _cuda(g["rgbs"]), nears, fars, 1.0)

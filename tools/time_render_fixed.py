@@ -1,5 +1,7 @@
-"""Timing helper: configs[1] render (fixed-step, 4096-ray chunks) — run under rocprofv3 --kernel-trace --stats."""
+"""Timing helper: configs[1] render (fixed-step, 4096-ray chunks) — run under rocprofv3 --kernel-trace --stats.
+Prints per view: host enqueue time (loop returned, nothing waited for) and wall time to completion, min / median over the views."""
 import os, sys, time
+import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -9,12 +11,21 @@ dev = torch.device("cuda", 0)
 m = bench.build_model(1, dev, seed=0).eval()
 poses, intr = bench.make_training_rays(dev, 1, 8, seed=0)
 ro, rd = synthetic.get_rays(poses[:1], intr, 800, 800)
-kw = dict(staged=True, max_ray_batch=4096, num_steps=512, upsample_steps=0, perturb=False, fused=True)
+views = int(os.environ.get("VIEWS", "8"))
+kw = dict(staged=True, max_ray_batch=int(os.environ.get("CHUNK", "4096")), num_steps=512, upsample_steps=0, perturb=False, fused=True)
+if os.environ.get("FIELDS") == "0":
+    kw["return_fields"] = False
+enq, tot = [], []
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
     m.render(ro, rd, **kw)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        m.render(ro, rd, **kw)
-    torch.cuda.synchronize()
-print("s/view", (time.perf_counter() - t0) / 3)
+    for _ in range(views):
+        t0 = time.perf_counter()
+        out = m.render(ro, rd, **kw)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        enq.append(t1 - t0); tot.append(t2 - t0)
+        del out
+print(f"enqueue min {min(enq):.4f} med {np.median(enq):.4f}  s/view min {min(tot):.4f} med {np.median(tot):.4f}")
+print("s/view", float(np.median(tot)))
