@@ -20,7 +20,14 @@ z = nears[:, None] + (fars - nears)[:, None] * t
 x = ((ro[:, None, :] + rd[:, None, :] * z[..., None]).clamp(-1, 1).view(-1, 3) + 1) / 2
 B = x.shape[0]
 pls = m.encoder.per_level_scale
-for kind, pts in (("ray-coherent", x.contiguous()), ("random", torch.rand_like(x))):
+from focnerf_amd import synthetic
+vo, vd = synthetic.get_rays(poses[:1], intr, bench.VIEW, bench.VIEW)
+vo, vd = vo.view(-1, 3)[400 * 800:400 * 800 + 4096].contiguous(), vd.view(-1, 3)[400 * 800:400 * 800 + 4096].contiguous()
+vn, vf = raymarching.near_far_from_aabb(vo, vd, m.aabb_train, m.min_near)
+vz = vn[:, None] + (vf - vn)[:, None] * t
+vx = ((vo[:, None, :] + vd[:, None, :] * vz[..., None]).clamp(-1, 1) + 1) / 2                 # [4096,512,3]
+for kind, pts in (("training rays, ray-major", x.contiguous()), ("view rows, ray-major", vx.reshape(-1, 3).contiguous()),
+                  ("view rows, 64-ray blocks", vx.view(64, 64, 512, 3).permute(0, 2, 1, 3).reshape(-1, 3).contiguous()), ("random", torch.rand_like(x))):
     out = []
     for l in range(16):
         res = int(np.ceil(16 * pls ** l))

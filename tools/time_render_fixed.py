@@ -10,7 +10,8 @@ from focnerf_amd import synthetic
 dev = torch.device("cuda", 0)
 m = bench.build_model(1, dev, seed=0).eval()
 poses, intr = bench.make_training_rays(dev, 1, 8, seed=0)
-ro, rd = synthetic.get_rays(poses[:1], intr, 800, 800)
+rays = [synthetic.get_rays(poses[v:v + 1], intr, 800, 800) for v in range(8)]
+ro, rd = rays[0]
 views = int(os.environ.get("VIEWS", "8"))
 kw = dict(staged=True, max_ray_batch=int(os.environ.get("CHUNK", "4096")), num_steps=512, upsample_steps=0, perturb=False, fused=True)
 if os.environ.get("FIELDS") == "0":
@@ -19,13 +20,13 @@ enq, tot = [], []
 with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
     m.render(ro, rd, **kw)
     torch.cuda.synchronize()
-    for _ in range(views):
+    for i in range(views):
         t0 = time.perf_counter()
-        out = m.render(ro, rd, **kw)
+        out = m.render(*rays[i % 8], **kw)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         enq.append(t1 - t0); tot.append(t2 - t0)
         del out
-print(f"enqueue min {min(enq):.4f} med {np.median(enq):.4f}  s/view min {min(tot):.4f} med {np.median(tot):.4f}")
-print("s/view", float(np.median(tot)))
+print(f"enqueue min {min(enq):.4f} med {np.median(enq):.4f}  s/view min {min(tot):.4f} mean {np.mean(tot):.4f} max {max(tot):.4f} (views cycle through 8 poses)")
+print("s/view", float(np.mean(tot)))

@@ -59,6 +59,21 @@ for name, x in (("rows 400..405 (row-major rays)", chunk_points(400 * bench.VIEW
     res["ray-major"] = time_fwd(x)
     res["step-major"] = time_fwd(x.permute(1, 0, 2))
     res["64-ray blocks"] = time_fwd(x.view(R // 64, 64, T, 3).permute(0, 2, 1, 3))
+    for rb in (16, 32, 128, 256):
+        res[f"{rb}-ray blocks"] = time_fwd(x.view(R // rb, rb, T, 3).permute(0, 2, 1, 3))
+    for rr, ss in ((32, 2), (16, 4), (8, 8), (4, 16)):        # a wave's lanes = rr neighbouring rays x ss consecutive depths
+        res[f"{rr}x{ss} patches"] = time_fwd(x.view(R // rr, rr, T // ss, ss, 3).permute(0, 2, 1, 3, 4))
     res["shuffled"] = time_fwd(x.reshape(-1, 3)[torch.randperm(R * T, device=dev)])
+    print(name, "\n   " + "\n   ".join(f"{k}: {v:.3f} ms" for k, v in res.items()), flush=True)
+gen = torch.Generator().manual_seed(1)
+inds = torch.randint(0, bench.VIEW * bench.VIEW, (R,), generator=gen).to(dev)
+for name, ii in (("training batch, rays as drawn", inds), ("training batch, rays in pixel order", inds.sort().values)):
+    o, d = ro[ii], rd[ii]
+    nears, fars = raymarching.near_far_from_aabb(o.contiguous(), d.contiguous(), m.aabb_train, m.min_near)
+    t = torch.linspace(0, 1, T, device=dev)[None, :]
+    z = nears[:, None] + (fars - nears)[:, None] * t
+    x = ((o[:, None, :] + d[:, None, :] * z[..., None]).clamp(-m.bound, m.bound) + m.bound) / (2 * m.bound)
+    res = {"ray-major": time_fwd(x), "64-ray blocks": time_fwd(x.view(R // 64, 64, T, 3).permute(0, 2, 1, 3)),
+           "8x8 patches": time_fwd(x.view(R // 8, 8, T // 8, 8, 3).permute(0, 2, 1, 3, 4))}
     print(name, " ".join(f"{k}: {v:.3f} ms" for k, v in res.items()), flush=True)
 print("uniform random", f"{time_fwd(torch.rand(R * T, 3, device=dev)):.3f} ms")
