@@ -236,6 +236,101 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
     }
 }
 
+// ---- forward, the shape FOC runs: hash gridtype, align_corners off, linear interpolation, fp16 tables with C = 2, D = 3, no dy_dx, row pairs
+// 8-byte aligned. ge_forward_one with every per-call decision already taken: what is left at run time is dense-or-hashed (wave-uniform,
+// decided by the caller with ge_level_hashed) and, on a hashed level, ONE lane-divergent branch (x odd: the four x+1 corners are no row
+// neighbours and take their own 4-byte loads) instead of four. Same arithmetic in the same order: bit-identical results.
+__device__ __forceinline__ bool ge_level_hashed(uint32_t hashmap_size, uint32_t resolution, uint32_t &st1, uint32_t &st2) {
+    const uint32_t r1 = resolution + 1u;                 // the reference's uint32 stride walk (gridencoder.cu:70-83), D = 3
+    uint32_t stride = 1u;
+    st1 = st2 = 0u;
+    if (stride <= hashmap_size) stride *= r1;
+    if (stride <= hashmap_size) { st1 = stride; stride *= r1; }
+    if (stride <= hashmap_size) { st2 = stride; stride *= r1; }
+    return stride > hashmap_size;
+}
+
+__device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, const uint32_t *__restrict__ tw, uint32_t hashmap_size, bool hashed,
+                                                 uint32_t st1, uint32_t st2, float scale, __half *__restrict__ out) {
+    if (oob) { *reinterpret_cast<uint32_t *>(out) = 0u; return; }
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float p = fmaf(x[d], scale, 0.5f);
+        pg[d] = (uint32_t)floorf(p);
+        pos[d] = p - (float)pg[d];
+    }
+    uint32_t r0[4], r1[4];                               // rows of the corners (x, y_j, z_j) and (x + 1, y_j, z_j), j = y bit | z bit << 1
+    uint2 wide[4];
+    uint32_t nar[4] = {0u, 0u, 0u, 0u};
+    bool pr[4];
+    if (hashed) {
+        const uint32_t mask = hashmap_size - 1u;
+        const uint32_t t1 = pg[1] * 2654435761u, t2 = pg[2] * 805459861u;
+        const uint32_t yz[4] = {t1 ^ t2, (t1 + 2654435761u) ^ t2, t1 ^ (t2 + 805459861u), (t1 + 2654435761u) ^ (t2 + 805459861u)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { r0[j] = (pg[0] ^ yz[j]) & mask; r1[j] = ((pg[0] + 1u) ^ yz[j]) & mask; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tw + (r0[j] & ~1u));
+        const bool even = (pg[0] & 1u) == 0u;            // x even: x + 1 == x ^ 1, every (x, x+1) corner pair is an aligned row pair
+        if (!even) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) nar[j] = tw[r1[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) pr[j] = even;
+    } else {
+        const uint32_t t1 = pg[1] * st1, t2 = pg[2] * st2;
+        const uint32_t yz[4] = {t1 + t2, (t1 + st1) + t2, t1 + (t2 + st2), (t1 + st1) + (t2 + st2)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { r0[j] = pg[0] + yz[j]; r1[j] = r0[j] + 1u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tw + (r0[j] & ~1u));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            pr[j] = (r0[j] & 1u) == 0u;
+            if (!pr[j]) nar[j] = tw[r1[j]];
+        }
+    }
+    const float wx[2] = {1 - pos[0], pos[0]}, wy[2] = {1 - pos[1], pos[1]}, wz[2] = {1 - pos[2], pos[2]};
+    float res0 = 0.0f, res1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool odd = (r0[j] & 1u) != 0u;
+        const uint32_t v0 = odd ? wide[j].y : wide[j].x;
+        const uint32_t v1 = pr[j] ? (odd ? wide[j].x : wide[j].y) : nar[j];
+        const __half2 h0 = *reinterpret_cast<const __half2 *>(&v0), h1 = *reinterpret_cast<const __half2 *>(&v1);
+        const float w0 = (wx[0] * wy[j & 1]) * wz[j >> 1], w1 = (wx[1] * wy[j & 1]) * wz[j >> 1];
+        res0 = fmaf(w0, __low2float(h0), res0); res1 = fmaf(w0, __high2float(h0), res1);
+        res0 = fmaf(w1, __low2float(h1), res0); res1 = fmaf(w1, __high2float(h1), res1);
+    }
+    *reinterpret_cast<__half2 *>(out) = __halves2half2(__float2half_rn(ge_opaque(res0)), __float2half_rn(ge_opaque(res1)));
+}
+
+// One level of the fast shape or of the general one (`fast`: the launch-wide part of the decision, taken on the host).
+template <typename T, uint32_t D, uint32_t C>
+__device__ __forceinline__ void ge_forward_level(const float (&x)[D], bool oob, const T *__restrict__ grid, uint32_t off0, uint32_t hashmap_size, float scale,
+                                                 uint32_t resolution, T *__restrict__ out, T *__restrict__ dy, uint32_t gridtype, bool align_corners,
+                                                 uint32_t interp, uint32_t pairs) {
+    const bool aligned = ((off0 | hashmap_size) & 1u) == 0u;                   // row pairs of this level are 8-byte aligned and inside it
+    if constexpr (sizeof(T) == 2 && D == 3 && C == 2) {
+        if (pairs == 2u && aligned) {
+            uint32_t st1, st2;
+            const bool hashed = ge_level_hashed(hashmap_size, resolution, st1, st2);
+            if (!hashed || (hashmap_size & (hashmap_size - 1u)) == 0u) {
+                ge_forward_hash3(x, oob, reinterpret_cast<const uint32_t *>(grid) + off0, hashmap_size, hashed, st1, st2, scale,
+                                 reinterpret_cast<__half *>(out));
+                return;
+            }
+        }
+    }
+    if (pairs && aligned)
+        ge_forward_one<T, D, C, true>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, scale, resolution, out, dy, gridtype, align_corners, interp);
+    else
+        ge_forward_one<T, D, C, false>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, scale, resolution, out, dy, gridtype, align_corners, interp);
+}
+
 // Encoding workgroup f of a plain level walk -> chunk of 256 points and the range of levels it encodes: the `lc` leading levels (the
 // small dense tables, 1.4 MiB together for the default grid) are done by ONE workgroup per chunk, which loads its points once; the
 // levels from `lc` up follow one at a time. At those small levels a launch moves 12 bytes of position per 4 bytes of result: what
@@ -268,12 +363,8 @@ __global__ void __launch_bounds__(256) k_grid_fwd_lbc(const float *__restrict__ 
         const uint32_t off0 = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
         T *dy = dy_dx ? dy_dx + ((uint64_t)b * L + level) * D * C : nullptr;
-        if (pairs && ((off0 | hashmap_size) & 1u) == 0u)                       // row pairs of this level are 8-byte aligned and inside it
-            ge_forward_one<T, D, C, true>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                                          outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
-        else
-            ge_forward_one<T, D, C, false>(x, oob, grid + (uint64_t)off0 * C, hashmap_size, lv.scale[level], lv.resolution[level],
-                                           outputs + ((uint64_t)level * B + b) * C, dy, gridtype, align_corners, interp);
+        ge_forward_level<T, D, C>(x, oob, grid, off0, hashmap_size, lv.scale[level], lv.resolution[level], outputs + ((uint64_t)level * B + b) * C, dy,
+                                  gridtype, align_corners, interp, pairs);
     }
 }
 
@@ -636,7 +727,7 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
 template <typename T>
 __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restrict__ inputs, const T *__restrict__ grid, const int32_t *__restrict__ offsets,
                                                           T *__restrict__ outputs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners,
-                                                          uint32_t interp, uint32_t chunks, bool pairs, GbHeader *__restrict__ hdr,
+                                                          uint32_t interp, uint32_t chunks, uint32_t pairs, GbHeader *__restrict__ hdr,
                                                           uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0, uint32_t lc) {
     __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
     // the counting workgroups sit among the encoding workgroups of the FINE levels (from block w0 on, one in `period`): those are the
@@ -660,12 +751,8 @@ __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restric
     for (uint32_t level = l0; level < l1; level++) {
         const uint32_t off0 = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-        if (pairs && ((off0 | hashmap_size) & 1u) == 0u)
-            ge_forward_one<T, 3, 2, true>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
-                                          outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
-        else
-            ge_forward_one<T, 3, 2, false>(x, oob, grid + (uint64_t)off0 * 2, hashmap_size, lv.scale[level], lv.resolution[level],
-                                           outputs + ((uint64_t)level * B + b) * 2, nullptr, gridtype, align_corners, interp);
+        ge_forward_level<T, 3, 2>(x, oob, grid, off0, hashmap_size, lv.scale[level], lv.resolution[level], outputs + ((uint64_t)level * B + b) * 2,
+                                  (T *)nullptr, gridtype, align_corners, interp, pairs);
     }
 }
 
@@ -1090,6 +1177,14 @@ static bool ge_pairs_enabled() {
     if (on < 0) { const char *e = getenv("FOC_GRID_PAIRS"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
+// The `pairs` argument of the level-major forward kernels: 0 = one load per corner, 1 = row pairs, 2 = row pairs and the call is of the
+// shape ge_forward_hash3 serves (the per-level part of that decision is taken in the kernel). FOC_GRID_FAST=0: never 2 (A/B runs).
+static uint32_t ge_pairs_mode(const void *emb, const void *dy_dx, size_t elem, uint32_t D, uint32_t C, uint32_t gridtype, bool ac, uint32_t interp) {
+    static int fast = -1;
+    if (fast < 0) { const char *e = getenv("FOC_GRID_FAST"); fast = e ? atoi(e) : 1; }
+    if (!ge_pairs_enabled() || ((uintptr_t)emb & 7u) != 0u || dy_dx) return 0u;
+    return (fast && elem == 2 && D == 3 && C == 2 && gridtype == 0u && !ac && interp == 0u) ? 2u : 1u;
+}
 
 template <typename T, uint32_t D, uint32_t C>
 static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
@@ -1107,7 +1202,7 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
         const uint32_t groups = lc >= 2u ? L - lc + 1u : L;
         hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,
-                           (ge_pairs_enabled() && ((uintptr_t)emb & 7u) == 0u && !dy_dx) ? 1u : 0u, lc);
+                           ge_pairs_mode(emb, dy_dx, sizeof(T), D, C, gridtype, ac, interp), lc);
     }
     FOC_CHECK_LAUNCH("grid_encode_forward");
     return FOC_OK;
@@ -1256,7 +1351,7 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     const uint32_t w0 = lo * chunks, fit = ((hi - lo) * chunks) / n_tiles + 1u, period = (fit & 1u) ? fit : fit - 1u;
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
     hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
-                       interp, chunks, ge_pairs_enabled() && sizeof(T) == 2 && ((uintptr_t)emb & 7u) == 0u, hdr, wg_hist, n_tiles, period, w0, lc);
+                       interp, chunks, sizeof(T) == 2 ? ge_pairs_mode(emb, nullptr, sizeof(T), 3, 2, gridtype, ac, interp) : 0u, hdr, wg_hist, n_tiles, period, w0, lc);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted");
     hipLaunchKernelGGL(k_gbin_scans, dim3(L * GB_MAX_SEGS + 1), dim3(256), 0, st, hdr, wg_hist, n_tiles, L);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted(scans)");
