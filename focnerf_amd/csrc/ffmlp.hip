@@ -820,13 +820,20 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             foc_lds_barrier();     // LDS tiles only: the next group's prefetched rows stay in flight, grad_inputs stores are not waited for
             // ---- dW_s: output tile `wave` (MTo x NTi tiles, at most 4 for HIDDEN, in_dim <= 64)
             {
-                const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32;
-                if (wave < MTo * NTi) {
-                    const uint32_t mt = wave / NTi, nt = wave % NTi;
+                // a stage with 4 output tiles gives every wave one of them over all four waves' rows; one with 2 (the 16-wide output
+                // stage, a 32-wide input) is split along the batch as well: waves 2, 3 take the same tiles over the rows of waves 2, 3 —
+                // every wave owns an accumulator for every stage anyway, and the flush adds them up
+                const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi;
+                const uint32_t ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+                if (wave < ntile * ksplit) {
+                    const uint32_t tile = wave % ntile, kpart = wave / ntile;
+                    const uint32_t mt = tile / NTi, nt = tile % NTi;
                     const uint32_t o = 32 * mt + (lane & 31), i = 32 * nt + (lane & 31);
                     const int q = (lane & 15) >> 2, p = lane & 3, cg = 16 * ((lane >> 4) & 1);
 #pragma unroll
-                    for (int wv = 0; wv < 4; wv++) {
+                    for (int wi = 0; wi < 4; wi++) {
+                        if (ksplit == 2u && wi >= 2) break;
+                        const uint32_t wv = ksplit == 2u ? 2u * kpart + wi : (uint32_t)wi;
                         const _Float16 *tD = sD + wv * RW * WD, *tA = sA + wv * RW * WA;
 #pragma unroll
                         for (int ks = 0; ks < RW / 16; ks++) {
@@ -948,9 +955,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
         const uint32_t IN = s < NL ? (uint32_t)HIDDEN : in_dim;
         const uint32_t fl = NL - s;                                               // forward layer whose matrix this is (s = 0: output matrix)
         const uint64_t ws_off = s == 0 ? first + (uint64_t)(NL - 1) * lsz : (fl == 0 ? 0 : first + (uint64_t)(fl - 1) * lsz);
-        const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32;
-        if (wave < MTo * NTi) {
-            const uint32_t mt = wave / NTi, nt = wave % NTi;
+        const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi;
+        const uint32_t ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+        if (wave < ntile * ksplit) {
+            const uint32_t tile = wave % ntile;
+            const uint32_t mt = tile / NTi, nt = tile % NTi;
             const uint32_t i = 32 * nt + (lane & 31);
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
