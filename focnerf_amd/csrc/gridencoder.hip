@@ -257,10 +257,13 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
     uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const float p = fmaf(x[d], scale, 0.5f);
-        pg[d] = (uint32_t)floorf(p);
-        pos[d] = p - (float)pg[d];
+        const float p = fmaf(x[d], scale, 0.5f);         // >= 0.5 here (0 <= x <= 1): truncation is the floor, and p - floor(p) is exact —
+        pg[d] = (uint32_t)p;                             // v_fract_f32 returns that same value in one instruction
+        pos[d] = __builtin_amdgcn_fractf(p);
     }
+    // rows as 32-bit BYTE offsets from the level's base: the loads take the base from scalar registers (global_load ... v_off, s[base])
+    // instead of a 64-bit address per lane and load (the launch wrapper admits this path for levels below 2^30 rows only)
+    const char *tb = reinterpret_cast<const char *>(tw);
     uint32_t r0[4], r1[4];                               // rows of the corners (x, y_j, z_j) and (x + 1, y_j, z_j), j = y bit | z bit << 1
     uint2 wide[4];
     uint32_t nar[4] = {0u, 0u, 0u, 0u};
@@ -272,11 +275,11 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
 #pragma unroll
         for (int j = 0; j < 4; j++) { r0[j] = (pg[0] ^ yz[j]) & mask; r1[j] = ((pg[0] + 1u) ^ yz[j]) & mask; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tw + (r0[j] & ~1u));
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + ((r0[j] & ~1u) << 2));
         const bool even = (pg[0] & 1u) == 0u;            // x even: x + 1 == x ^ 1, every (x, x+1) corner pair is an aligned row pair
         if (!even) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) nar[j] = tw[r1[j]];
+            for (int j = 0; j < 4; j++) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (r1[j] << 2));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) pr[j] = even;
@@ -286,11 +289,11 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
 #pragma unroll
         for (int j = 0; j < 4; j++) { r0[j] = pg[0] + yz[j]; r1[j] = r0[j] + 1u; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tw + (r0[j] & ~1u));
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + ((r0[j] & ~1u) << 2));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             pr[j] = (r0[j] & 1u) == 0u;
-            if (!pr[j]) nar[j] = tw[r1[j]];
+            if (!pr[j]) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (r1[j] << 2));
         }
     }
     const float wx[2] = {1 - pos[0], pos[0]}, wy[2] = {1 - pos[1], pos[1]}, wz[2] = {1 - pos[2], pos[2]};
@@ -318,7 +321,7 @@ __device__ __forceinline__ void ge_forward_level(const float (&x)[D], bool oob, 
         if (pairs == 2u && aligned) {
             uint32_t st1, st2;
             const bool hashed = ge_level_hashed(hashmap_size, resolution, st1, st2);
-            if (!hashed || (hashmap_size & (hashmap_size - 1u)) == 0u) {
+            if ((!hashed || (hashmap_size & (hashmap_size - 1u)) == 0u) && hashmap_size <= (1u << 30)) {      // 32-bit byte offsets inside the level
                 ge_forward_hash3(x, oob, reinterpret_cast<const uint32_t *>(grid) + off0, hashmap_size, hashed, st1, st2, scale,
                                  reinterpret_cast<__half *>(out));
                 return;
