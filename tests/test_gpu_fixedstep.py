@@ -124,6 +124,34 @@ def test_blocked_sample_order_is_bitwise_the_ray_major_path(hw, T, perturb, bg, 
     assert bl.shape == (nb * 64 * T, 3) and torch.equal(torch.nan_to_num(bl), torch.nan_to_num(rm[rows]))
 
 
+@pytest.mark.parametrize("streams", ["1", "2", "3"])
+def test_staged_render_assembles_the_view_in_place_on_alternating_streams(streams, monkeypatch):
+    """`render(staged=True)` in eval mode returns image, depth and the per-sample fields of the whole view (nerf/renderer.py:511-560). The
+    fused path writes every chunk's part straight into those buffers, chunks alternating over side streams: the result is bit for bit the
+    unstaged `run()` on all rays, for a chunk size that divides neither the ray count nor 64, two views in the batch, and a caller that
+    is itself on a non-default stream."""
+    from focnerf_amd import synthetic
+    monkeypatch.setenv("FOC_RENDER_STREAMS", streams)
+    m = _model(1, 21).eval()
+    o, d = synthetic.make_view_rays(20, 20, 1, 2, seed=8, device="cuda", radius=2.0)      # [2, 400, 3]
+    T = 96
+    user = torch.cuda.Stream()
+    user.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(user), torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        o2, d2 = o * 1.0, d * 1.0                                    # produced on the caller's stream: the side streams must wait for it
+        staged = m.render(o2, d2, staged=True, max_ray_batch=150, num_steps=T, upsample_steps=0, perturb=False, fused=True, bg_color=1.0)
+        image = staged["image"].clone()                              # consumed on the caller's stream right away
+    torch.cuda.current_stream().wait_stream(user)
+    assert staged["densities"].shape == (2, 400, T) and staged["rgbs"].shape == (2, 400, T, 3)
+    for b in range(2):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            ref = m.run(o[b:b + 1], d[b:b + 1], num_steps=T, upsample_steps=0, perturb=False, fused=True, bg_color=1.0)
+        assert torch.equal(image[b], ref["image"][0]) and torch.equal(staged["image"][b], ref["image"][0])
+        assert torch.equal(torch.nan_to_num(staged["depth"][b]), torch.nan_to_num(ref["depth"][0]))
+        assert torch.equal(staged["densities"][b], ref["densities"].view(400, T))
+        assert torch.equal(staged["rgbs"][b], ref["rgbs"])
+
+
 def test_sample_positions_bit_exact_vs_torch():
     """fixed_sample reproduces the reference's z_vals / xyz arithmetic bit for bit (incl. torch.linspace's fill order)."""
     from focnerf_amd.fixedstep import fixed_sample
