@@ -480,6 +480,8 @@ struct GbHeader {                              // lives at the start of the work
     uint32_t chunk_prefix[GE_MAX_LEVELS * GB_MAX_SEGS + 1];
 };
 
+struct GbSizes { uint32_t size[GE_MAX_LEVELS]; };          // rows per level (offsets[l + 1] - offsets[l]), from the host copy of the offsets
+
 template <typename T> struct GbRec;
 template <> struct GbRec<__half> { static constexpr uint32_t bytes = 8; };    // {u32 local row, half2}
 template <> struct GbRec<float> { static constexpr uint32_t bytes = 12; };    // u32 rows[] + float2 vals[]
@@ -543,7 +545,7 @@ __device__ __forceinline__ void gb_corners(const float (&x)[D], uint32_t hashmap
 // lanes a run of lanes with equal cells is summed on the lanes (segmented DPP scan, fp32) and only the run's last lane emits
 // records. The count and the scatter kernel derive the run structure from the same values with the same code, so their record
 // counts agree by construction.
-#define GB_MERGE_MAX_RES 1000u                 // default; levels above this resolution are not merged (and cells < 2^10 per axis are needed for the key)
+#define GB_MERGE_MAX_RES 480u                  // default; levels above this resolution are not merged (hashed ones travel as factored 8-byte records); cells < 2^10 per axis are needed for the key
 template <int CTRL>
 __device__ __forceinline__ uint32_t gb_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 struct GbRun { uint32_t f0, f1, f2, f3; float k0, k1, k2, k3; bool tail; };       // f_k: "do not add from lane - 2^k" at scan step k; k_k = f_k ? 0 : 1
@@ -774,7 +776,7 @@ template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-    bool align_corners, uint32_t interp, bool grad_bl) {
+    bool align_corners, uint32_t interp, bool grad_bl, uint32_t fact_mask, GbSizes sz) {
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
     // a record carries the two corners along x of one (y, z) corner pair: 4 per point, 5 when one pair straddles a segment boundary
     // (two pairs of a point cannot: their rows differ by less than 8192 and not by a multiple of it on a dense level, and a hashed
@@ -803,30 +805,43 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
 #pragma unroll
     for (uint32_t w = 0; w < GW; w++) gnext[w] = L ? gp[w] : 0u;
     // wave 0 keeps the (base, end) pair of the level about to be processed in registers
-    uint32_t nb0 = 0, nb1 = 0;
+    uint32_t nsb = 0, nw0 = 0, nw1 = 0;
     auto fetch_bases = [&](uint32_t level) {
         if (threadIdx.x < GB_MAX_SEGS && level < L) {
             const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
             const uint32_t sb = hdr->base[slot];           // wg_base holds the prefix inside the slot
-            nb0 = sb + wg_base[(uint64_t)slot * n_wg + blockIdx.x];
-            nb1 = sb + (blockIdx.x + 1 < n_wg ? wg_base[(uint64_t)slot * n_wg + blockIdx.x + 1] : hdr->counts[slot]);
+            const uint32_t wi = slot * n_wg + blockIdx.x;      // < 2^26 (gb_check: B * 8 * L < 2^32); a 32-bit offset from the scalar base keeps one register live
+            // loaded values only, no arithmetic: the sums are taken where the next level consumes them, so wave 0 does not wait for these
+            // loads in front of the barrier the other fifteen waves are parked at
+            nsb = sb;
+            nw0 = wg_base[wi];
+            nw1 = *(blockIdx.x + 1 < n_wg ? &wg_base[wi + 1u] : &hdr->counts[slot]);
         }
     };
+    // Wave 0 prepares the segment tables of level l + 1 (cur / pre / gb of the other parity) right AFTER the first barrier of level l,
+    // from bases fetched a level earlier: in front of the barrier it made the other fifteen waves wait for its loads (and, vmcnt being
+    // one in-order counter on gfx950, for the acknowledgement of its copy-out stores). The tables of that parity were last read by the
+    // copy-out of level l - 1, which every thread has left when it passes the barrier.
+    auto setup_tables = [&](uint32_t pbn) {
+        const uint32_t nb0 = nsb + nw0;
+        const uint32_t hc = nw1 - nw0;
+        const uint32_t incl = (uint32_t)wave_incl_sum_i((int)hc, (int)threadIdx.x);
+        pre[pbn][threadIdx.x] = incl - hc;
+        cur[pbn][threadIdx.x] = incl - hc;
+        gb[pbn][threadIdx.x] = nb0 - (incl - hc);
+        if (threadIdx.x == GB_MAX_SEGS - 1) pre[pbn][GB_MAX_SEGS] = incl;
+    };
     fetch_bases(0);
-#pragma unroll
-    for (uint32_t level = 0; level < GE_MAX_LEVELS; level++) {
-        if (level < L) {
+    if (threadIdx.x < GB_MAX_SEGS) { if (L) setup_tables(0u); fetch_bases(1); }
+    // The per-level parameters (scale, resolution, rows of the level) come out of the KERNEL ARGUMENTS with a scalar index: as vector
+    // loads (`offsets[level]` from memory, `lv.scale[level]` with the level in a VGPR) each of them was followed by `s_waitcnt vmcnt(0)`,
+    // which on gfx950 also waits for the gradient prefetch just issued and for every copy-out store of the level before.
+    for (uint32_t level_v = 0; level_v < L; level_v++) {
+        {
+        const uint32_t level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level_v);
         const uint32_t pb = level & 1u;
-        if (threadIdx.x < GB_MAX_SEGS) {
-            const uint32_t hc = nb1 - nb0;
-            const uint32_t incl = (uint32_t)wave_incl_sum_i((int)hc, (int)threadIdx.x);
-            pre[pb][threadIdx.x] = incl - hc;
-            cur[pb][threadIdx.x] = incl - hc;
-            gb[pb][threadIdx.x] = nb0 - (incl - hc);
-            if (threadIdx.x == GB_MAX_SEGS - 1) pre[pb][GB_MAX_SEGS] = incl;
-            fetch_bases(level + 1);
-        }
         foc_lds_barrier();
+        if (threadIdx.x < GB_MAX_SEGS && level + 1u < L) { setup_tables(pb ^ 1u); fetch_bases(level + 2u); }
         float g[2];
         if constexpr (sizeof(T) == 2) {
             g[0] = __half2float(__ushort_as_half((unsigned short)(gnext[0] & 0xFFFFu)));
@@ -839,7 +854,37 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
             for (uint32_t w = 0; w < GW; w++) gnext[w] = gp[(uint64_t)(level + 1) * gstride + w];
         }
         if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
-        {
+        const bool fact = sizeof(T) == 2 && ((fact_mask >> level) & 1u) != 0u;      // kernel-uniform per level (gb_fact_mask)
+        if (fact) {
+            // FACTORED record (unmerged hashed levels, fp16 tables): the two corners along x of a (y, z) pair get (1 - fx) p and fx p of the
+            // SAME product p = w_y w_z g, and on a hashed level their rows differ by x ^ (x + 1) = 2^(jb+1) - 1 (jb = trailing ones of x,
+            // < 13 below resolution 8191) — so the pair travels as 8 bytes {local row 0 (13) | jb (4) | fx (15 bits), half2 p} instead of
+            // 12 {row 0 | row 1, half2 v0, half2 v1}; the reduce rebuilds row 1 and both addends. One-third fewer record bytes written and
+            // read back on the levels where nothing merges, four weights instead of eight, no run scan.
+            uint32_t pg[3]; float pf[3];
+            gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
+            if (inside) {
+                const uint32_t mask = sz.size[level] - 1u;
+                const uint32_t ty0 = pg[1] * 2654435761u, ty1 = ty0 + 2654435761u, tz0 = pg[2] * 805459861u, tz1 = tz0 + 805459861u;
+                const uint32_t jb = (uint32_t)__builtin_ctz(~pg[0]);
+                const uint32_t fxq = min((uint32_t)rintf(pf[0] * 32768.0f), 32767u);
+                const uint32_t meta = (jb << 13) | (fxq << 17);
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t row = (pg[0] ^ ((j & 1) ? ty1 : ty0) ^ ((j >> 1) ? tz1 : tz0)) & mask;
+                    const float w = ((j & 1) ? pf[1] : 1 - pf[1]) * ((j >> 1) ? pf[2] : 1 - pf[2]);
+                    typedef _Float16 gb_h2 __attribute__((ext_vector_type(2)));
+                    const gb_h2 hv = {(_Float16)ge_opaque(w * g[0]), (_Float16)ge_opaque(w * g[1])};
+                    const uint32_t seg = row >> GB_SEG_SHIFT;
+                    const uint32_t pos = atomicAdd(&cur[pb][seg], 1u);
+                    if (pos < NREC) {
+                        s_rows[pos] = (row & (GB_SEG - 1u)) | meta;
+                        s_val[0][pos] = *reinterpret_cast<const uint32_t *>(&hv);
+                        s_val[VW][pos] = seg;
+                    }
+                }
+            }
+        } else {
             const uint32_t resolution = lv.resolution[level];
             uint32_t pg[3]; float pf[3];
             gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
@@ -862,7 +907,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
                 } else { pv0[i] = __float_as_uint(v0); pv1[i] = __float_as_uint(v1); }
             }
             if (emit) {
-                const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+                const uint32_t hashmap_size = sz.size[level];
                 uint32_t rows[8];
                 bool hashed;
                 ge_rows3(pg, hashmap_size, resolution, gridtype, align_corners, rows, &hashed);
@@ -892,6 +937,15 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         const uint32_t total = min(pre[pb][GB_MAX_SEGS], NREC);
         uint32_t *rec_rows = reinterpret_cast<uint32_t *>(recs);                       // [max_recs] rows, then [max_recs] values (16-byte aligned)
         uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
+        if (fact) {
+            if constexpr (sizeof(T) == 2) {
+                for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
+                    const uint32_t at = gb[pb][s_val[1][j] & (GB_MAX_SEGS - 1u)] + j;
+                    if (at >= max_recs) continue;
+                    reinterpret_cast<uint2 *>(rec_vals)[at] = make_uint2(s_rows[j], s_val[0][j]);      // the rows array is not touched on these levels
+                }
+            }
+        } else
         for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
             const uint32_t rw = s_rows[j];
             const uint32_t at = gb[pb][rw >> 26] + j;
@@ -921,7 +975,7 @@ __device__ __forceinline__ unsigned long long gb_half_to_fixed(uint32_t h) {
 #define GB_RTHREADS 1024u
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
-                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L) {
+                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L, uint32_t fact_mask) {
     // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64), one PLANE per channel: with the two channels
     // of a row side by side a wave instruction (one channel of 64 random rows) could only ever touch every other pair of banks —
     // half of the LDS's banks idle, twice the conflict cycles; planes spread a channel's 64 addends over all 64 banks
@@ -957,11 +1011,6 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     if constexpr (sizeof(T) == 2) {
         const uint2 *vv = reinterpret_cast<const uint2 *>(rec_vals);
-        uint32_t cr[UNR], nr[UNR]; uint2 cv[UNR], nv[UNR];
-        uint32_t i0 = lo + threadIdx.x;
-        // records past the chunk's end read as "row 0 += 0": no validity branch in the loop
-#pragma unroll
-        for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i0 + u * GB_RTHREADS; const bool ok = i < hi; cr[u] = ok ? rec_rows[i] : 0u; cv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
         // fp16 addends are exact multiples of 2^-24 below 2^16: as 2^24-scaled 64-bit integers their sum is EXACT (and order
         // independent); ds_add_u64 is also the fastest LDS atomic that can hold it (tools/bench_lds_atomic.hip: 1335 G two-channel records/s on
         // planes, ds_add_f64 600, ds_add_f32 100, ds_pk_add_f16 200). The kernel ran at a third of that rate: its VALU was 59 % busy with the
@@ -993,20 +1042,103 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
             }
             add_fast(row, hv);
         };
-        while (i0 < hi) {
-            const uint32_t i1 = i0 + GB_RTHREADS * UNR;
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = i1 + u * GB_RTHREADS; const bool ok = i < hi; nr[u] = ok ? rec_rows[i] : 0u; nv[u] = ok ? vv[i] : make_uint2(0u, 0u); }
-#pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) {
-                const uint32_t r0 = cr[u] & (GB_SEG - 1u), r1 = (cr[u] >> 13) & (GB_SEG - 1u);
-                const uint32_t nonfinite = (((cv[u].x & 0x7C007C00u) + 0x04000400u) | ((cv[u].y & 0x7C007C00u) + 0x04000400u)) & 0x80008000u;
-                if (__builtin_expect(nonfinite == 0u, 1)) { add_fast(r0, cv[u].x); add_fast(r1, cv[u].y); }
-                else { add_slow(r0, cv[u].x); add_slow(r1, cv[u].y); }
+        // Software pipeline over batches of UNR x 1024 records: the loads of batch k + 1 are issued, then batch k goes through the LDS adds.
+        // The loads of a COMPLETE batch carry no per-lane guard: with `i < hi ? load : 0` every load sat in its own exec-masked branch, the
+        // compiler could no longer count the loads in flight and put `s_waitcnt vmcnt(0)` right behind the prefetch — each iteration
+        // waited out the full latency of the loads it had just issued. Only the last batch of a chunk (partial) takes guarded loads;
+        // its missing records read as "row 0 += 0".
+        constexpr uint32_t BATCH = GB_RTHREADS * UNR;
+        auto pipeline = [&](auto load_full, auto load_tail, auto process) {
+            uint32_t cr[UNR], nr[UNR]; uint2 cv[UNR], nv[UNR];
+            uint32_t base = lo;                                    // workgroup-uniform
+            if (base + BATCH <= hi) load_full(base, cr, cv); else load_tail(base, cr, cv);
+            while (base + 3u * BATCH <= hi) {                      // two more complete batches: ping-pong, no register rotation (a rotation
+                load_full(base + BATCH, nr, nv);                   // is a v_mov of loaded registers, i.e. a wait for the loads just issued)
+                process(cr, cv);
+                load_full(base + 2u * BATCH, cr, cv);
+                process(nr, nv);
+                base += 2u * BATCH;
             }
+            while (base + 2u * BATCH <= hi) {                      // batch k + 1 is complete too
+                load_full(base + BATCH, nr, nv);
+                process(cr, cv);
 #pragma unroll
-            for (uint32_t u = 0; u < UNR; u++) { cr[u] = nr[u]; cv[u] = nv[u]; }
-            i0 = i1;
+                for (uint32_t u = 0; u < UNR; u++) { cr[u] = nr[u]; cv[u] = nv[u]; }
+                base += BATCH;
+            }
+            if (base + BATCH < hi) { load_tail(base + BATCH, nr, nv); process(cr, cv); process(nr, nv); }
+            else if (base < hi) process(cr, cv);
+        };
+        if ((fact_mask >> (slot / GB_MAX_SEGS)) & 1u) {
+            // factored records (k_gbin_scatter_pms): {local row 0 | jb << 13 | fx << 17, half2 p} -> row 1 = row 0 ^ (2^(jb+1) - 1),
+            // addends (p - fx p, fx p) per channel. They are fp32 values, not halves: `fixedf` takes any |f| < 2^17 and drops what lies below
+            // 2^-24, the spacing of the smallest halves — the sum stays order independent.
+            // v_fract_f32 instead of s - floor(s): for a tiny negative s the difference rounds to 1.0 and the fraction word would carry
+            // into H (an addend off by 2^-4); the instruction returns at most 1 - 2^-24
+            auto fixedf = [](float f, uint32_t &wlo, uint32_t &whi) {
+                const float sc = f * 16.0f;
+                const int32_t Hi = (int32_t)floorf(sc);
+                wlo = ((uint32_t)Hi << 20) | (uint32_t)(__builtin_amdgcn_fractf(sc) * 1048576.0f);
+                whi = (uint32_t)(Hi >> 12);
+            };
+            auto add2 = [&](uint32_t row, float a, float b) {
+                uint32_t l0, h0, l1, h1;
+                fixedf(a, l0, h0);
+                fixedf(b, l1, h1);
+                atomicAdd(&acci[row], ((unsigned long long)h0 << 32) | l0);
+                atomicAdd(&acci[GB_SEG + row], ((unsigned long long)h1 << 32) | l1);
+            };
+            pipeline(
+                [&](uint32_t base, uint32_t (&)[UNR], uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) v[u] = vv[base + threadIdx.x + u * GB_RTHREADS];
+                },
+                [&](uint32_t base, uint32_t (&)[UNR], uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = base + threadIdx.x + u * GB_RTHREADS; v[u] = i < hi ? vv[i] : make_uint2(0u, 0u); }
+                },
+                [&](const uint32_t (&)[UNR], const uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) {
+                        const uint32_t w = v[u].x;
+                        const uint32_t r0 = w & (GB_SEG - 1u), r1 = (r0 ^ ((2u << ((w >> 13) & 15u)) - 1u)) & (GB_SEG - 1u);
+                        const float fx = (float)(w >> 17) * (1.0f / 32768.0f);
+                        const uint32_t nonfinite = ((v[u].y & 0x7C007C00u) + 0x04000400u) & 0x80008000u;
+                        if (__builtin_expect(nonfinite == 0u, 1)) {
+                            const __half2 h2 = *reinterpret_cast<const __half2 *>(&v[u].y);
+                            const float p0 = __low2float(h2), p1 = __high2float(h2);
+                            const float a1 = fx * p0, b1 = fx * p1;
+                            add2(r0, p0 - a1, p1 - b1);
+                            add2(r1, a1, b1);
+                        } else {
+                            atomicOr(&s_bad[r0 >> 5], 1u << (r0 & 31u));
+                            atomicOr(&s_bad[r1 >> 5], 1u << (r1 & 31u));
+                        }
+                    }
+                });
+        } else {
+            pipeline(
+                [&](uint32_t base, uint32_t (&r)[UNR], uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) { const uint32_t i = base + threadIdx.x + u * GB_RTHREADS; r[u] = rec_rows[i]; v[u] = vv[i]; }
+                },
+                [&](uint32_t base, uint32_t (&r)[UNR], uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) {
+                        const uint32_t i = base + threadIdx.x + u * GB_RTHREADS;
+                        const bool ok = i < hi;
+                        r[u] = ok ? rec_rows[i] : 0u; v[u] = ok ? vv[i] : make_uint2(0u, 0u);
+                    }
+                },
+                [&](const uint32_t (&r)[UNR], const uint2 (&v)[UNR]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < UNR; u++) {
+                        const uint32_t r0 = r[u] & (GB_SEG - 1u), r1 = (r[u] >> 13) & (GB_SEG - 1u);
+                        const uint32_t nonfinite = (((v[u].x & 0x7C007C00u) + 0x04000400u) | ((v[u].y & 0x7C007C00u) + 0x04000400u)) & 0x80008000u;
+                        if (__builtin_expect(nonfinite == 0u, 1)) { add_fast(r0, v[u].x); add_fast(r1, v[u].y); }
+                        else { add_slow(r0, v[u].x); add_slow(r1, v[u].y); }
+                    }
+                });
         }
     } else {
         const float4 *vv = reinterpret_cast<const float4 *>(rec_vals);
@@ -1361,9 +1493,28 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     return FOC_OK;
 }
 
+// Levels whose two-corner records travel in the factored 8-byte form (k_gbin_scatter_pms): fp16 tables, a hashed level (ge_rows3's
+// decision, in its uint32 arithmetic) with a power-of-two size of at least one segment, above the run-merging threshold.
+// FOC_GB_FACTORED=0 keeps the 12-byte records everywhere (A/B runs).
+static uint32_t gb_fact_mask(uint32_t L, const GeLevels &lv, const int32_t *offsets_host, uint32_t gridtype, bool ac, int dtype) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("FOC_GB_FACTORED"); on = e ? atoi(e) : 1; }
+    if (!on || dtype != FOC_F16 || gridtype != 0u) return 0u;
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < L && l < 32u; l++) {
+        const uint32_t size = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        const uint32_t r1 = ac ? lv.resolution[l] : lv.resolution[l] + 1u;
+        uint32_t stride = 1u;
+        for (int d = 0; d < 3; d++) if (stride <= size) stride *= r1;
+        const bool hashed = stride > size;
+        if (hashed && (size & (size - 1u)) == 0u && size >= GB_SEG && lv.resolution[l] > lv.merge_max_res) m |= 1u << l;
+    }
+    return m;
+}
+
 template <typename T>
 static int gb_run(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, const GeLevels &lv,
-                  uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, bool counted, hipStream_t st) {
+                  uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, bool counted, uint32_t fact_mask, const GbSizes &sz, hipStream_t st) {
     GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
     const uint64_t max_recs = gb_max_recs(B, L);
@@ -1375,10 +1526,10 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         if (rc) return rc;
     }
     hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
-                       interp, bl);
+                       interp, bl, fact_mask, sz);
     FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
     const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;
-    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L);
+    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L, fact_mask);
     FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return FOC_OK;
 }
@@ -1516,8 +1667,11 @@ static int gb_entry(const void *grad, const float *inputs, const int32_t *offset
     ge_make_levels(L, S, H, lv);
     hipStream_t st = (hipStream_t)stream;
     const bool ac = align_corners != 0, bl = grad_is_bl != 0;
-    int rc = dtype == FOC_F32 ? gb_run<float>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, st)
-                              : gb_run<__half>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, st);
+    const uint32_t fact_mask = gb_fact_mask(L, lv, offsets_host, gridtype, ac, dtype);
+    GbSizes sz;
+    for (uint32_t l = 0; l < GE_MAX_LEVELS; l++) sz.size[l] = l < L ? (uint32_t)(offsets_host[l + 1] - offsets_host[l]) : 0u;
+    int rc = dtype == FOC_F32 ? gb_run<float>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, 0u, sz, st)
+                              : gb_run<__half>(grad, inputs, offsets, grad_embeddings, B, L, lv, gridtype, ac, interp, bl, workspace, counted, fact_mask, sz, st);
     if (rc) return rc;
     if (dy_dx && grad_inputs) {
         const uint32_t g = foc_grid_1d((uint64_t)B * 3, 256);
