@@ -106,6 +106,13 @@ __device__ __forceinline__ void ld_head_raw(const _Float16 *__restrict__ hrows, 
     v = *reinterpret_cast<const u32x4 *>(p);
     nxt = h == 0 ? p[4] : 0u;
 }
+// prefetching form: the dword after the lane's 16 bytes is loaded by EVERY lane (upper lane-half: a dword of its own 16 bytes, dropped by
+// the caller when it shifts) so that the load sits in no exec-masked branch
+__device__ __forceinline__ void ld_head_raw_all(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(hrows + row * 16) + 4 * h;
+    v = *reinterpret_cast<const u32x4 *>(p);
+    nxt = p[h == 0 ? 4 : 3];
+}
 __device__ __forceinline__ h8 head_shift(const u32x4 v, uint32_t nxt) {
     const u32x4 r = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16), __builtin_amdgcn_alignbit(v.w, v.z, 16),
                      __builtin_amdgcn_alignbit(nxt, v.w, 16)};
@@ -578,12 +585,14 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
     for (int e = 0; e < 16; e++) FZ[e] = 0.0f;
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16, RW = 32 * NB;
-    constexpr bool planar = IMODE == 1;
-    static_assert(IMODE != 2 || RECOMP, "input mode 2 has no stored-activation form");
+    // IMODE: 0 = [B, in_dim] rows, 1 = planar, 2 = colour-network head (MlpHead) with [B,16] output gradients, 3 = the head with [B,4]
+    // output gradients (hd.out_width == 4) as a compile-time fact: as a runtime branch around the prefetch loads it cost a wait per group
+    constexpr bool planar = IMODE == 1, HEAD = IMODE >= 2, NARROW = IMODE == 3;
+    static_assert(!HEAD || RECOMP, "the head input modes have no stored-activation form");
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const bool with_dx = grad_inputs != nullptr;
-    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx, IMODE == 2);
+    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx, HEAD);
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
     _Float16 *sD = lds + lds_w_halfs;                    // [4][RW][WD]
     _Float16 *sA = sD + 4 * RW * WD;                     // [4][RW][WA]
@@ -606,49 +615,58 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 
     const uint32_t rows_per_group = 4 * RW;
     const uint32_t n_groups = (B + rows_per_group - 1) / rows_per_group;
-    constexpr int KS0M = 4;                              // in_dim <= 64 on this path
-    const uint32_t KS0 = in_dim / 16;
+    constexpr int KS0M = HEAD ? 2 : 4;             // in_dim <= 64 on this path; input mode 2 is the 32-wide colour input by construction
+    const uint32_t KS0 = HEAD ? 2u : in_dim / 16;
     // RECOMP: this wave's grad rows (D_0 tile order) and input rows (layer-0 B operand order) of the group about to be processed
     h8 g_nxt[(RW * 2 + 63) / 64];
     h8 x_nxt[KS0M][NB];
     _Float16 h0_nxt[NB];                                 // input mode 2: the density path's gradient of h[:,0] for this lane's rows
     uint32_t hx_nxt[NB];                                 // input mode 2: the dword after the lane's 16 bytes of its h row
+    // Every prefetch load is UNCONDITIONAL (rows clamped to B - 1, k-chunks to the last existing one, a readable dummy address where a
+    // pointer is null); what must read as zero is zeroed when the registers become "current". With `cond ? load : 0` each load sat in an
+    // exec-masked or uniform branch of its own, the compiler could not count the loads in flight and placed s_waitcnt vmcnt(0) between the
+    // prefetch loads themselves — a full memory latency per group of 128 rows, in a kernel with two waves per SIMD to cover it.
+    static_assert((RW * 2) % 64 == 0, "a wave's grad rows are whole 64-lane passes");
     auto fetch_group = [&](uint32_t grp) {
         const uint64_t r0 = (uint64_t)grp * rows_per_group + wave * RW;
-        if constexpr (IMODE == 2) {
+        if constexpr (HEAD) {
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
-                const uint64_t row = r0 + nb * 32 + c;
-                h0_nxt[nb] = (hd.grad_h0 && row < B) ? hd.grad_h0[row] : (_Float16)0;
+                const uint64_t row = min(r0 + nb * 32 + c, (uint64_t)B - 1);
+                const _Float16 *p = hd.grad_h0 ? hd.grad_h0 + row : grad;
+                h0_nxt[nb] = *p;
             }
         }
 #pragma unroll
-        for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
+        for (uint32_t it = 0; it < (RW * 2) / 64; it++) {
             const uint32_t idx = lane + 64 * it, rr = idx >> 1, cc = (idx & 1) * 8;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < RW * 2 && r0 + rr < B) {
-                if (IMODE == 2 && hd.out_width == 4u) {      // [B,4] output gradients: columns 4..15 are zeros that were never written
-                    if (cc == 0) { const h4 q = *reinterpret_cast<const h4 *>(grad + (r0 + rr) * 4); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
-                } else v = *reinterpret_cast<const h8 *>(grad + (r0 + rr) * 16 + cc);
-            }
-            g_nxt[it] = v;
+            const uint64_t row = min(r0 + rr, (uint64_t)B - 1);
+            if constexpr (NARROW) {                          // [B,4] output gradients: columns 4..15 are zeros that were never written (odd lanes: dropped below)
+                const uint2 q = *reinterpret_cast<const uint2 *>(grad + row * 4);
+                g_nxt[it] = __builtin_bit_cast(h8, (u32x4){q.x, q.y, 0u, 0u});
+            } else g_nxt[it] = *reinterpret_cast<const h8 *>(grad + row * 16 + cc);
         }
 #pragma unroll
         for (int kc = 0; kc < KS0M; kc++)
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
-                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if ((uint32_t)kc < KS0) {
-                    const uint64_t row = min(r0 + nb * 32 + c, (uint64_t)B - 1);
-                    if constexpr (IMODE == 2) {
-                        if (kc == 0) v = ld_head8(inputs, hd, row, 0, h);
-                        else { u32x4 raw; ld_head_raw(inputs, row, h, raw, hx_nxt[nb]); v = __builtin_bit_cast(h8, raw); }   // shifted when it becomes x_cur
-                    } else v = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
-                }
+                const uint32_t kce = min((uint32_t)kc, KS0 - 1u);           // chunks past in_dim repeat the last one; they are never used
+                const uint64_t row = min(r0 + nb * 32 + c, (uint64_t)B - 1);
+                h8 v;
+                if constexpr (HEAD) {
+                    if (kc == 0) v = ld_head8(inputs, hd, row, 0, h);
+                    else { u32x4 raw; ld_head_raw_all(inputs, row, h, raw, hx_nxt[nb]); v = __builtin_bit_cast(h8, raw); }   // shifted when it becomes x_cur
+                } else v = planar ? ld_planar8(inputs, B, row, kce, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kce + 8 * h);
                 x_nxt[kc][nb] = v;
             }
     };
-    if constexpr (RECOMP) { if (blockIdx.x < n_groups) fetch_group(blockIdx.x); }
+    if constexpr (RECOMP) {
+        if (blockIdx.x < n_groups) fetch_group(blockIdx.x);
+        // The first group's rows are waited for HERE, once: the compiler lets these loads land directly in the registers the loop reads
+        // as "current" and then, merging that state over the back edge, waited in EVERY iteration for the oldest of the prefetch loads it
+        // had just issued (s_waitcnt vmcnt(3) behind four loads: one exposed memory latency per group of 128 rows).
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), expcnt / lgkmcnt untouched
+    }
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const uint64_t row0 = (uint64_t)grp * rows_per_group + wave * RW;     // this wave's first row
         f16v acc[MT][NB];
@@ -657,20 +675,25 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
         h8 g_cur[(RW * 2 + 63) / 64];
         h8 x_cur[KS0M][NB];
         _Float16 h0_cur[NB];
-        if constexpr (IMODE == 2) {
+        if constexpr (HEAD) {
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) h0_cur[nb] = h0_nxt[nb];
+            for (int nb = 0; nb < NB; nb++) h0_cur[nb] = (hd.grad_h0 && row0 + nb * 32 + c < B) ? h0_nxt[nb] : (_Float16)0;
         }
         if constexpr (RECOMP) {
 #pragma unroll
-            for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) g_cur[it] = g_nxt[it];
+            for (uint32_t it = 0; it < (RW * 2 + 63) / 64; it++) {
+                const uint32_t idx = lane + 64 * it;
+                const bool live = row0 + (idx >> 1) < B && !(NARROW && (idx & 1u)), live_hi = live && !NARROW;
+                const u32x4 gv = __builtin_bit_cast(u32x4, g_nxt[it]);
+                g_cur[it] = __builtin_bit_cast(h8, (u32x4){live ? gv.x : 0u, live ? gv.y : 0u, live_hi ? gv.z : 0u, live_hi ? gv.w : 0u});
+            }
 #pragma unroll
             for (int kc = 0; kc < KS0M; kc++)
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) x_cur[kc][nb] = x_nxt[kc][nb];
-            if constexpr (IMODE == 2) {
+            if constexpr (HEAD) {
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) x_cur[1][nb] = head_shift(__builtin_bit_cast(u32x4, x_nxt[1][nb]), hx_nxt[nb]);
+                for (int nb = 0; nb < NB; nb++) x_cur[1][nb] = head_shift(__builtin_bit_cast(u32x4, x_nxt[1][nb]), h == 0 ? hx_nxt[nb] : 0u);
             }
             if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
@@ -891,7 +914,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        if constexpr (IMODE == 2) {
+                        if constexpr (HEAD) {
                             // rows 16..31 of the tile = gradient of h columns 0..15 (staged shifted); column 0 comes from the density path
                             const uint64_t row = row0 + nb * 32 + c;
                             if (row < B) {
@@ -1277,7 +1300,10 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
                                  : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, false>))
                        : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0, false>;
-    if constexpr (HIDDEN == 64 && NL <= 3) { if (head) kern = relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>; }
+    if constexpr (HIDDEN == 64 && NL <= 3) {
+        if (head) kern = head->out_width == 4u ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, false>)
+                                               : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>);
+    }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
