@@ -1092,24 +1092,45 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             }
         }
     };
-    for (uint32_t tile = blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += gridDim.x * MLP_WAVES) {
+    // The encoding rows and the directions of tile t + 1 are in flight while tile t goes through its 64 MFMAs: two register sets used in
+    // turn (a rotation `cur = nxt` would be a v_mov of loaded registers, i.e. a wait for the loads just issued, and the kernel has two
+    // waves per SIMD to cover a memory latency). Every prefetch load is unconditional — rows clamped to B - 1, the tile after the last
+    // one repeats the last — so the compiler can count the loads in flight; the loop used to stop twice per tile for a full latency
+    // (planes, then directions behind the sigma store).
+    struct TileIn { h8 b[KS0][NB]; float d[NB][3]; };
+    auto fetch_tile = [&](uint32_t tile, TileIn &t) {
+        const uint64_t row0 = (uint64_t)min(tile, n_tiles - 1u) * 32 * NB;
+#pragma unroll
+        for (int kc = 0; kc < KS0; kc++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
+                t.b[kc][nb] = PLANAR ? ld_planar8(enc, B, row, kc, h) : *reinterpret_cast<const h8 *>(enc + row * IN + 16 * kc + 8 * h);
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+            // row -> direction: dir_div consecutive rows per direction, or (dir_block > 0) the block-interleaved sample order of
+            // csrc/fixedstep.hip (fs_block_row): dir_block rays x dir_div depths per block, the ray index fastest
+            // (32-bit arithmetic: B is a uint32_t, and a 64-bit division is ~150 instructions per lane)
+            const uint32_t r32 = (uint32_t)min(row0 + nb * 32 + c, (uint64_t)B - 1);
+            uint32_t di = r32 / dir_div;
+            if (dir_block) di = min((r32 / (dir_block * dir_div)) * dir_block + r32 % dir_block, n_dirs - 1);
+            const float *dp = dirs + (uint64_t)di * 3;
+            t.d[nb][0] = dp[0]; t.d[nb][1] = dp[1]; t.d[nb][2] = dp[2];
+        }
+    };
+    auto eval_tile = [&](uint32_t tile, const TileIn &t) {
         const uint64_t row0 = (uint64_t)tile * 32 * NB;
         f16v acc[MT][NB];
         h8 bf[KC][NB];
         // ---- sigma net
 #pragma unroll
         for (int kc = 0; kc < KS0; kc++) {
-            h8 b[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++) {
-                const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
-                b[nb] = PLANAR ? ld_planar8(enc, B, row, kc, h) : *reinterpret_cast<const h8 *>(enc + row * IN + 16 * kc + 8 * h);
-            }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[nb], kc == 0 ? FZ : acc[mt][nb]);
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, t.b[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
             }
         }
         hidden_stack(acc, bf, lds, MT * KS0, NLS);
@@ -1126,16 +1147,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
         for (int nb = 0; nb < NB; nb++) {
             geo[nb] = acc_to_frag<false>(o[nb], 0);
             const uint64_t row = row0 + nb * 32 + c;
-            const uint64_t rl = min(row, (uint64_t)B - 1);
             if (h == 0 && row < B && sigma_out) sigma_out[row] = expf((float)geo[nb][0]);
-            // row -> direction: dir_div consecutive rows per direction, or (dir_block > 0) the block-interleaved sample order of
-            // csrc/fixedstep.hip (fs_block_row): dir_block rays x dir_div depths per block, the ray index fastest
-            // (32-bit arithmetic: B is a uint32_t, and a 64-bit division is ~150 instructions per lane)
-            const uint32_t r32 = (uint32_t)rl;
-            uint32_t di = r32 / dir_div;
-            if (dir_block) di = min((r32 / (dir_block * dir_div)) * dir_block + r32 % dir_block, n_dirs - 1);
-            const float *dp = dirs + (uint64_t)di * 3;
-            nf_sh16_half(dp[0], dp[1], dp[2], h, sh[nb]);
+            nf_sh16_half(t.d[nb][0], t.d[nb][1], t.d[nb][2], h, sh[nb]);
         }
         // ---- colour net
 #pragma unroll
@@ -1169,6 +1182,20 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
                 }
             }
         }
+    };
+    const uint32_t stride = gridDim.x * MLP_WAVES;
+    uint32_t tile = blockIdx.x * MLP_WAVES + wave;
+    TileIn ta, tb;
+    if (tile < n_tiles) fetch_tile(tile, ta);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) once, here: see k_mlp_bwd_fused
+    while (tile < n_tiles) {
+        fetch_tile(tile + stride, tb);
+        eval_tile(tile, ta);
+        tile += stride;
+        if (tile >= n_tiles) break;
+        fetch_tile(tile + stride, ta);
+        eval_tile(tile, tb);
+        tile += stride;
     }
 }
 

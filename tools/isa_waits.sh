@@ -10,7 +10,7 @@ D=$(cd "$(dirname "$SRC")" && pwd)
 OUT=/tmp/isa_$(basename "$SRC" .hip).s
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I"$D" -S --cuda-device-only "$@" "$SRC" -o "$OUT" 2>/dev/null
 L=$(grep -n "^$PFX" "$OUT" | head -1 | cut -d: -f1)
-[ -n "$L" ] || { echo "no kernel starting with $PFX; candidates:"; grep -o "^_Z[A-Za-z0-9_]*" "$OUT" | sort -u | head -50; exit 1; }
+[ -n "$L" ] || { echo "no kernel starting with $PFX; candidates:"; grep -o "^_Z[A-Za-z0-9_]*" "$OUT" | sort -u | head -12; exit 1; }
 awk -v s="$L" 'NR>=s' "$OUT" | awk '{print} /s_endpgm/{exit}' > /tmp/isa_kernel.s
 awk -v s="$L" 'NR>=s' "$OUT" | grep -m1 -A40 "\.amdhsa_kernel" | grep "next_free_vgpr\|accum_offset\|private_segment_fixed_size\|group_segment_fixed_size" || true
 echo "instructions: $(grep -c '^\s*[vsd]_\|^\s*global_\|^\s*buffer_\|^\s*scratch_\|^\s*flat_' /tmp/isa_kernel.s)  (listing in /tmp/isa_kernel.s)"
