@@ -1497,8 +1497,8 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
 // decision, in its uint32 arithmetic) with a power-of-two size of at least one segment, above the run-merging threshold.
 // FOC_GB_FACTORED=0 keeps the 12-byte records everywhere (A/B runs).
 static uint32_t gb_fact_mask(uint32_t L, const GeLevels &lv, const int32_t *offsets_host, uint32_t gridtype, bool ac, int dtype) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("FOC_GB_FACTORED"); on = e ? atoi(e) : 1; }
+    const char *e = getenv("FOC_GB_FACTORED");     // read per call (tests compare the two record forms in one process)
+    const int on = e ? atoi(e) : 1;
     if (!on || dtype != FOC_F16 || gridtype != 0u) return 0u;
     uint32_t m = 0;
     for (uint32_t l = 0; l < L && l < 32u; l++) {

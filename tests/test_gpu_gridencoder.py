@@ -569,3 +569,36 @@ def test_encoder_mlp_node_replays_in_a_hip_graph_with_new_data():
             assert torch.equal(ge_s, ge), f"table gradient, round {rounds}"
             scale = gw.abs().max().item()
             assert (gw_s.float() - gw.float()).abs().max().item() <= 2e-3 * scale, f"weight gradient, round {rounds}"
+
+
+def test_factored_records_agree_with_the_two_corner_records(monkeypatch):
+    """Unmerged hashed levels send a pair of corners as 8 bytes {row, jb, fx, half2 p} and the reduce rebuilds (1 - fx) p and fx p
+    (csrc/gridencoder.hip, k_gbin_scatter_pms / k_gbin_reduce). Against the 12-byte form (both addends rounded to half by the scatter):
+    p is rounded once before the split and fx carries 15 bits, so an addend moves by at most ~1 half-ulp; both forms are deterministic,
+    keep the per-level checksum, and agree on which rows receive anything."""
+    D, C, L, H, lh, desired, gridtype, ac, interp = CASES[0]
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, np.float16)
+    B = 6000                                          # 4 B records per level at most: every (level, segment) fits ONE reduce chunk of 32768 records, so
+    x = _points(B, D, 11)                             # each row is rounded to half once (several chunks add their half-rounded partial sums in arrival order)
+    rng = np.random.default_rng(5)
+    grad = (rng.standard_normal((L, B, C)) * 0.25).astype(np.float16)
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    g = torch.from_numpy(grad).cuda()
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("FOC_GB_FACTORED", mode)
+        ge = torch.zeros(int(off[-1]), C, dtype=torch.float16, device="cuda")
+        _be().grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=False)
+        if mode in res:
+            assert torch.equal(res[mode], ge), "the factored form is deterministic"
+        res[mode] = ge
+    a, b = to_np(res["0"]).astype(np.float32), to_np(res["1"]).astype(np.float32)
+    assert not np.array_equal(a, b), "the switch must reach the kernels (the finest levels of this grid are factored)"
+    assert np.array_equal(a != 0, b != 0) or np.abs(a - b)[(a != 0) != (b != 0)].max() < 2.0 ** -14
+    # a row of a fine level receives a handful of addends of magnitude <= 0.25 * |w|: a few half-ulps of the row's value
+    tol = 4 * 2.0 ** -11 * np.maximum(np.abs(a), np.abs(b)) + 4 * 2.0 ** -14
+    assert (np.abs(a - b) <= tol).all(), float((np.abs(a - b) - tol).max())
+    inb = np.all((x >= 0) & (x <= 1), axis=1)
+    for l in range(L):
+        want = grad[l][inb].astype(np.float64).sum(0)
+        np.testing.assert_allclose(b[off[l]:off[l + 1]].astype(np.float64).sum(0), want, atol=0.5)
