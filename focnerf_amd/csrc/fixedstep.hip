@@ -44,6 +44,17 @@ __device__ __forceinline__ float fs_z(const FsGeom &g, uint32_t i, uint32_t T, c
     return z;
 }
 
+// the same value from a noise draw that is already in a register (NOISE = false: no jitter term at all, like fs_z with a null pointer).
+// The tail kernels load both draws a sample needs up front, unconditionally, so that all loads of an iteration are in flight together:
+// behind `if (noise)` / `if (i + 1 < T)` each load was its own round trip (s_waitcnt vmcnt(0) after every one of them).
+template <bool NOISE>
+__device__ __forceinline__ float fs_zu(const FsGeom &g, uint32_t i, uint32_t T, float u) {
+    const float lin = (i < T / 2) ? (g.step * (float)i) : fmaf(-g.step, (float)(T - 1 - i), 1.0f);
+    float z = g.near + g.span * lin;
+    if (NOISE) z = z + (u - 0.5f) * g.sample_dist;
+    return z;
+}
+
 // degree-4 real spherical harmonics (focnerf_amd/shencoder.py), same expressions in fp32
 __device__ __forceinline__ void fs_sh16(float x, float y, float z, float (&o)[16]) {
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
@@ -301,6 +312,7 @@ __global__ void __launch_bounds__(256) k_fs_composite_bwd(const float *__restric
 // ---------------------------------------------------------------- training tail: density head + composite in one pass per direction
 // What k_fs_head_fwd (without the colour-net input) and k_fs_composite_fwd compute, one wave per ray, with the same per-lane
 // accumulation order, so the results are the same bits; the weights are not re-read. c [M,16] fp16 = colour-net output.
+template <bool NOISE>
 __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict__ h, const _Float16 *__restrict__ c, const float *__restrict__ nears,
                                                      const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
                                                      float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
@@ -314,12 +326,16 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
     for (uint32_t base = 0; base < T; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < T;
-        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
-        const float sigma = expf((float)h[s * 16]);                             // trunc_exp forward (activation.py:9)
+        const uint32_t ic = valid ? i : T - 1;
+        const uint64_t s = (uint64_t)n * T + ic;
+        const _Float16 h0 = h[s * 16];
         const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * c_ld);
-        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        float u0 = 0.0f, u1 = 0.0f;
+        if (NOISE) { u0 = noise[s]; u1 = noise[(uint64_t)n * T + min(ic + 1u, T - 1u)]; }
+        const float sigma = expf((float)h0);                                    // trunc_exp forward (activation.py:9)
+        const float z = fs_zu<NOISE>(g, ic, T, u0);
         float delta = g.sample_dist;
-        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        if (i + 1 < T) delta = fs_zu<NOISE>(g, i + 1, T, u1) - z;
         const float alpha = valid ? 1 - expf((-delta * density_scale) * sigma) : 0.0f;
         const float om = valid ? (1 - alpha + 1e-15f) : 1.0f;
         const float P = wave_incl_prod(om, (int)lane);
@@ -353,6 +369,7 @@ __device__ __forceinline__ float fs_opaque(float v) { asm volatile("" : "+v"(v))
 // k_fs_composite_bwd and k_fs_head_bwd (column 0 only) in one pass: grad_image [N,3], grad_ws / grad_depth [N] (may be null)
 // -> grad_c [M,16] fp16 and grad_h0 [M] fp16. The gradient of the weights never leaves the lane. trunc_exp's backward factor
 // exp(clamp(h0, -15, 15)) is taken as clamp(sigma, exp(-15), exp(15)) — the same bits, expf being monotonic — so h is not read.
+template <bool NOISE>
 __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ grad_image, const float *__restrict__ grad_ws, const float *__restrict__ grad_depth,
                                                      const _Float16 *__restrict__ c, const float *__restrict__ sigma_in, const float *__restrict__ trans_in,
                                                      const float *__restrict__ weights, const float *__restrict__ nears, const float *__restrict__ fars,
@@ -371,15 +388,18 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
     for (uint32_t cidx = n_chunks; cidx-- > 0;) {
         const uint32_t i = cidx * 64 + lane;
         const bool valid = i < T;
-        const uint64_t s = (uint64_t)n * T + (valid ? i : T - 1);
+        const uint32_t ic = valid ? i : T - 1;
+        const uint64_t s = (uint64_t)n * T + ic;
         const float sigma = sigma_in[s], Tb = trans_in[s], w = weights[s];
+        const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * c_ld);       // loaded for every sample (used above the weight threshold only)
+        float u0 = 0.0f, u1 = 0.0f;
+        if (NOISE) { u0 = noise[s]; u1 = noise[(uint64_t)n * T + min(ic + 1u, T - 1u)]; }
         // ---- composite backward (k_fs_composite_bwd)
         float gw = -(g0 * b0 + g1 * b1 + g2 * b2);
         h8 o0, o1;
 #pragma unroll
         for (int k = 0; k < 8; k++) { o0[k] = (_Float16)0; o1[k] = (_Float16)0; }
         if (w > thresh) {
-            const uint2 raw = *reinterpret_cast<const uint2 *>(c + s * c_ld);
             const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
             const float y0 = fs_sigmoid_h((float)cc[0]), y1 = fs_sigmoid_h((float)cc[1]), y2 = fs_sigmoid_h((float)cc[2]);
             gw += g0 * y0 + g1 * y1 + g2 * y2;
@@ -390,9 +410,9 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
             else { h8 *dst = reinterpret_cast<h8 *>(grad_c + s * 16); dst[0] = o0; dst[1] = o1; }
         }
         // ---- density head backward (k_fs_head_bwd)
-        const float z = fs_z(g, valid ? i : T - 1, T, noise, s);
+        const float z = fs_zu<NOISE>(g, ic, T, u0);
         float delta = g.sample_dist;
-        if (i + 1 < T) delta = fs_z(g, i + 1, T, noise, s + 1) - z;
+        if (i + 1 < T) delta = fs_zu<NOISE>(g, i + 1, T, u1) - z;
         const float ex = expf((-delta * density_scale) * sigma);
         const float alpha = 1 - ex;
         const float om = 1 - alpha + 1e-15f;
@@ -604,7 +624,8 @@ int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, con
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_forward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(h && c && nears && fars && sigma && trans && weights && weights_sum && depth && image, FOC_E_INVALID, "fixed_tail_forward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_forward: T must be >= 2");
-    hipLaunchKernelGGL(k_fs_tail_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, (const _Float16 *)c, nears, fars, noise,
+    auto kern = noise ? k_fs_tail_fwd<true> : k_fs_tail_fwd<false>;
+    hipLaunchKernelGGL(kern, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, (const _Float16 *)c, nears, fars, noise,
                        bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image, c_width);
     FOC_CHECK_LAUNCH("fixed_tail_forward");
     return FOC_OK;
@@ -618,7 +639,8 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_backward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(grad_image && c && sigma && trans && weights && nears && fars && grad_c && grad_h0, FOC_E_INVALID, "fixed_tail_backward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_backward: T must be >= 2");
-    hipLaunchKernelGGL(k_fs_tail_bwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, grad_image, grad_ws, grad_depth, (const _Float16 *)c, sigma,
+    auto kern = noise ? k_fs_tail_bwd<true> : k_fs_tail_bwd<false>;
+    hipLaunchKernelGGL(kern, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, grad_image, grad_ws, grad_depth, (const _Float16 *)c, sigma,
                        trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0, c_width);
     FOC_CHECK_LAUNCH("fixed_tail_backward");
     return FOC_OK;
