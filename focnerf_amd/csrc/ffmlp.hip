@@ -121,8 +121,8 @@ __device__ __forceinline__ h8 head_shift(const u32x4 v, uint32_t nxt) {
 __device__ __forceinline__ h8 ld_head8(const _Float16 *__restrict__ hrows, const MlpHead &hd, uint64_t row, uint32_t kc, int h) {
     if (kc == 0) return *reinterpret_cast<const h8 *>(hd.ray_sh + (uint64_t)((uint32_t)row / hd.samples_per_ray) * 16 + 8 * h);
     u32x4 v; uint32_t nxt;
-    ld_head_raw(hrows, row, h, v, nxt);
-    return head_shift(v, nxt);
+    ld_head_raw_all(hrows, row, h, v, nxt);
+    return head_shift(v, h == 0 ? nxt : 0u);
 }
 
 // ---------------------------------------------------------------- weight staging
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const uint32_t KS0 = in_dim / 16;
+    const uint32_t KS0 = IMODE == 2 ? 2u : in_dim / 16;
     const uint32_t f_hidden = MT * KS0, f_out = f_hidden + (num_layers - 1) * MT * KC;
     const uint32_t tile_rows = 32 * NB;
     const uint32_t n_tiles = (B + tile_rows - 1) / tile_rows;
@@ -265,13 +265,34 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
                 for (int e = 0; e < 16; e++) acc[mt][nb][e] = 0.0f;
 
         // ---- layer 0: B operand straight from global inputs (natural k order)
+        if constexpr (IMODE == 2) {
+            // head mode (two k-chunks: the ray's SH row, the shifted h row): both requested before the first MFMA and pinned — left alone the
+            // compiler sinks the second chunk's loads below the MFMAs of the first (54 -> 52 us per 2 M rows). The same hoist made the
+            // planar form SLOWER (53 -> 62 us: sixteen dword loads waited for at once instead of overlapping the first chunk's MFMAs).
+            h8 b[2][NB];
+#pragma unroll
+            for (int kc = 0; kc < 2; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) b[kc][nb] = ld_head8(inputs, hd, min(row0 + nb * 32 + c, (uint64_t)B - 1), kc, h);
+#pragma unroll
+            for (int kc = 0; kc < 2; kc++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) asm volatile("" : "+v"(b[kc][nb]));
+#pragma unroll
+            for (int kc = 0; kc < 2; kc++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h8 a = ld_frag(lds, mt * KS0 + kc, lane);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, b[kc][nb], acc[mt][nb]);
+                }
+        } else
         for (uint32_t kc = 0; kc < KS0; kc++) {
             h8 b[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
                 const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
-                if constexpr (IMODE == 2) b[nb] = ld_head8(inputs, hd, row, kc, h);
-                else b[nb] = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
+                b[nb] = planar ? ld_planar8(inputs, B, row, kc, h) : *reinterpret_cast<const h8 *>(inputs + row * in_dim + 16 * kc + 8 * h);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
