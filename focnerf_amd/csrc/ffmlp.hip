@@ -862,6 +862,53 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                 }
             }
             foc_lds_barrier();     // LDS tiles only: the next group's prefetched rows stay in flight, grad_inputs stores are not waited for
+            // ---- input gradients (last stage) BEFORE this stage's weight-gradient MFMAs: they need the delta fragments in registers only, and the
+            // stores then have the whole dW section to be acknowledged — the wait for the prefetched rows at the top of the next group is a
+            // vmcnt(0) (stores behind per-lane guards cannot be counted), which used to sit right behind these stores
+            if (s == NL && with_dx) {
+                for (uint32_t mt0 = 0; mt0 < MT0; mt0++) {
+                    f16v x[NB];
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const h8 a = ld_frag(lds, f_dx + mt0 * KC + kc, lane);
+#pragma unroll
+                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : x[nb]);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        if constexpr (HEAD) {
+                            // rows 16..31 of the tile = gradient of h columns 0..15 (staged shifted); column 0 comes from the density path
+                            const uint64_t row = row0 + nb * 32 + c;
+                            if (row < B) {
+                                h4 lo = {(_Float16)x[nb][8], (_Float16)x[nb][9], (_Float16)x[nb][10], (_Float16)x[nb][11]};
+                                const h4 hi = {(_Float16)x[nb][12], (_Float16)x[nb][13], (_Float16)x[nb][14], (_Float16)x[nb][15]};
+                                if (h == 0) lo[0] = h0_cur[nb];
+                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 4 * h) = lo;
+                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 8 + 4 * h) = hi;
+                            }
+                        } else if constexpr (RECOMP && IMODE == 1) {
+                            // [in_dim/2][B] half2 planes (the encoder's [L,B,C] gradient layout): register quad q = features 32mt0 + 8q + 4h .. +3
+                            const uint64_t row = row0 + nb * 32 + c;
+                            if (row < B) {
+                                uint32_t *gp = reinterpret_cast<uint32_t *>(grad_inputs);
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const uint32_t col = 32 * mt0 + 8 * q + 4 * h;
+                                    if (col < in_dim) {
+                                        const h4 v = {(_Float16)x[nb][4 * q], (_Float16)x[nb][4 * q + 1], (_Float16)x[nb][4 * q + 2], (_Float16)x[nb][4 * q + 3]};
+                                        const u32x2 w = __builtin_bit_cast(u32x2, v);
+                                        gp[(uint64_t)(col / 2) * B + row] = w.x;
+                                        gp[(uint64_t)(col / 2 + 1) * B + row] = w.y;
+                                    }
+                                }
+                            }
+                        } else {
+                            store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
+                        }
+                    }
+                }
+            
+            }
             // ---- dW_s: output tile `wave` (MTo x NTi tiles, at most 4 for HIDDEN, in_dim <= 64)
             {
                 // a stage with 4 output tiles gives every wave one of them over all four waves' rows; one with 2 (the 16-wide output
@@ -924,48 +971,6 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
                     }
-            } else if (with_dx) {
-                for (uint32_t mt0 = 0; mt0 < MT0; mt0++) {
-                    f16v x[NB];
-#pragma unroll
-                    for (int kc = 0; kc < KC; kc++) {
-                        const h8 a = ld_frag(lds, f_dx + mt0 * KC + kc, lane);
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++) x[nb] = mfma16(a, bf[kc][nb], kc == 0 ? FZ : x[nb]);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; nb++) {
-                        if constexpr (HEAD) {
-                            // rows 16..31 of the tile = gradient of h columns 0..15 (staged shifted); column 0 comes from the density path
-                            const uint64_t row = row0 + nb * 32 + c;
-                            if (row < B) {
-                                h4 lo = {(_Float16)x[nb][8], (_Float16)x[nb][9], (_Float16)x[nb][10], (_Float16)x[nb][11]};
-                                const h4 hi = {(_Float16)x[nb][12], (_Float16)x[nb][13], (_Float16)x[nb][14], (_Float16)x[nb][15]};
-                                if (h == 0) lo[0] = h0_cur[nb];
-                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 4 * h) = lo;
-                                *reinterpret_cast<h4 *>(grad_inputs + row * 16 + 8 + 4 * h) = hi;
-                            }
-                        } else if constexpr (RECOMP && IMODE == 1) {
-                            // [in_dim/2][B] half2 planes (the encoder's [L,B,C] gradient layout): register quad q = features 32mt0 + 8q + 4h .. +3
-                            const uint64_t row = row0 + nb * 32 + c;
-                            if (row < B) {
-                                uint32_t *gp = reinterpret_cast<uint32_t *>(grad_inputs);
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const uint32_t col = 32 * mt0 + 8 * q + 4 * h;
-                                    if (col < in_dim) {
-                                        const h4 v = {(_Float16)x[nb][4 * q], (_Float16)x[nb][4 * q + 1], (_Float16)x[nb][4 * q + 2], (_Float16)x[nb][4 * q + 3]};
-                                        const u32x2 w = __builtin_bit_cast(u32x2, v);
-                                        gp[(uint64_t)(col / 2) * B + row] = w.x;
-                                        gp[(uint64_t)(col / 2 + 1) * B + row] = w.y;
-                                    }
-                                }
-                            }
-                        } else {
-                            store_tile<false>(grad_inputs, in_dim, row0 + nb * 32 + c, B, 32 * mt0, in_dim, x[nb], h);
-                        }
-                    }
-                }
             }
             if (!RECOMP && s < NL && relu) {
 #pragma unroll
