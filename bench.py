@@ -515,7 +515,9 @@ def main():
         "data": "synthetic", "step_ms": step_stats,
         "numerics": "fp16 storage, fp32 MFMA accumulation (the reference accumulates in fp16): sample indices / positions bit-exact, hash-grid forward "
                     "bit-exact vs the oracle, MLP outputs within a few fp16 ulps of the reference-literal fp16 accumulation (so sigma = exp(h0) ~1e-3 "
-                    "relative), composites 1e-4 — tolerances stated per test in tests/",
+                    "relative), composites 1e-4; hash-grid gradients: fixed-point (2^-24) sums per 32768-record chunk, the unmerged levels' addends "
+                    "rebuilt from factored records (<= ~1 half-ulp per addend; the reference adds with rounding half2 atomics) — tolerances stated per "
+                    "test in tests/",
         "config": {"workload": "configs[1]: single-object hash-grid(L16,C2,2^19)+ffmlp fp16 NeRF, rays from synthetic 800x800 views, "
                                "fixed-step renderer num_steps=512", "rays_per_step": NUM_RAYS, "samples_per_step": samples_per_step,
                    "objects": world, "parallelism": f"one object per GPU x{world}", "optimizer": "Adam(fused) inside the timed step",
