@@ -616,11 +616,19 @@ __device__ __forceinline__ void gb_run_sum16(float (&v)[16], const GbRun &run) {
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = gb_run_sum(v[i], run);
 #else
+    // a scan step in which no lane of the wave adds anything is skipped (f_k set everywhere: every run is shorter than 2^k + 1 lanes) —
+    // from resolution ~150 up runs of more than four samples are rare, and a step is 16 instructions; f_{k+1} clear implies f_k clear
     float k;
-    k = run.k0; GB_FMAC16("row_shr:1");
-    k = run.k1; GB_FMAC16("row_shr:2");
-    k = run.k2; GB_FMAC16("row_shr:4");
-    k = run.k3; GB_FMAC16("row_shr:8");
+    if (__builtin_amdgcn_ballot_w64(run.f0 == 0u) != 0ull) {
+        k = run.k0; GB_FMAC16("row_shr:1");
+        if (__builtin_amdgcn_ballot_w64(run.f1 == 0u) != 0ull) {
+            k = run.k1; GB_FMAC16("row_shr:2");
+            if (__builtin_amdgcn_ballot_w64(run.f2 == 0u) != 0ull) {
+                k = run.k2; GB_FMAC16("row_shr:4");
+                if (__builtin_amdgcn_ballot_w64(run.f3 == 0u) != 0ull) { k = run.k3; GB_FMAC16("row_shr:8"); }
+            }
+        }
+    }
 #endif
 }
 
