@@ -800,18 +800,37 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
     float x[3] = {0.f, 0.f, 0.f};
     const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
-    // gradient of this point, one level at a time: fp16 -> one dword (half2) per level, fp32 -> two. The value of level l + 1 is fetched
-    // while level l is processed ([L,B,C] planes, the reference's layout, gridencoder.cu:283: a coalesced dword per lane; [B, L*C] rows:
-    // the lane's own 64-byte row, one sector). Holding all L values in registers spilled them to scratch at the 64-register budget of two
-    // workgroups per CU: 128 B per point written and read back through the memory system, 0.27 GB per 2 M points.
+    // Gradient of the tile, one level at a time (fp16 -> one dword per point, fp32 -> two), through LDS: WAVE 0 requests the 1024 points'
+    // values of level l + 1 with LDS-direct loads (global_load_lds_dword: no register destination; 16 x 64 lanes, coalesced on the
+    // [L,B,C] planes of gridencoder.cu:283, one sector per lane on [B, L*C] rows) behind the first barrier of level l; everybody reads its
+    // value after the first barrier of level l + 1. Wave 0 issues every LOAD of the kernel (these and the segment bases) and takes no
+    // part in the copy-out, the other fifteen waves issue nothing but the copy-out STORES — so no wave ever waits for a store:
+    // vmcnt is one in-order counter for loads and stores, and with the per-thread prefetch register the kernel had before, each wave's
+    // wait for its gradient at the top of a level was a wait for every record it had stored in the level before (timing builds: 292 us,
+    // 206 us without the stores — they did not overlap the next level's work at all).
     constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
-    const uint32_t bq = b < B ? b : 0u;
-    const uint32_t *gp = grad_bl ? reinterpret_cast<const uint32_t *>(grad) + (uint64_t)bq * L * GW
-                                 : reinterpret_cast<const uint32_t *>(grad) + (uint64_t)bq * GW;
-    const uint64_t gstride = grad_bl ? (uint64_t)GW : (uint64_t)B * GW;
-    uint32_t gnext[GW];
+    __shared__ uint32_t s_grad[2][GW][GB_PM_TILE];
+    auto fetch_grad = [&](uint32_t level) {                 // wave 0 only
+        if (level < L) {
+            const uint32_t *gbase = reinterpret_cast<const uint32_t *>(grad);
+#pragma unroll 4
+            for (uint32_t k = 0; k < GB_PM_TILE / 64u; k++) {
+                const uint32_t pt = blockIdx.x * GB_PM_TILE + k * 64u + threadIdx.x;
+                const uint32_t pq = pt < B ? pt : 0u;
+                const uint32_t *src = grad_bl ? gbase + ((uint64_t)pq * L + level) * GW : gbase + ((uint64_t)level * B + pq) * GW;
+                // as inline asm: with the builtin, hipcc 7.2 puts `s_waitcnt vmcnt(0)` in front of EVERY later LDS access of every wave (it cannot
+                // tell the LDS-DMA's destination from the other arrays) — the stores the other waves have in flight would be waited for again
 #pragma unroll
-    for (uint32_t w = 0; w < GW; w++) gnext[w] = L ? gp[w] : 0u;
+                for (uint32_t w = 0; w < GW; w++) {
+                    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&s_grad[level & 1u][w][k * 64u]);
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src + w), "s"(dst) : "memory");
+                }
+            }
+        }
+    };
     // wave 0 keeps the (base, end) pair of the level about to be processed in registers
     uint32_t nsb = 0, nw0 = 0, nw1 = 0;
     auto fetch_bases = [&](uint32_t level) {
@@ -840,7 +859,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         if (threadIdx.x == GB_MAX_SEGS - 1) pre[pbn][GB_MAX_SEGS] = incl;
     };
     fetch_bases(0);
-    if (threadIdx.x < GB_MAX_SEGS) { if (L) setup_tables(0u); fetch_bases(1); }
+    if (threadIdx.x < GB_MAX_SEGS) { if (L) setup_tables(0u); fetch_bases(1); fetch_grad(0); }
     // The per-level parameters (scale, resolution, rows of the level) come out of the KERNEL ARGUMENTS with a scalar index: as vector
     // loads (`offsets[level]` from memory, `lv.scale[level]` with the level in a VGPR) each of them was followed by `s_waitcnt vmcnt(0)`,
     // which on gfx950 also waits for the gradient prefetch just issued and for every copy-out store of the level before.
@@ -848,18 +867,16 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         {
         const uint32_t level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level_v);
         const uint32_t pb = level & 1u;
+        if (threadIdx.x < GB_MAX_SEGS) __builtin_amdgcn_s_waitcnt(0x0F70);       // wave 0: this level's gradients (and bases) have landed: vmcnt(0), issued a level ago
         foc_lds_barrier();
-        if (threadIdx.x < GB_MAX_SEGS && level + 1u < L) { setup_tables(pb ^ 1u); fetch_bases(level + 2u); }
+        if (threadIdx.x < GB_MAX_SEGS && level + 1u < L) { setup_tables(pb ^ 1u); fetch_bases(level + 2u); fetch_grad(level + 1u); }
         float g[2];
         if constexpr (sizeof(T) == 2) {
-            g[0] = __half2float(__ushort_as_half((unsigned short)(gnext[0] & 0xFFFFu)));
-            g[1] = __half2float(__ushort_as_half((unsigned short)(gnext[0] >> 16)));
+            const uint32_t gw = s_grad[pb][0][threadIdx.x];
+            g[0] = __half2float(__ushort_as_half((unsigned short)(gw & 0xFFFFu)));
+            g[1] = __half2float(__ushort_as_half((unsigned short)(gw >> 16)));
         } else {
-            g[0] = __uint_as_float(gnext[0]); g[1] = __uint_as_float(gnext[GW - 1]);
-        }
-        if (level + 1 < L) {
-#pragma unroll
-            for (uint32_t w = 0; w < GW; w++) gnext[w] = gp[(uint64_t)(level + 1) * gstride + w];
+            g[0] = __uint_as_float(s_grad[pb][0][threadIdx.x]); g[1] = __uint_as_float(s_grad[pb][GW - 1][threadIdx.x]);
         }
         if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
         const bool fact = sizeof(T) == 2 && ((fact_mask >> level) & 1u) != 0u;      // kernel-uniform per level (gb_fact_mask)
@@ -947,14 +964,14 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         uint32_t *rec_vals = rec_rows + ((max_recs + 3) & ~(uint64_t)3);
         if (fact) {
             if constexpr (sizeof(T) == 2) {
-                for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
+                for (uint32_t j = threadIdx.x - 64u; j < total; j += GB_PMS_WG - 64u) {      // wave 0 (j wraps past total) copies nothing
                     const uint32_t at = gb[pb][s_val[1][j] & (GB_MAX_SEGS - 1u)] + j;
                     if (at >= max_recs) continue;
                     reinterpret_cast<uint2 *>(rec_vals)[at] = make_uint2(s_rows[j], s_val[0][j]);      // the rows array is not touched on these levels
                 }
             }
         } else
-        for (uint32_t j = threadIdx.x; j < total; j += GB_PMS_WG) {
+        for (uint32_t j = threadIdx.x - 64u; j < total; j += GB_PMS_WG - 64u) {
             const uint32_t rw = s_rows[j];
             const uint32_t at = gb[pb][rw >> 26] + j;
             if (at >= max_recs) continue;                  // cannot happen when count and scatter agree; keeps a logic slip from faulting
