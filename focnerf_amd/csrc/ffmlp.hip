@@ -1046,7 +1046,11 @@ __device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h
     for (int j = 0; j < 8; j++) out[j] = (_Float16)o[j];
 }
 
-template <int NLS, int NLC, bool PLANAR, bool RELU_CT>
+// BLK: the rows stand in 64-ray blocks (dir_block == 64 == the tile's rows, csrc/fixedstep.hip fs_block_row) — a tile is 64 rays at one
+// depth, tile / dir_div is its block, and a wave takes CONSECUTIVE tiles: the SH values of its lanes' rays change once per block, so they
+// are computed when the block changes and kept in registers (per tile they were 60 of the kernel's ~550 VALU instructions, plus the loads
+// of the directions and the division that finds them).
+template <int NLS, int NLC, bool PLANAR, bool RELU_CT, bool BLK>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
                                                           uint32_t dir_block, uint32_t n_dirs, const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
                                                           int relu_rt, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
@@ -1123,7 +1127,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
     // waves per SIMD to cover a memory latency). Every prefetch load is unconditional — rows clamped to B - 1, the tile after the last
     // one repeats the last — so the compiler can count the loads in flight; the loop used to stop twice per tile for a full latency
     // (planes, then directions behind the sigma store).
-    struct TileIn { h8 b[KS0][NB]; float d[NB][3]; };
+    struct TileIn { h8 b[KS0][NB]; float d[BLK ? 1 : NB][3]; };
     auto fetch_tile = [&](uint32_t tile, TileIn &t) {
         const uint64_t row0 = (uint64_t)min(tile, n_tiles - 1u) * 32 * NB;
 #pragma unroll
@@ -1133,6 +1137,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
                 const uint64_t row = min(row0 + nb * 32 + c, (uint64_t)B - 1);
                 t.b[kc][nb] = PLANAR ? ld_planar8(enc, B, row, kc, h) : *reinterpret_cast<const h8 *>(enc + row * IN + 16 * kc + 8 * h);
             }
+        if constexpr (!BLK)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
             // row -> direction: dir_div consecutive rows per direction, or (dir_block > 0) the block-interleaved sample order of
@@ -1145,6 +1150,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             t.d[nb][0] = dp[0]; t.d[nb][1] = dp[1]; t.d[nb][2] = dp[2];
         }
     };
+    uint32_t sh_blk = 0xFFFFFFFFu;                     // BLK: the block whose SH values sh_keep holds
+    h8 sh_keep[NB];
     auto eval_tile = [&](uint32_t tile, const TileIn &t) {
         const uint64_t row0 = (uint64_t)tile * 32 * NB;
         f16v acc[MT][NB];
@@ -1174,7 +1181,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             geo[nb] = acc_to_frag<false>(o[nb], 0);
             const uint64_t row = row0 + nb * 32 + c;
             if (h == 0 && row < B && sigma_out) sigma_out[row] = expf((float)geo[nb][0]);
-            nf_sh16_half(t.d[nb][0], t.d[nb][1], t.d[nb][2], h, sh[nb]);
+            if constexpr (BLK) {
+                const uint32_t blk = tile / dir_div;                          // wave-uniform
+                if (blk != sh_blk) {
+                    const uint32_t di = min(blk * dir_block + (uint32_t)(nb * 32 + c), n_dirs - 1u);
+                    const float *dp = dirs + (uint64_t)di * 3;
+                    nf_sh16_half(dp[0], dp[1], dp[2], h, sh_keep[nb]);
+                    if (nb == NB - 1) sh_blk = blk;
+                }
+                sh[nb] = sh_keep[nb];
+            } else nf_sh16_half(t.d[nb][0], t.d[nb][1], t.d[nb][2], h, sh[nb]);
         }
         // ---- colour net
 #pragma unroll
@@ -1209,16 +1225,20 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             }
         }
     };
-    const uint32_t stride = gridDim.x * MLP_WAVES;
-    uint32_t tile = blockIdx.x * MLP_WAVES + wave;
+    // tiles of a wave: every (waves of the grid)-th one, or in BLK mode a run of consecutive ones
+    const uint32_t n_waves = gridDim.x * MLP_WAVES, my_wave = blockIdx.x * MLP_WAVES + wave;
+    const uint32_t per = BLK ? (n_tiles + n_waves - 1u) / n_waves : 1u;
+    const uint32_t stride = BLK ? 1u : n_waves;
+    uint32_t tile = BLK ? my_wave * per : my_wave;
+    const uint32_t t_end = BLK ? min(n_tiles, tile + per) : n_tiles;
     TileIn ta, tb;
-    if (tile < n_tiles) fetch_tile(tile, ta);
+    if (tile < t_end) fetch_tile(tile, ta);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) once, here: see k_mlp_bwd_fused
-    while (tile < n_tiles) {
+    while (tile < t_end) {
         fetch_tile(tile + stride, tb);
         eval_tile(tile, ta);
         tile += stride;
-        if (tile >= n_tiles) break;
+        if (tile >= t_end) break;
         fetch_tile(tile + stride, ta);
         eval_tile(tile, tb);
         tile += stride;
@@ -1432,8 +1452,10 @@ template <int NLS, int NLC>
 static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
                              float *sigma, float *rgb, hipStream_t st) {
     const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024;
-    auto kern = planar ? (relu ? k_nerf_infer<NLS, NLC, true, true> : k_nerf_infer<NLS, NLC, true, false>)
-                       : (relu ? k_nerf_infer<NLS, NLC, false, true> : k_nerf_infer<NLS, NLC, false, false>);
+    const bool blk = planar && dir_block == 64u;     // the staged render's sample order (fixedstep.hip FS_RAY_BLOCK)
+    auto kern = planar ? (blk ? (relu ? k_nerf_infer<NLS, NLC, true, true, true> : k_nerf_infer<NLS, NLC, true, false, true>)
+                              : (relu ? k_nerf_infer<NLS, NLC, true, true, false> : k_nerf_infer<NLS, NLC, true, false, false>))
+                       : (relu ? k_nerf_infer<NLS, NLC, false, true, false> : k_nerf_infer<NLS, NLC, false, false, false>);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     uint32_t grid = foc_div_up(foc_div_up(B, 64), MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);
