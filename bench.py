@@ -182,6 +182,39 @@ def build_model(bound, device, cuda_ray=False, seed=0):
     return model
 
 
+def build_foc_model(bound, device, seed=0):
+    """FOC's object-conditioned network (nerf/network_tcnn.py:451-681 topology: 48-wide colour input [SH16 | geo15 | object feature 16 | 0]) —
+    the network main_nerf.py:108 and COMBINED.py:84 actually construct."""
+    from focnerf_amd.network_foc import NeRFNetwork
+    torch.manual_seed(seed)
+    return NeRFNetwork(bound=bound).to(device)
+
+
+def foc_yolo_details(device, n_rays, seed):
+    """Synthetic `yolo_details` = (object mask of the batch's rays [1,N] bool, bbox (unused on the path), raw object feature [144] fp32) —
+    what nerf/provider.py hands the trainer per image (utils.py:818-823)."""
+    g = torch.Generator().manual_seed(seed)
+    mask = (torch.rand(1, n_rays, generator=g) < 0.7).to(device)
+    feat = torch.randn(144, generator=g).to(device)          # resident like the rays (the reference's --preload): no H2D copy inside a step
+    return (mask, None, feat)
+
+
+def foc_train_step(model, opt, scaler, rays_o, rays_d, target, yolo, sched=None):
+    """nerf/utils.py:818-902 (train_step of the FOC trainer): render with yolo_details, MSE + 1e-8 * outside-mask density criterion."""
+    opt.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = model.render(rays_o, rays_d, yolo, staged=False, num_steps=NUM_STEPS, upsample_steps=0, perturb=True, bg_color=None, fused=True)
+        loss = torch.nn.functional.mse_loss(out["image"], target)
+        if out.get("criterion_outside_mask") is not None:
+            loss = loss + 1e-8 * out["criterion_outside_mask"]
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    if sched is not None:
+        sched.step()
+    return loss
+
+
 def make_training_rays(device, bound, n_views, seed):
     from focnerf_amd import synthetic
     g = torch.Generator().manual_seed(seed)
@@ -600,6 +633,44 @@ def main():
             result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
                                             "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
 
+            # ---- the same two measurements on FOC's object-conditioned network (network_tcnn.py topology, 48-wide colour input)
+            progress("FOC object-conditioned network legs")
+            try:
+                mf = build_foc_model(bound, device, seed=rank).train()
+                optf = torch.optim.Adam(mf.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+                scf = torch.amp.GradScaler("cuda")
+                yolo = foc_yolo_details(device, NUM_RAYS, 7 + rank)
+                for i in range(max(args.warmup, 10)):
+                    foc_train_step(mf, optf, scf, *batches[i % len(batches)], yolo)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    foc_train_step(mf, optf, scf, *batches[(args.warmup + i) % len(batches)], yolo)
+                barrier()
+                elf = max_over_ranks(time.perf_counter() - t0)
+                foc = {"network": "focnerf_amd.network_foc.NeRFNetwork: hash grid 32 -> 64 -> 64 -> 16; colour [SH16 | geo15 | encoded object feature 16 | 0] = 48 -> 64 -> 64 -> 3; "
+                                  "object-feature encoder 144 -> 16 -> 16 (nerf/network_tcnn.py:451-681)",
+                       "train": {"metric": "train_samples_per_sec", "value": world * samples_per_step * args.steps / elf, "unit": "samples/s",
+                                 "ms_per_step": 1000.0 * elf / args.steps, "vs_plain_topology": (world * samples_per_step * args.steps / elf) / value,
+                                 "path": "same step as the headline with yolo_details: fused tail with the object feature, outside-mask criterion, Adam over 5 groups"}}
+                mf.eval()
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                    mf.render(rays_o, rays_d, yolo, return_fields=False, **rkw)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(args.render_views):
+                        mf.render(*view_rays[i % len(view_rays)], yolo, return_fields=False, **rkw)
+                    barrier()
+                relo = max_over_ranks(time.perf_counter() - t0)
+                foc["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / relo, "unit": "rays/s",
+                                 "s_per_view": relo / args.render_views, "vs_plain_topology": (world * VIEW * VIEW * args.render_views / relo) / result["render"]["value"],
+                                 "path": "fixed-step run() with yolo_details, whole-field kernel with the object feature"}
+                result["foc_network"] = foc
+                del mf, optf
+            except Exception as e:
+                import traceback
+                result["foc_network"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
+
             # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
             m2 = build_model(2, device, cuda_ray=True, seed=rank).train()
             opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
@@ -681,19 +752,24 @@ def main():
             from focnerf_amd.fixedstep import render_field4
             vo, vd = rays_o[0].contiguous(), rays_d[0].contiguous()
             vn, vf = rm.near_far_from_aabb(vo, vd, model.aabb_infer, model.min_near)
+            # the objects COMBINED.py loads are network_tcnn networks (COMBINED.py:84): one FOC object-conditioned network per rank, each
+            # with its own object feature (gather_obj_feats, utils.py:177-187)
+            obj_model = build_foc_model(bound, device, seed=rank).eval()
+            obj_yolo = foc_yolo_details(device, 1, 50 + rank)
 
             def my_object(lo, hi, out):
-                return render_field4(model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, out=out)
+                return render_field4(obj_model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=obj_yolo, out=out)
             with torch.no_grad(), half_cache_scope():
                 result["combined_render"] = combined_render_leg(rank, world, device, {"nears": vn, "fars": vf}, args.combined_views, my_object, barrier,
                                                                 max_over_ranks)
+            result["combined_render"]["objects_network"] = "focnerf_amd.network_foc.NeRFNetwork (object-conditioned, 48-wide colour input), one per rank"
             if world == 1:
                 # the single-GPU form of the same job: K = 4 objects RESIDENT on one device (COMBINED.py reloads a checkpoint per object per view)
-                others = [build_model(bound, device, cuda_ray=False, seed=100 + k).eval() for k in range(3)]
-                objs = [model] + others
+                objs = [obj_model] + [build_foc_model(bound, device, seed=100 + k).eval() for k in range(3)]
+                yolos = [obj_yolo] + [foc_yolo_details(device, 1, 60 + k) for k in range(3)]
                 from focnerf_amd.combine import ObjectCombiner
                 comb1 = ObjectCombiner(rank=0, world_size=1)
-                fns = [(lambda lo, hi, out, m=m: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, out=out)) for m in objs]
+                fns = [(lambda lo, hi, out, m=m, y=y: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=y, out=out)) for m, y in zip(objs, yolos)]
                 with torch.no_grad(), half_cache_scope():
                     comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
                     barrier()

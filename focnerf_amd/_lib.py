@@ -78,12 +78,12 @@ SIGNATURES = {
     "foc_fixed_field_pack": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_composite_fixed_steps": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_fixed_sample": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, u32, c_vp]),
-    "foc_fixed_tail_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
-    "foc_fixed_tail_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, u32, c_vp]),
+    "foc_fixed_tail_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp]),
+    "foc_fixed_tail_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, u32, c_vp, c_vp]),
     "foc_fixed_head_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_fixed_head_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, u32, c_vp]),
-    "foc_color_head_forward": (i32, [c_vp, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, u32, c_vp]),
-    "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u32, c_vp]),
+    "foc_color_head_forward": (i32, [c_vp, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, u32, c_vp, c_vp]),
+    "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_vp]),
     "foc_fixed_composite_forward": (i32, [c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp]),
     "foc_fixed_composite_backward": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_sample_head_forward": (i32, [c_vp, c_vp, u64, c_vp, c_vp, c_vp, u32, c_vp]),
@@ -92,7 +92,7 @@ SIGNATURES = {
     "foc_rgb_head_forward": (i32, [c_vp, u64, c_vp, c_vp]),
     "foc_rgb_head_backward": (i32, [c_vp, c_vp, u64, c_vp, c_vp]),
     "foc_fixed_render_inference": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp]),
-    "foc_nerf_field_inference": (i32, [c_vp, i32, c_vp, u32, u32, u32, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
+    "foc_nerf_field_inference": (i32, [c_vp, i32, c_vp, u32, u32, u32, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, c_vp]),
     "foc_mark_untrained_grid": (i32, [c_vp, u32, f32, f32, f32, f32, f32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_grid_cells_xyz": (i32, [u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_grid_update_sample_workspace_bytes": (u64, [u32, u32]),

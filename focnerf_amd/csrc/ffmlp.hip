@@ -99,7 +99,34 @@ struct MlpHead {
     const _Float16 *grad_h0;       // backward: [B], gradient of h[:,0] (the density path), merged into grad_h column 0
     uint32_t samples_per_ray;
     uint32_t out_width;            // 16: [B,16] outputs / output gradients; 4: only columns 0..3 exist in memory ([B,4]: rgb logits + 1 pad)
+    // FOC's object-conditioned colour network (nerf/network_tcnn.py:611-640): the input row is [SH16 | h[1:16] | obj 16 | 0] = 48 wide, and
+    // the encoded object feature `obj` [16] is ONE vector for every sample of the launch. W0[:, 31:47] . obj is therefore a constant per
+    // neuron: it enters as the initial value of the layer-0 accumulators (obj_bias in LDS) and the k-chunks stay the two of the 32-wide
+    // form. Backward: column 31 of the layer-0 input tile is set to 1, so the weight-gradient MFMAs deliver the column sum of delta_0 in
+    // dW0[:, 31]; dW0[:, 31:47] = colsum (x) obj and grad_obj = W0[:, 31:47]^T colsum follow in the finalize kernel. W0 rows are 48 wide.
+    const _Float16 *obj;           // [16] or null
 };
+#define HEAD_OBJ_LD 48u
+__device__ __forceinline__ uint32_t head_ld0(const MlpHead &hd) { return hd.obj ? HEAD_OBJ_LD : 32u; }
+
+// obj_bias[mt][h][reg] (fp32, accumulator-register order of acc_row) = sum_j W0[n][31 + j] * obj[j], n = 32 mt + acc_row(reg, h):
+// 64 threads, sequential fmaf in j order. `W0` has HEAD_OBJ_LD-wide rows.
+__device__ __forceinline__ void stage_obj_bias(const _Float16 *__restrict__ W0, const _Float16 *__restrict__ obj, float *bias, uint32_t hidden) {
+    if (threadIdx.x < hidden) {
+        const uint32_t n = threadIdx.x, r = n & 31u, mt = n >> 5;
+        const uint32_t h = (r >> 2) & 1u, reg = (r & 3u) + 4u * (r >> 3);
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) a = fmaf((float)W0[(size_t)n * HEAD_OBJ_LD + 31 + j], (float)obj[j], a);
+        bias[(mt * 2 + h) * 16 + reg] = a;
+    }
+}
+__device__ __forceinline__ f16v ld_obj_bias(const float *bias, int mt, int h) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *p = reinterpret_cast<const f4 *>(bias + (mt * 2 + h) * 16);
+    const f4 a = p[0], b = p[1], c = p[2], d = p[3];
+    return f16v{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+}
 // the loads and the shift are separate so that a prefetching caller can keep the raw dwords in flight
 __device__ __forceinline__ void ld_head_raw(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
     const uint32_t *p = reinterpret_cast<const uint32_t *>(hrows + row * 16) + 4 * h;
@@ -131,12 +158,15 @@ __device__ __forceinline__ h8 ld_head8(const _Float16 *__restrict__ hrows, const
 //   hidden l>=1  : Wl[32*mt + r][chain_k(kc, h, j)]
 //   output layer : Wout[r][chain_k(kc, h, j)]  for r < 16, else 0
 // Fragment order: layer0 [mt][kc0] | hidden layers [l][mt][kc] | out [kc].
+// ld0 = 0: W0 rows are in_dim wide and all in_dim / 16 k-chunks are staged; ld0 > in_dim (head with an object feature): rows are ld0 wide,
+// the first in_dim / 16 chunks are staged
 template <int HIDDEN>
-__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_out = true) {
+__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_out = true, uint32_t ld0 = 0) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const uint32_t KS0 = in_dim / 16;
+    if (!ld0) ld0 = in_dim;
     const uint32_t n0 = MT * KS0, nh = (num_layers - 1) * MT * KC, total = n0 + nh + (with_out ? KC : 0);
-    const _Float16 *Wh = W + (size_t)HIDDEN * in_dim;
+    const _Float16 *Wh = W + (size_t)HIDDEN * ld0;
     const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
     for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
         const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
@@ -145,7 +175,7 @@ __device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds,
         for (int j = 0; j < 8; j++) v[j] = (_Float16)0;
         if (f < n0) {
             const uint32_t mt = f / KS0, kc = f % KS0, row = 32 * mt + r;
-            if (row < HIDDEN) v = *reinterpret_cast<const h8 *>(W + (size_t)row * in_dim + 16 * kc + 8 * h);
+            if (row < HIDDEN) v = *reinterpret_cast<const h8 *>(W + (size_t)row * ld0 + 16 * kc + 8 * h);
         } else if (f < n0 + nh) {
             const uint32_t g = f - n0, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, row = 32 * mt + r;
             if (row < HIDDEN) {
@@ -173,11 +203,13 @@ __device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds,
 //   dX          [mt0][kc]   : W0[chain_k(kc,h,j)][32*mt0 + r]  (i < in_dim, else 0)
 // Fragment order: out [mt] | hidden [l][mt][kc] | dX [mt0][kc].
 template <int HIDDEN>
-__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx, bool head = false) {
+__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx, bool head = false,
+                                  uint32_t ld0 = 0) {
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     const uint32_t MT0 = (in_dim + 31) / 32;
+    if (!ld0) ld0 = in_dim;
     const uint32_t no = MT, nh = (num_layers - 1) * MT * KC, nx = with_dx ? MT0 * KC : 0, total = no + nh + nx;
-    const _Float16 *Wh = W + (size_t)HIDDEN * in_dim;
+    const _Float16 *Wh = W + (size_t)HIDDEN * ld0;
     const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
     for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
         const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
@@ -202,11 +234,11 @@ __device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds,
                 // input mode 2: result row 16 + k is the gradient of h column k = input column 15 + k (k = 1..15); rows 0..16 are not used
                 if (i >= 17 && i < 32) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * in_dim + (i - 1)];
+                    for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * ld0 + (i - 1)];
                 }
             } else if (i < in_dim) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * in_dim + i];
+                for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * ld0 + i];
             }
         }
         *reinterpret_cast<h8 *>(lds + (size_t)f * 512 + lane * 8) = v;
@@ -244,13 +276,17 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     constexpr bool planar = IMODE == 1;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
+    const uint32_t KS0 = IMODE == 2 ? 2u : in_dim / 16;
+    const uint32_t f_hidden = MT * KS0, f_out = f_hidden + (num_layers - 1) * MT * KC;
+    const float *obj_bias = reinterpret_cast<const float *>(lds + (size_t)(f_out + KC) * 512);      // head mode with an object feature only
+    if constexpr (IMODE == 2) {
+        stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers, true, head_ld0(hd));
+        if (hd.obj) stage_obj_bias(weights, hd.obj, const_cast<float *>(obj_bias), HIDDEN);
+    } else stage_weights_fwd<HIDDEN>(weights, lds, in_dim, num_layers);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const uint32_t KS0 = IMODE == 2 ? 2u : in_dim / 16;
-    const uint32_t f_hidden = MT * KS0, f_out = f_hidden + (num_layers - 1) * MT * KC;
     const uint32_t tile_rows = 32 * NB;
     const uint32_t n_tiles = (B + tile_rows - 1) / tile_rows;
 
@@ -266,6 +302,14 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
 
         // ---- layer 0: B operand straight from global inputs (natural k order)
         if constexpr (IMODE == 2) {
+            if (hd.obj) {                                  // the object feature's share of layer 0: a constant per neuron (MlpHead)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const f16v b0 = ld_obj_bias(obj_bias, mt, h);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) acc[mt][nb] = b0;
+                }
+            }
             // head mode (two k-chunks: the ray's SH row, the shifted h row): both requested before the first MFMA and pinned — left alone the
             // compiler sinks the second chunk's loads below the MFMAs of the first (54 -> 52 us per 2 M rows). The same hoist made the
             // planar form SLOWER (53 -> 62 us: sixteen dword loads waited for at once instead of overlapping the first chunk's MFMAs).
@@ -613,19 +657,27 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const bool with_dx = grad_inputs != nullptr;
-    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx, HEAD);
+    // row width of W0 in the blob and in the weight-gradient workspace: in_dim, or 48 for the colour head with an object feature (MlpHead)
+    uint32_t ld0 = in_dim;
+    bool has_obj = false;
+    if constexpr (HEAD) { ld0 = head_ld0(hd); has_obj = hd.obj != nullptr; }
+    stage_weights_bwd<HIDDEN>(weights, lds, in_dim, NL, with_dx, HEAD, ld0);
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
     _Float16 *sD = lds + lds_w_halfs;                    // [4][RW][WD]
     _Float16 *sA = sD + 4 * RW * WD;                     // [4][RW][WA]
     _Float16 *ldsF = sA + 4 * RW * WA;                   // RECOMP: forward weight image (layer 0 + hidden matrices)
-    if constexpr (RECOMP) stage_weights_fwd<HIDDEN>(weights, ldsF, in_dim, NL, false);
+    const float *obj_bias = reinterpret_cast<const float *>(ldsF + (size_t)(((HIDDEN + 31) / 32) * (in_dim / 16) + (NL - 1) * ((HIDDEN + 31) / 32) * (HIDDEN / 16)) * 512);
+    if constexpr (RECOMP) {
+        stage_weights_fwd<HIDDEN>(weights, ldsF, in_dim, NL, false, ld0);
+        if constexpr (HEAD) { if (has_obj) stage_obj_bias(weights, hd.obj, const_cast<float *>(obj_bias), HIDDEN); }
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
-    const uint64_t first = (uint64_t)HIDDEN * in_dim, lsz = (uint64_t)HIDDEN * HIDDEN;
+    const uint64_t first = (uint64_t)HIDDEN * ld0, lsz = (uint64_t)HIDDEN * HIDDEN;
     _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
 
     f16v dwacc[NL + 1];
@@ -718,6 +770,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             }
             if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
+            if constexpr (HEAD) {
+                // the colour head's layer 0 starts from the object feature's share (a constant per neuron) when there is one
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    f16v b0 = FZ;
+                    if (has_obj) b0 = ld_obj_bias(obj_bias, mt, h);
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) acc[mt][nb] = b0;
+                }
+            }
 #pragma unroll
             for (int kc = 0; kc < KS0M; kc++) {
                 if (kc == 0 || (uint32_t)kc < KS0) {             // in_dim >= 16: k-chunk 0 always exists and starts the chain from the constant 0
@@ -725,7 +787,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     for (int mt = 0; mt < MT; mt++) {
                         const h8 a = ld_frag(ldsF, mt * KS0 + kc, lane);
 #pragma unroll
-                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], kc == 0 ? FZ : acc[mt][nb]);
+                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], (kc == 0 && !HEAD) ? FZ : acc[mt][nb]);
                     }
                 }
             }
@@ -850,7 +912,12 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     for (int kc = 0; kc < KS0M; kc++)
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++)
-                            if ((uint32_t)kc < KS0) *reinterpret_cast<h8 *>(myA + (nb * 32 + c) * WA + 16 * kc + 8 * h) = x_cur[kc][nb];
+                            if ((uint32_t)kc < KS0) {
+                                h8 v = x_cur[kc][nb];
+                                // object feature: column 31 of the input tile (a zero of the shifted h row) becomes 1, so that dW0[:, 31] = sum_b delta_0
+                                if constexpr (HEAD) { if (kc == 1 && has_obj && h == 1) v[7] = (_Float16)1.0f; }
+                                *reinterpret_cast<h8 *>(myA + (nb * 32 + c) * WA + 16 * kc + 8 * h) = v;
+                            }
                 }
             } else {
                 // rows past B as zeros: they must not reach dW
@@ -1013,9 +1080,30 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const uint32_t o = 32 * mt + acc_row(reg, h);
-                if (o < OUT && i < IN) (void)__hip_atomic_fetch_add(ws + ws_off + (uint64_t)o * IN + i, dwacc[s][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o < OUT && i < IN) (void)__hip_atomic_fetch_add(ws + ws_off + (uint64_t)o * (s == NL ? ld0 : IN) + i, dwacc[s][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+}
+
+// Finalize of the colour head with an object feature (MlpHead): the workspace's W0 block has 48-wide rows of which the MFMAs filled
+// columns 0..30 and column 31 = cs[o] = sum_b delta_0[b][o]. dW0[o][31 + j] = cs[o] * obj[j] (the input columns 31..46 hold the same
+// obj[j] for every sample), dW0[o][47] = 0 (zero pad input), and grad_obj[j] = sum_o W0[o][31 + j] * cs[o] (fp32, [16]).
+__global__ void __launch_bounds__(256) k_mlp_dw_finalize_obj(const float *__restrict__ ws, _Float16 *__restrict__ gw, uint32_t n, uint32_t hidden,
+                                                             const _Float16 *__restrict__ W, const _Float16 *__restrict__ obj, float *__restrict__ grad_obj) {
+    const uint32_t n0 = hidden * HEAD_OBJ_LD;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float v = ws[i];
+        if (i < n0) {
+            const uint32_t o = i / HEAD_OBJ_LD, col = i % HEAD_OBJ_LD;
+            if (col >= 31) v = col < 47 ? ws[o * HEAD_OBJ_LD + 31] * (float)obj[col - 31] : 0.0f;
+        }
+        gw[i] = (_Float16)v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16 && grad_obj) {
+        float a = 0.0f;
+        for (uint32_t o = 0; o < hidden; o++) a = fmaf((float)W[o * HEAD_OBJ_LD + 31 + threadIdx.x], ws[o * HEAD_OBJ_LD + 31], a);
+        grad_obj[threadIdx.x] = a;
     }
 }
 
@@ -1050,10 +1138,12 @@ __device__ __forceinline__ void nf_sh16_half(float x, float y, float z, int h, h
 // depth, tile / dir_div is its block, and a wave takes CONSECUTIVE tiles: the SH values of its lanes' rays change once per block, so they
 // are computed when the block changes and kept in registers (per tile they were 60 of the kernel's ~550 VALU instructions, plus the loads
 // of the directions and the division that finds them).
-template <int NLS, int NLC, bool PLANAR, bool RELU_CT, bool BLK>
+// OBJ: FOC's object-conditioned colour network (nerf/network_tcnn.py:611-640, MlpHead above): 48-wide W0 rows, the encoded object feature's
+// share W0[:, 31:47] . obj as the initial value of the colour layer-0 accumulators.
+template <int NLS, int NLC, bool PLANAR, bool RELU_CT, bool BLK, bool OBJ>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__restrict__ enc, const float *__restrict__ dirs, uint32_t dir_div,
                                                           uint32_t dir_block, uint32_t n_dirs, const _Float16 *__restrict__ w_sigma, const _Float16 *__restrict__ w_color, uint32_t B,
-                                                          int relu_rt, float *__restrict__ sigma_out, float *__restrict__ rgb_out) {
+                                                          int relu_rt, float *__restrict__ sigma_out, float *__restrict__ rgb_out, const _Float16 *__restrict__ obj) {
     const int relu = RELU_CT ? 1 : relu_rt;            // ReLU as a compile-time fact (see k_mlp_bwd_fused); `false` keeps the runtime flag
     f16v FZ;                                           // constant zero C operand: the first MFMA of every chain takes the inline constant 0
 #pragma unroll
@@ -1066,17 +1156,18 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
     stage_weights_fwd<HIDDEN>(w_sigma, lds, IN, NLS);
     {
         constexpr uint32_t n0 = MT * KS0, nh = (NLC - 1) * MT * KC, total = n0 + nh + KC;
-        const _Float16 *Wh = w_color + (size_t)HIDDEN * IN;
+        constexpr uint32_t LD0 = OBJ ? HEAD_OBJ_LD : (uint32_t)IN;      // row width of the colour net's W0
+        const _Float16 *Wh = w_color + (size_t)HIDDEN * LD0;
         const _Float16 *Wo = Wh + (size_t)(NLC - 1) * HIDDEN * HIDDEN;
         for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
             const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (f < n0) {
                 const uint32_t mt = f / KS0, kc = f % KS0, row = 32 * mt + r;
-                if (kc == 0) v = *reinterpret_cast<const h8 *>(w_color + (size_t)row * IN + 8 * h);          // SH chunk, natural order
+                if (kc == 0) v = *reinterpret_cast<const h8 *>(w_color + (size_t)row * LD0 + 8 * h);          // SH chunk, natural order
                 else {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { const int n = chain_k(0, h, j); if (n >= 1) v[j] = w_color[(size_t)row * IN + 15 + n]; }
+                    for (int j = 0; j < 8; j++) { const int n = chain_k(0, h, j); if (n >= 1) v[j] = w_color[(size_t)row * LD0 + 15 + n]; }
                 }
             } else if (f < n0 + nh) {
                 const uint32_t g = f - n0, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, row = 32 * mt + r;
@@ -1096,6 +1187,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
             *reinterpret_cast<h8 *>(ldsC + (size_t)f * 512 + lane * 8) = v;
         }
     }
+    const float *obj_bias = reinterpret_cast<const float *>(ldsC + (size_t)(MT * KS0 + (NLC - 1) * MT * KC + KC) * 512);
+    if constexpr (OBJ) stage_obj_bias(w_color, obj, const_cast<float *>(obj_bias), HIDDEN);
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1196,8 +1289,17 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const h8 a0 = ld_frag(ldsC, mt * KS0 + 0, lane);
+            if constexpr (OBJ) {
+                // read per tile (pointer laundered): hoisted out of the tile loop the 32 values stay live across it and the kernel spills
+                const float *bp = obj_bias;
+                asm volatile("" : "+v"(bp));
+                const f16v b0 = ld_obj_bias(bp, mt, h);
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], FZ);
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], b0);
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a0, sh[nb], FZ);
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
@@ -1318,7 +1420,7 @@ template <int HIDDEN, bool TRAIN>
 static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
                           void *fwd_buf, void *outputs, int planar, hipStream_t st, const MlpHead *head = nullptr) {
     constexpr int NB = 1;                          // one 32-row tile per wave: 92 registers, 5 waves per SIMD (two tiles: 157 registers, 3 waves; 57 -> 54 us per 2 M rows)
-    const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers);
+    const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers) + (head && head->obj ? 256 : 0);       // + obj_bias [2][2][16] fp32
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     FOC_REQUIRE(!(planar && TRAIN), FOC_E_INVALID, "ffmlp_forward: planar inputs go with the activation-free forward");
     auto kern = planar ? k_mlp_fwd<HIDDEN, NB, false, 1> : k_mlp_fwd<HIDDEN, NB, TRAIN, 0>;
@@ -1330,7 +1432,7 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u, 16u});
+                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
@@ -1359,7 +1461,8 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
 
 template <int HIDDEN, int NL>
 static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, int relu,
-                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st, const MlpHead *head = nullptr) {
+                                void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st, const MlpHead *head = nullptr,
+                                float *grad_obj = nullptr) {
     FOC_REQUIRE(!planar || fwd_buf == nullptr, FOC_E_INVALID, "ffmlp_backward: planar inputs need the re-evaluating form (forward_buffer NULL)");
     constexpr int NB = 1, RW = 32 * NB, WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     const bool dx = grad_inputs != nullptr;
@@ -1367,7 +1470,8 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const uint32_t WA = (in_dim > (uint32_t)HIDDEN ? in_dim : (uint32_t)(HIDDEN < 32 ? 32 : HIDDEN)) + 8;
     const bool recomp = fwd_buf == nullptr;
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
-    const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0);
+    const bool has_obj = head && head->obj;
+    const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0) + (has_obj ? 256 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
     // the re-evaluating forms exist twice: ReLU as a compile-time fact (what every NeRF network uses) and with the runtime flag
     auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
@@ -1379,16 +1483,18 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (NL - 1) + 16);
+    const uint32_t n_w = HIDDEN * ((has_obj ? HEAD_OBJ_LD : in_dim) + HIDDEN * (NL - 1) + 16);
     if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t grid = foc_div_up(B, 4 * RW);
     const uint32_t cap = mlp_num_cus() * 2;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
                        (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
-                       head ? *head : MlpHead{nullptr, nullptr, 1u, 16u});
+                       head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
-    hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
+    if (has_obj) hipLaunchKernelGGL(k_mlp_dw_finalize_obj, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w, (uint32_t)HIDDEN,
+                                    (const _Float16 *)weights, head->obj, grad_obj);
+    else hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
     FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
     return FOC_OK;
 }
@@ -1450,18 +1556,23 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
 
 template <int NLS, int NLC>
 static int nerf_infer_launch(const void *enc, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs, const void *w_sigma, const void *w_color, uint32_t B, int relu, int planar,
-                             float *sigma, float *rgb, hipStream_t st) {
-    const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024;
+                             float *sigma, float *rgb, const void *obj, hipStream_t st) {
+    const size_t lds = (size_t)((2 * 2 + (NLS - 1) * 8 + 4) + (2 * 2 + (NLC - 1) * 8 + 4)) * 1024 + (obj ? 256 : 0);
     const bool blk = planar && dir_block == 64u;     // the staged render's sample order (fixedstep.hip FS_RAY_BLOCK)
-    auto kern = planar ? (blk ? (relu ? k_nerf_infer<NLS, NLC, true, true, true> : k_nerf_infer<NLS, NLC, true, false, true>)
-                              : (relu ? k_nerf_infer<NLS, NLC, true, true, false> : k_nerf_infer<NLS, NLC, true, false, false>))
-                       : (relu ? k_nerf_infer<NLS, NLC, false, true, false> : k_nerf_infer<NLS, NLC, false, false, false>);
+    auto kern = planar ? (blk ? (relu ? k_nerf_infer<NLS, NLC, true, true, true, false> : k_nerf_infer<NLS, NLC, true, false, true, false>)
+                              : (relu ? k_nerf_infer<NLS, NLC, true, true, false, false> : k_nerf_infer<NLS, NLC, true, false, false, false>))
+                       : (relu ? k_nerf_infer<NLS, NLC, false, true, false, false> : k_nerf_infer<NLS, NLC, false, false, false, false>);
+    if (obj) {
+        // the object-conditioned form is built for what FOC runs: ReLU networks on the encoder's planes
+        FOC_REQUIRE(planar && relu, FOC_E_INVALID, "nerf_field_inference: an object feature needs planar encodings and ReLU networks");
+        kern = blk ? k_nerf_infer<NLS, NLC, true, true, true, true> : k_nerf_infer<NLS, NLC, true, true, false, true>;
+    }
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     uint32_t grid = foc_div_up(foc_div_up(B, 64), MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)enc, dirs, dir_div, dir_block, n_dirs, (const _Float16 *)w_sigma,
-                       (const _Float16 *)w_color, B, relu, sigma, rgb);
+                       (const _Float16 *)w_color, B, relu, sigma, rgb, (const _Float16 *)obj);
     FOC_CHECK_LAUNCH("nerf_field_inference");
     return FOC_OK;
 }
@@ -1545,7 +1656,7 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
 int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs,
                              const void *sigma_weights, uint32_t sigma_layers,
                              const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B, float *sigma,
-                             float *rgb, void *stream) {
+                             float *rgb, const void *obj_feat, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(enc && dirs && sigma_weights && color_weights && rgb, FOC_E_INVALID, "nerf_field_inference: null pointer");
@@ -1557,16 +1668,16 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
     hipStream_t st = (hipStream_t)stream;
     const uint32_t key = sigma_layers * 10 + color_layers;
     switch (key) {
-        case 22: return nerf_infer_launch<2, 2>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
-        case 23: return nerf_infer_launch<2, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
-        case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, st);
+        case 22: return nerf_infer_launch<2, 2>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, obj_feat, st);
+        case 23: return nerf_infer_launch<2, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, obj_feat, st);
+        case 33: return nerf_infer_launch<3, 3>(enc, dirs, dir_div, dir_block, n_dirs, sigma_weights, color_weights, B, relu, enc_planar, sigma, rgb, obj_feat, st);
         default: foc_set_error("nerf_field_inference: layer counts (%u, %u) are not built (2/2, 2/3, 3/3)", sigma_layers, color_layers); return FOC_E_INVALID;
     }
 }
 
 // The colour network of the fixed-step training path, fed from the sigma network's output rows and a per-ray SH table (input mode 2).
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights, uint32_t B, uint32_t hidden_dim,
-                           uint32_t num_layers, uint32_t activation, void *outputs, uint32_t out_width, void *stream) {
+                           uint32_t num_layers, uint32_t activation, void *outputs, uint32_t out_width, const void *obj_feat, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     int rc = mlp_check("color_head_forward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
@@ -1574,13 +1685,13 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
     FOC_REQUIRE(h && ray_sh && weights && outputs, FOC_E_INVALID, "color_head_forward: null pointer");
     FOC_REQUIRE(hidden_dim == 64 && samples_per_ray >= 1, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64 (got %u), samples_per_ray >= 1", hidden_dim);
     FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_forward: out_width must be 16 or 4 (got %u)", out_width);
-    const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray, out_width};
+    const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray, out_width, (const _Float16 *)obj_feat};
     return mlp_fwd_launch<64, false>(h, weights, B, 32, num_layers, activation == 0, nullptr, outputs, 0, (hipStream_t)stream, &hd);
 }
 
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
                             uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
-                            uint32_t out_width, void *stream) {
+                            uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
@@ -1588,16 +1699,17 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
                 "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3 (got %u, %u)", hidden_dim, num_layers);
     if (B == 0) {
         FOC_REQUIRE(grad_weights, FOC_E_INVALID, "color_head_backward: null pointer");
-        const size_t n_w = (size_t)64 * (32 + (size_t)64 * (num_layers - 1) + 16);
+        const size_t n_w = (size_t)64 * ((obj_feat ? HEAD_OBJ_LD : 32u) + (size_t)64 * (num_layers - 1) + 16);
         if (foc_zero_async(grad_weights, n_w * sizeof(_Float16), (hipStream_t)stream) != hipSuccess) { foc_set_error("color_head_backward: memset failed"); return FOC_E_LAUNCH; }
+        if (grad_obj && foc_zero_async(grad_obj, 16 * sizeof(float), (hipStream_t)stream) != hipSuccess) { foc_set_error("color_head_backward: memset failed"); return FOC_E_LAUNCH; }
         return FOC_OK;
     }
     FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");
     FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_backward: out_width must be 16 or 4 (got %u)", out_width);
-    const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray, out_width};
+    const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray, out_width, (const _Float16 *)obj_feat};
     const int relu = activation == 0;
-    if (num_layers == 2) return mlp_bwd_fused_launch<64, 2>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);
-    return mlp_bwd_fused_launch<64, 3>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd);
+    if (num_layers == 2) return mlp_bwd_fused_launch<64, 2>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd, grad_obj);
+    return mlp_bwd_fused_launch<64, 3>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd, grad_obj);
 }
 
 int foc_allocate_splitk(uint64_t size) { (void)size; return FOC_OK; }

@@ -317,12 +317,13 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
                                                      const float *__restrict__ fars, const float *__restrict__ noise, const float *__restrict__ bg_ray,
                                                      float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
                                                      float *__restrict__ sigma_out, float *__restrict__ trans_out, float *__restrict__ weights_out,
-                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, uint32_t c_ld) {
+                                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, uint32_t c_ld,
+                                                     float *__restrict__ ray_sumsq) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const FsGeom g = fs_geom(nears, fars, n, T);
-    float Tc = 1.0f, ws = 0, dp = 0, r = 0, gg = 0, b = 0;
+    float Tc = 1.0f, ws = 0, dp = 0, r = 0, gg = 0, b = 0, sq = 0;
     for (uint32_t base = 0; base < T; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < T;
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
             sigma_out[s] = sigma; trans_out[s] = Tb; weights_out[s] = w;
             float oz = (z - g.near) / g.span;
             oz = oz < 0.0f ? 0.0f : (oz > 1.0f ? 1.0f : oz);
-            ws += w; dp += w * oz;
+            ws += w; dp += w * oz; sq = fmaf(sigma, sigma, sq);
             if (w > thresh) {
                 const _Float16 *cc = reinterpret_cast<const _Float16 *>(&raw);
                 r += w * fs_sigmoid_h((float)cc[0]); gg += w * fs_sigmoid_h((float)cc[1]); b += w * fs_sigmoid_h((float)cc[2]);
@@ -356,6 +357,10 @@ __global__ void __launch_bounds__(256) k_fs_tail_fwd(const _Float16 *__restrict_
         Tc *= __shfl(P, 63, 64);
     }
     ws = wave_sum(ws); dp = wave_sum(dp); r = wave_sum(r); gg = wave_sum(gg); b = wave_sum(b);
+    if (ray_sumsq) {                                       // wave-uniform
+        sq = wave_sum(sq);
+        if (lane == 0) ray_sumsq[n] = sq;
+    }
     if (lane == 0) {
         const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
         image[n * 3] = r + (1 - ws) * b0; image[n * 3 + 1] = gg + (1 - ws) * b1; image[n * 3 + 2] = b + (1 - ws) * b2;
@@ -374,12 +379,14 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
                                                      const _Float16 *__restrict__ c, const float *__restrict__ sigma_in, const float *__restrict__ trans_in,
                                                      const float *__restrict__ weights, const float *__restrict__ nears, const float *__restrict__ fars,
                                                      const float *__restrict__ noise, const float *__restrict__ bg_ray, float bg_scalar, uint32_t N, uint32_t T,
-                                                     float density_scale, float thresh, _Float16 *__restrict__ grad_c, _Float16 *__restrict__ grad_h0, uint32_t c_ld) {
+                                                     float density_scale, float thresh, _Float16 *__restrict__ grad_c, _Float16 *__restrict__ grad_h0, uint32_t c_ld,
+                                                     const float *__restrict__ grad_sumsq) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const FsGeom g = fs_geom(nears, fars, n, T);
     const float gws = grad_ws ? grad_ws[n] : 0.0f, gdp = grad_depth ? grad_depth[n] : 0.0f;
+    const float gsq2 = grad_sumsq ? 2.0f * grad_sumsq[n] : 0.0f;      // d(sum sigma^2)/d sigma = 2 sigma
     const float g0 = grad_image[n * 3], g1 = grad_image[n * 3 + 1], g2 = grad_image[n * 3 + 2];
     const float b0 = bg_ray ? bg_ray[n * 3] : bg_scalar, b1 = bg_ray ? bg_ray[n * 3 + 1] : bg_scalar, b2 = bg_ray ? bg_ray[n * 3 + 2] : bg_scalar;
     const float e_lo = expf(fs_opaque(-15.0f)), e_hi = expf(fs_opaque(15.0f));
@@ -424,7 +431,8 @@ __global__ void __launch_bounds__(256) k_fs_tail_bwd(const float *__restrict__ g
         const float incl = wave_suffix_incl_sum(gw_i, (int)lane);
         const float S_i = S_carry + (incl - gw_i);
         const float dalpha = gi * Tb - S_i / om;
-        const float dsigma = dalpha * (delta * density_scale) * ex;
+        float dsigma = dalpha * (delta * density_scale) * ex;
+        if (gsq2 != 0.0f) dsigma = fmaf(gsq2, sigma, dsigma);          // the outside-mask density criterion's share (nerf/renderer.py:163-165)
         const float dh0 = dsigma * fminf(fmaxf(sigma, e_lo), e_hi);
         if (valid) grad_h0[s] = foc_f2h(dh0);
         S_carry += __shfl(incl, 0, 64);
@@ -618,7 +626,7 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
 
 int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
                            uint32_t N, uint32_t T, float density_scale, float thresh, float *sigma, float *trans, float *weights, float *weights_sum,
-                           float *depth, float *image, uint32_t c_width, void *stream) {
+                           float *depth, float *image, uint32_t c_width, float *ray_sumsq, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_forward: c_width must be 16 or 4 (got %u)", c_width);
@@ -626,14 +634,15 @@ int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, con
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_forward: T must be >= 2");
     auto kern = noise ? k_fs_tail_fwd<true> : k_fs_tail_fwd<false>;
     hipLaunchKernelGGL(kern, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)h, (const _Float16 *)c, nears, fars, noise,
-                       bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image, c_width);
+                       bg_ray, bg_scalar, N, T, density_scale, thresh, sigma, trans, weights, weights_sum, depth, image, c_width, ray_sumsq);
     FOC_CHECK_LAUNCH("fixed_tail_forward");
     return FOC_OK;
 }
 
 int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c, const float *sigma, const float *trans,
                             const float *weights, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
-                            uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width, void *stream) {
+                            uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width, const float *grad_sumsq,
+                            void *stream) {
     FocDeviceGuard foc_guard_(stream);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_backward: c_width must be 16 or 4 (got %u)", c_width);
@@ -641,7 +650,8 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_tail_backward: T must be >= 2");
     auto kern = noise ? k_fs_tail_bwd<true> : k_fs_tail_bwd<false>;
     hipLaunchKernelGGL(kern, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, grad_image, grad_ws, grad_depth, (const _Float16 *)c, sigma,
-                       trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0, c_width);
+                       trans, weights, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, (_Float16 *)grad_c, (_Float16 *)grad_h0, c_width,
+                       grad_sumsq);
     FOC_CHECK_LAUNCH("fixed_tail_backward");
     return FOC_OK;
 }

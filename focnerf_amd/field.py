@@ -73,6 +73,26 @@ def _half_of(param):
     return h
 
 
+def scope_cached(key, owner, make):
+    """`make()` -> tensor, once per open `half_cache_scope` for (key, owner) — `owner` is kept and compared by identity so that a recycled
+    id() cannot alias. Like `_half_of`, a value made on one stream is handed to another stream behind an event. No scope: `make()`."""
+    if _half_scope is None:
+        return make()
+    hit = _half_scope.get(key)
+    if hit is not None and hit[0] is owner:
+        if hit[2] is not None and torch.cuda.current_stream(hit[1].device) != hit[3]:
+            torch.cuda.current_stream(hit[1].device).wait_event(hit[2])
+        return hit[1]
+    v = make()
+    ev = st = None
+    if v.is_cuda:
+        st = torch.cuda.current_stream(v.device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+    _half_scope[key] = (owner, v, ev, st)
+    return v
+
+
 class _hashgrid_mlp(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
@@ -116,19 +136,22 @@ class _hashgrid_mlp(Function):
 
 def infer_fusable(model):
     """Whole-field inference kernel (csrc/ffmlp.hip, k_nerf_infer): hash grid (D=3, C=2, 16 levels) -> 64-wide sigma net -> degree-4 SH
-    + 15 geometry features -> 64-wide colour net."""
+    + 15 geometry features (+ FOC's 16-wide encoded object feature, network_tcnn.py:611-640: 48-wide colour input) -> 64-wide colour net."""
     from .shencoder import SHEncoder
     enc, sn, cn = getattr(model, "encoder", None), getattr(model, "sigma_net", None), getattr(model, "color_net", None)
+    obj = getattr(model, "uses_object_feature", False)
     return (field_fusable(enc, sn) and isinstance(cn, FFMLP) and isinstance(getattr(model, "encoder_dir", None), SHEncoder)
-            and sn.input_dim == 32 and sn.hidden_dim == 64 and cn.hidden_dim == 64 and cn.input_dim == 32 and cn.padded_output_dim == 16
+            and sn.input_dim == 32 and sn.hidden_dim == 64 and cn.hidden_dim == 64 and cn.input_dim == (48 if obj else 32) and cn.padded_output_dim == 16
             and getattr(model, "geo_feat_dim", 0) == 15 and (sn.num_layers, cn.num_layers) in ((2, 2), (2, 3), (3, 3))
+            and (not obj or (getattr(model, "yolo_encoding_dim", 0) == 16 and sn.activation == 0))
             and sn.activation == cn.activation and os.environ.get("FOC_FUSED_INFER", "1") != "0")
 
 
 @torch.no_grad()
-def field_infer(model, xn, dirs, dir_div=1, dir_block=0):
+def field_infer(model, xn, dirs, dir_div=1, dir_block=0, obj_feat=None):
     """xn [M,3] fp32 in [0,1] (already normalised), dirs [M / dir_div, 3] -> sigma [M] fp32, rgb [M,3] fp32 (no autograd).
-    dir_block = 64: the rows stand in the block-interleaved order of `fixedstep.fixed_sample(..., ray_block=64)`."""
+    dir_block = 64: the rows stand in the block-interleaved order of `fixedstep.fixed_sample(..., ray_block=64)`.
+    obj_feat [16]: the encoded object feature of an object-conditioned network (required iff `model.uses_object_feature`)."""
     from ._lib import lib, ptr, stream_of, check
     enc, sn, cn = model.encoder, model.sigma_net, model.color_net
     xn = xn.contiguous().float()
@@ -141,8 +164,14 @@ def field_infer(model, xn, dirs, dir_div=1, dir_block=0):
                                      enc.gridtype_id, enc.align_corners, enc.interp_id)
     sigma = torch.empty(M, dtype=torch.float32, device=xn.device)
     rgb = torch.empty(M, 3, dtype=torch.float32, device=xn.device)
+    obj16 = None
+    if getattr(model, "uses_object_feature", False):
+        if obj_feat is None:
+            raise RuntimeError("field_infer: an object-conditioned network needs its encoded object feature")
+        obj16 = obj_feat.detach().reshape(-1).half().contiguous()
+        assert obj16.numel() == 16
     check(lib.foc_nerf_field_inference(ptr(planes), 1, ptr(dirs), int(dir_div), int(dir_block), dirs.shape[0], ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, 64, sn.activation, M,
-                                       ptr(sigma), ptr(rgb), stream_of(xn)), "nerf_field_inference")
+                                       ptr(sigma), ptr(rgb), ptr(obj16), stream_of(xn)), "nerf_field_inference")
     return sigma, rgb
 
 

@@ -135,14 +135,16 @@ class _fixed_composite(Function):
 
 
 def tail_fusable(model):
-    """Shapes `_render_tail` serves: 16-wide sigma head, degree-4 SH, 64-wide colour network of 2 or 3 layers, no object feature."""
+    """Shapes `_render_tail` serves: 16-wide sigma head, degree-4 SH, 64-wide colour network of 2 or 3 layers, its input the 32-wide
+    [SH16 | geo15 | 0] of network_ff.py or FOC's 48-wide [SH16 | geo15 | object feature 16 | 0] (network_tcnn.py:611-640)."""
     import os
     from .ffmlp import FFMLP
     from .shencoder import SHEncoder
     cn = getattr(model, "color_net", None)
-    return (isinstance(cn, FFMLP) and cn.input_dim == 32 and cn.hidden_dim == 64 and cn.num_layers in (2, 3) and cn.padded_output_dim == 16
+    want_in = 48 if getattr(model, "uses_object_feature", False) else 32
+    return (isinstance(cn, FFMLP) and cn.input_dim == want_in and cn.hidden_dim == 64 and cn.num_layers in (2, 3) and cn.padded_output_dim == 16
             and isinstance(getattr(model, "encoder_dir", None), SHEncoder) and getattr(model, "geo_feat_dim", 0) == 15
-            and not getattr(model, "uses_object_feature", False) and os.environ.get("FOC_FUSED_TAIL", "1") != "0")
+            and (want_in == 32 or getattr(model, "yolo_encoding_dim", 0) == 16) and os.environ.get("FOC_FUSED_TAIL", "1") != "0")
 
 
 _C_WIDTH = 4        # columns of the colour network's output that exist in memory on the fused tail (rgb logits + one pad)
@@ -156,10 +158,15 @@ class _render_tail(Function):
     network's input: its kernels read h and one SH row per ray (foc_color_head_forward), and in the backward pass the colour
     network writes grad_h itself — its input gradient for columns 1..15 merged with the density path's column 0 — so neither
     cin [M,32] nor grad_cin [M,32] exists (0.5 GB of traffic per 2 M-sample step). Head and composite are one kernel per
-    direction (foc_fixed_tail_forward / _backward). ray_sh [N,16] half: `fixed_sample(..., want_ray_sh=True)` or `ray_sh_rows`."""
+    direction (foc_fixed_tail_forward / _backward). ray_sh [N,16] half: `fixed_sample(..., want_ray_sh=True)` or `ray_sh_rows`.
+
+    obj_feat [16] (or None): FOC's encoded object feature — the colour network then has 48-wide W0 rows; the feature's share of layer 0
+    is a constant per neuron inside the kernels, its gradient (for the object-feature encoder) comes back as one [16] vector.
+    want_sumsq: a seventh, differentiable output sumsq [N] = sum_t sigma^2 per ray (the samples' share of the outside-mask criterion)."""
 
     @staticmethod
-    def forward(ctx, h, cweights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation):
+    def forward(ctx, h, cweights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation, obj_feat=None,
+                want_sumsq=False):
         from .field import _half_of
         h = h.contiguous()
         assert h.dtype == torch.float16 and h.shape == (N * T, 16)
@@ -169,7 +176,11 @@ class _render_tail(Function):
         w16 = _half_of(cweights)
         # of the colour network's 16 padded outputs only the rgb logits are ever read: they travel as [M,4] rows (as does their gradient)
         c = torch.empty(M, _C_WIDTH, dtype=torch.float16, device=dev)
-        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), _C_WIDTH, st),
+        obj16 = None
+        if obj_feat is not None:
+            obj16 = obj_feat.detach().reshape(-1).half().contiguous()
+            assert obj16.numel() == 16 and w16.numel() == 64 * (48 + 64 * (int(num_layers) - 1) + 16)
+        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), _C_WIDTH, ptr(obj16), st),
               "color_head_forward")
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         trans = torch.empty(M, dtype=torch.float32, device=dev)
@@ -177,22 +188,28 @@ class _render_tail(Function):
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        sumsq = torch.empty(N, dtype=torch.float32, device=dev) if want_sumsq else None
         check(lib.foc_fixed_tail_forward(ptr(h), ptr(c), ptr(nears), ptr(fars), ptr(noise), ptr(bg_ray), float(bg_scalar), N, T, float(density_scale),
-                                         float(thresh), ptr(sigma), ptr(trans), ptr(weights), ptr(ws), ptr(depth), ptr(image), _C_WIDTH, st), "fixed_tail_forward")
+                                         float(thresh), ptr(sigma), ptr(trans), ptr(weights), ptr(ws), ptr(depth), ptr(image), _C_WIDTH, ptr(sumsq), st),
+              "fixed_tail_forward")
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise if noise is not None else empty,
-                              bg_ray if bg_ray is not None else empty)
-        ctx.flags = (noise is not None, bg_ray is not None)
+                              bg_ray if bg_ray is not None else empty, obj16 if obj16 is not None else empty)
+        ctx.flags = (noise is not None, bg_ray is not None, obj16 is not None, obj_feat.dtype if obj_feat is not None else None,
+                     tuple(obj_feat.shape) if obj_feat is not None else None)
         ctx.dims = (N, T, float(density_scale), float(thresh), float(bg_scalar), int(num_layers), int(activation))
         ctx.mark_non_differentiable(sigma, weights, c)
         ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as five freshly zero-filled tensors (25 us)
+        if want_sumsq:
+            return image, ws, depth, sigma, weights, c, sumsq
         return image, ws, depth, sigma, weights, c
 
     @staticmethod
-    def backward(ctx, g_image, g_ws, g_depth, _g_sigma, _g_weights, _g_c):
+    def backward(ctx, g_image, g_ws, g_depth, _g_sigma, _g_weights, _g_c, g_sumsq=None):
         from .backend import _scratch
-        h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise, bg_ray = ctx.saved_tensors
-        has_noise, has_bg = ctx.flags
+        h, w16, sigma, trans, weights, c, ray_sh, nears, fars, noise, bg_ray, obj16 = ctx.saved_tensors
+        has_noise, has_bg, has_obj, obj_dtype, obj_shape = ctx.flags
+        obj16 = obj16 if has_obj else None
         N, T, ds, thresh, bg_scalar, num_layers, activation = ctx.dims
         noise = noise if has_noise else None
         bg_ray = bg_ray if has_bg else None
@@ -201,16 +218,37 @@ class _render_tail(Function):
         g_image = g_image.contiguous().float() if g_image is not None else torch.zeros(N, 3, dtype=torch.float32, device=dev)
         g_ws = g_ws.contiguous().float() if g_ws is not None else None
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
+        g_sumsq = g_sumsq.contiguous().float() if g_sumsq is not None else None
         grad_c = torch.empty_like(c)
         grad_h0 = torch.empty(M, dtype=torch.float16, device=dev)
         check(lib.foc_fixed_tail_backward(ptr(g_image), ptr(g_ws), ptr(g_depth), ptr(c), ptr(sigma), ptr(trans), ptr(weights), ptr(nears), ptr(fars),
-                                          ptr(noise), ptr(bg_ray), bg_scalar, N, T, ds, thresh, ptr(grad_c), ptr(grad_h0), _C_WIDTH, st), "fixed_tail_backward")
+                                          ptr(noise), ptr(bg_ray), bg_scalar, N, T, ds, thresh, ptr(grad_c), ptr(grad_h0), _C_WIDTH, ptr(g_sumsq), st),
+              "fixed_tail_backward")
         grad_h = torch.empty_like(h)
         g_w = torch.empty_like(w16)
-        wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(32, 64, num_layers), dev)
+        wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(48 if has_obj else 32, 64, num_layers), dev)
+        g_obj32 = torch.empty(16, dtype=torch.float32, device=dev) if has_obj and ctx.needs_input_grad[14] else None
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
-                                          ptr(g_w), ptr(wsb), _C_WIDTH, st), "color_head_backward")
-        return (grad_h, g_w) + (None,) * 12
+                                          ptr(g_w), ptr(wsb), _C_WIDTH, ptr(obj16), ptr(g_obj32), st), "color_head_backward")
+        g_obj = g_obj32.to(obj_dtype).view(obj_shape) if g_obj32 is not None else None
+        return (grad_h, g_w) + (None,) * 12 + (g_obj, None)
+
+
+class _masked_norm(Function):
+    """sqrt(sum(sumsq[outside])) with the subgradient 0 at 0 that torch.norm has: FOC's `criterion_outside_mask`
+    (nerf/renderer.py:163-165: torch.norm(sigma[~mask_rays])) from the per-ray sums of sigma^2 the tail kernel returns."""
+
+    @staticmethod
+    def forward(ctx, sumsq, outside):
+        crit = torch.sqrt((sumsq * outside).sum())
+        ctx.save_for_backward(crit, outside)
+        return crit
+
+    @staticmethod
+    def backward(ctx, g):
+        crit, outside = ctx.saved_tensors
+        coef = torch.where(crit > 0, g / (2 * crit), torch.zeros_like(crit))
+        return outside * coef, None
 
 
 def _background(bg_color, N, dev):
@@ -242,7 +280,7 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
     noise = torch.rand(N * T, dtype=torch.float32, device=dev) if perturb else None
     want_tail = (tail_fusable(model) and model.training and torch.is_grad_enabled())
     from .field import infer_fusable, field_infer
-    fused_infer = not torch.is_grad_enabled() and infer_fusable(model) and not getattr(model, "uses_object_feature", False)
+    fused_infer = not torch.is_grad_enabled() and infer_fusable(model)
     rb = ray_block_default() if fused_infer else 0
     enc_in, _, ray_sh = fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, want_ray_sh=True) if want_tail else \
         fixed_sample(rays_o, rays_d, nears, fars, aabb, noise, T, model.bound, ray_block=rb) + (None,)
@@ -250,7 +288,8 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
     if fused_infer:
         # inference: sample -> encoder planes -> whole-field kernel -> weights + mask + composite kernel; between the kernels the samples
         # stand in 64-ray blocks (neighbouring rays at one depth on the lanes of a wave: the encoder's gathers share cache lines)
-        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb)
+        obj_feat = model.encode_object_feature(yolo_details, dev) if getattr(model, "uses_object_feature", False) else None
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb, obj_feat=obj_feat)
         bg_ray, bg_scalar = _background(bg_color, N, dev)
         # `_out` = (depth [N], image [N,3]) fp32 contiguous views of the caller's whole-view buffers (NeRFRenderer.render, staged)
         direct = (_out is not None and _out[0].dtype == torch.float32 and _out[1].dtype == torch.float32 and _out[0].is_contiguous()
@@ -297,16 +336,24 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         obj_feat = None
         if getattr(model, "uses_object_feature", False):                  # FOC network (network_foc.py): encoded YOLO feature in the colour input
             obj_feat = model.encode_object_feature(yolo_details, dev)
-        fused_tail = want_tail and obj_feat is None
+        fused_tail = want_tail
+        # nerf/renderer.py:163-165: in training with an object mask, the norm of the densities of the rays outside it
+        want_crit = model.training and yolo_details is not None and yolo_details[0] is not None
+        criterion_outside_mask = None
         if fused_tail:
             cn = model.color_net
             bg_ray, bg_scalar = _background(bg_color, N, dev)
-            image, weights_sum, depth, sigma, weights, c = _render_tail.apply(h, cn.weights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T,
-                                                                              model.density_scale, weight_thresh, cn.num_layers, cn.activation)
+            outs = _render_tail.apply(h, cn.weights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, model.density_scale, weight_thresh,
+                                      cn.num_layers, cn.activation, obj_feat, want_crit and yolo_details[0].numel() == N)
+            image, weights_sum, depth, sigma, weights, c = outs[:6]
+            if len(outs) == 7:
+                # a per-ray mask: the samples' sum of sigma^2 comes out of the tail kernel (no [M]-sized torch expression, no boolean-mask
+                # indexing with its host sync); sigma here is the kernel's exp(h0) — density_scale == 1 in every FOC configuration, and the
+                # criterion is taken on trunc_exp(h0) itself like the reference's
+                criterion_outside_mask = _masked_norm.apply(outs[6], (~yolo_details[0].reshape(N)).to(torch.float32))
         else:
             weights, weights_sum, depth, sigma, cin = _density_head.apply(h, rays_d, nears, fars, noise, N, T, model.density_scale, obj_feat)
-        criterion_outside_mask = None
-        if model.training and yolo_details is not None:                   # nerf/renderer.py:163-165
+        if want_crit and criterion_outside_mask is None:
             from .activation import trunc_exp
             criterion_outside_mask = torch.norm(trunc_exp(h[:, 0]).view(N, T)[~yolo_details[0].squeeze(0)] - 0)
         if not fused_tail:
@@ -344,12 +391,13 @@ def render_field4(model, rays_o, rays_d, num_steps=512, weight_thresh=1e-10, yol
     if out is None:
         out = torch.empty(N, T, 4, dtype=torch.float32, device=dev)
     assert out.shape == (N, T, 4) and out.dtype == torch.float32 and out.is_contiguous()
-    if infer_fusable(model) and not getattr(model, "uses_object_feature", False) and model.bg_radius <= 0:
+    if infer_fusable(model) and model.bg_radius <= 0:
         aabb = model.aabb_train if model.training else model.aabb_infer
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, model.min_near)
         rb = ray_block_default()
         enc_in, _ = fixed_sample(rays_o, rays_d, nears, fars, aabb, None, T, model.bound, ray_block=rb)
-        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb)
+        obj_feat = model.encode_object_feature(yolo_details, dev) if getattr(model, "uses_object_feature", False) else None
+        sigma, rgb = field_infer(model, enc_in, rays_d, dir_div=T, dir_block=rb, obj_feat=obj_feat)
         check(lib.foc_fixed_field_pack(ptr(sigma), ptr(rgb), ptr(nears), ptr(fars), None, None, 1.0, N, T, float(model.density_scale),
                                        float(weight_thresh), None, None, None, ptr(out), rb, stream_of(sigma)), "fixed_field_pack")
         return out

@@ -9,8 +9,15 @@ nerf/network_tcnn.py:451-681 (`NeRFNetwork` with a YOLO object feature in the co
 Differences from the tcnn file, all forced by the in-tree FFMLP (ffmlp.py:83-86) and recorded for parity purposes:
 FFMLP has at least two hidden layers, so `num_layers=2` means 32->64->64->16 like nerf/network_ff.py:31 (tcnn: one hidden
 layer); the 47-wide colour input is padded to 48 (tcnn pads to a multiple of 16 internally). tinycudann is an un-vendored,
-unpinned dependency of the reference: **parity unpinned by construction**; the tests pin this file to its own
+unpinned dependency of the reference: **parity unpinned by construction**; the tests pin this file to the CPU oracle's
+chain (oracle.grid_encode_forward -> ffmlp_forward -> oracle/torch_cpu_nerf.sh_encode_deg4 -> 48-wide ffmlp_forward), to its own
 torch expressions and to `network.NeRFNetwork` with a zero object feature.
+
+Fast paths (round 3): the object feature is ONE 16-vector per object, so its share of the colour network's first layer,
+W0[:, 31:47] . obj, is a constant per neuron. The fused training tail (`fixedstep._render_tail`), the whole-field inference kernel
+(`field.field_infer`) and the combiner's producer (`fixedstep.render_field4`) take it as the initial value of the layer-0 accumulators
+and otherwise run the 32-wide kernels of `network.NeRFNetwork`; the gradient of the encoded feature (for `yolo_feat_encoder`) and of
+W0[:, 31:47] follow from the column sum of the first layer's delta (csrc/ffmlp.hip, MlpHead).
 """
 import os
 
@@ -64,8 +71,13 @@ class NeRFNetwork(NeRFRenderer):
         """yolo_details = (mask, bbox, raw object feature [yolo_feats_encoder_dim]) -> [16] (network_tcnn.py:607-613)."""
         if yolo_details is None:
             return torch.zeros(self.yolo_encoding_dim, device=device)
-        raw = torch.as_tensor(yolo_details[2], device=device, dtype=torch.float32)
-        return self.yolo_feat_encoder(raw.unsqueeze(0)).squeeze(0)
+        def encode():
+            raw = torch.as_tensor(yolo_details[2], device=device, dtype=torch.float32)
+            return self.yolo_feat_encoder(raw.unsqueeze(0)).squeeze(0)
+        if torch.is_grad_enabled():
+            return encode()
+        from .field import scope_cached          # a staged render asks once per ray chunk: one encoding per half_cache_scope
+        return scope_cached(("object_feature", id(self), id(yolo_details[2])), yolo_details[2], encode)
 
     # ------------------------------------------------------------------ field
     def _fused_ok(self, x):
@@ -84,7 +96,10 @@ class NeRFNetwork(NeRFRenderer):
         obj = yolo_details[2] if yolo_details is not None else torch.zeros(self.yolo_encoding_dim, device=x.device)
         obj = torch.as_tensor(obj, device=x.device)
         if self._fused_ok(x) and obj.numel() == self.yolo_encoding_dim:
+            from .field import field_infer, infer_fusable
             from .head import sample_head, rgb_head
+            if not torch.is_grad_enabled() and infer_fusable(self):
+                return field_infer(self, (x + self.bound) / (2 * self.bound), d, obj_feat=obj)
             sigma, cin = sample_head(self._sigma_features(x), d, obj)
             return sigma, rgb_head(self.color_net.forward_padded(cin))
         h = self._sigma_features(x)

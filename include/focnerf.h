@@ -299,11 +299,15 @@ int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const
  * -> foc_rgb_head_forward; hidden_dim 64, (sigma_layers, color_layers) in {(2,2), (2,3), (3,3)}.
  * dir_block > 0: the rows stand in the block-interleaved sample order of foc_fixed_sample (ray_block = dir_block, dir_div =
  * samples per ray): row r uses direction min((r / (dir_block*dir_div))*dir_block + r % dir_block, n_dirs - 1). dir_block = 0:
- * n_dirs is not read. */
+ * n_dirs is not read.
+ * obj_feat (may be NULL): FOC's object-conditioned colour network, nerf/network_tcnn.py:611-640 — [16] fp16, the ENCODED object
+ * feature (yolo_feat_encoder output), one vector for every sample. The colour network's input row is then
+ * [SH16 | h[1:16] | obj_feat 16 | 0] (48 wide, W0 rows of 48 in color_weights); its share W0[:,31:47] . obj_feat enters as the
+ * initial value of the layer-0 accumulators (fp32), nothing else changes. Needs enc_planar = 1 and ReLU. */
 int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div,
                              uint32_t dir_block, uint32_t n_dirs, const void *sigma_weights, uint32_t sigma_layers, const void *color_weights,
                              uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B,
-                             float *sigma, float *rgb, void *stream);
+                             float *sigma, float *rgb, const void *obj_feat, void *stream);
 
 /* The colour network of a ray-ordered sample list without its materialised input (network_ff.py:104-108 builds
  * cin = [SH16(dir) | h[:,1:16] | 0] per sample, 64 B written and read twice): the kernels take the sigma network's output
@@ -314,14 +318,19 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
  * [grad_h0 | grad_cin[:,16:31]] with grad_h0 [B] fp16 (NULL = zeros) the density path's gradient of h[:,0]
  * (foc_fixed_tail_backward) — the row the sigma network's backward consumes, written once. hidden_dim 64, 2 or 3 layers.
  * out_width 16: outputs / grad are [B,16]; 4: only the columns that are ever read exist, outputs / grad are [B,4] (of the 16 padded
- * outputs of a 3-output network columns 0..2 are the rgb logits; the gradient of the others is zero by construction). */
+ * outputs of a 3-output network columns 0..2 are the rgb logits; the gradient of the others is zero by construction).
+ * obj_feat (may be NULL): FOC's object-conditioned colour network (nerf/network_tcnn.py:611-640; see foc_nerf_field_inference) —
+ * [16] fp16, cin = [SH16 | h[:,1:16] | obj_feat | 0] (48 wide; weights and grad_weights then have 48-wide W0 rows, the workspace is
+ * foc_ffmlp_backward_workspace_bytes(48, ...)). Same values as foc_ffmlp_forward / _backward on that cin up to fp32 summation order
+ * (the object columns' products are summed first). Backward: grad_weights[:, 31:47] = (sum_b delta_0[b,:]) (x) obj_feat, and
+ * grad_obj [16] fp32 (may be NULL) = W0[:,31:47]^T sum_b delta_0[b,:], the gradient the object-feature encoder consumes. */
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights,
                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
-                           void *outputs, uint32_t out_width, void *stream);
+                           void *outputs, uint32_t out_width, const void *obj_feat, void *stream);
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray,
                             const void *grad_h0, const void *weights, uint32_t B, uint32_t hidden_dim,
                             uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights,
-                            void *workspace, uint32_t out_width, void *stream);
+                            void *workspace, uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream);
 
 /* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
  * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the
@@ -407,16 +416,19 @@ int foc_fixed_head_backward(const void *h, const float *sigma, const float *tran
  * and foc_fixed_composite_backward + column 0 of foc_fixed_head_backward (written as grad_h0 [M] fp16) — the same bits as the pairs; the weights are not
  * re-read, their gradient never leaves the lane, and the backward does not read h (exp(clamp(h0,-15,15)) = clamp(sigma, ...)).
  * c_width 16: c and grad_c are [M,16] rows as above; 4: they are [M,4] (rgb logits + one pad column), the compact form
- * foc_color_head_forward / _backward exchange with out_width 4. */
+ * foc_color_head_forward / _backward exchange with out_width 4.
+ * ray_sumsq [N] (may be NULL): sum over the ray's samples of sigma^2 — what FOC's outside-mask density criterion
+ * ||sigma[rays outside the object mask]||_2 (nerf/renderer.py:163-165) needs from the samples; grad_sumsq [N] (may be NULL) is its
+ * gradient, added to the density path as 2 sigma grad_sumsq[ray] before trunc_exp's backward factor. */
 int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise,
                            const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh,
                            float *sigma, float *trans, float *weights, float *weights_sum, float *depth, float *image,
-                           uint32_t c_width, void *stream);
+                           uint32_t c_width, float *ray_sumsq, void *stream);
 int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const float *grad_depth, const void *c,
                             const float *sigma, const float *trans, const float *weights, const float *nears,
                             const float *fars, const float *noise, const float *bg_ray, float bg_scalar, uint32_t N,
                             uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width,
-                            void *stream);
+                            const float *grad_sumsq, void *stream);
 
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL

@@ -104,7 +104,7 @@ def test_reference_run_fixture_through_the_training_tail(name):
     sigma, trans, weights = (torch.empty(M, device="cuda") for _ in range(3))
     ws, depth, image = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
     check(lib.foc_fixed_tail_forward(ptr(h), ptr(c), ptr(nears), ptr(fars), None, None, 1.0, N, T, 1.0, 1e-10, ptr(sigma), ptr(trans), ptr(weights), ptr(ws),
-                                     ptr(depth), ptr(image), 4, stream_of(h)), "fixed_tail_forward")
+                                     ptr(depth), ptr(image), 4, None, stream_of(h)), "fixed_tail_forward")
     hit = g["nears"] < 1e30
     # (1) against the reference's own outputs, tolerance = fp16 quantisation of the logits
     np.testing.assert_allclose(to_np(ws), g["weights_sum"], rtol=0, atol=5e-3)
