@@ -59,16 +59,17 @@ OP_KERNELS = {
 }
 
 
-def pmc_traffic_bytes(op):
-    """HBM bytes per launch of `op` from the newest committed PMC summary (collected in separate rocprofv3 --pmc passes), or None."""
+def pmc_traffic_bytes(op, which="bench", kernels=None):
+    """HBM bytes per launch of `op` from the newest committed PMC summary of the `which` run (profiles/rNN_<which>_pmc_hbm.csv, collected
+    in separate rocprofv3 --pmc passes), or None."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_hbm.csv")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{which}_pmc_hbm.csv")))
     if not files:
         return None
     total, found = 0.0, False
     for row in csv.DictReader(open(files[-1])):
-        if any(k in row["kernel"] for k in OP_KERNELS.get(op, [])):
+        if any(k in row["kernel"] for k in (kernels or OP_KERNELS.get(op, []))):
             total += float(row["hbm_bytes_per_launch"])
             found = True
     return total if found else None
@@ -170,6 +171,86 @@ class KernelTimer:
             out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                          "avg_units": (sum(units) / len(units)) if units else None}
         return out
+
+
+class LibTimer:
+    """Event pairs around chosen C-ABI entry points (attributes of focnerf_amd._lib.lib), recorded on torch's current stream — the stream
+    the entry point launches on. `with LibTimer([...]) as t: ...; t.summary()` -> {name: (launches, avg_ms)}."""
+
+    def __init__(self, names):
+        self.names, self.records, self._orig = names, {}, {}
+
+    def __enter__(self):
+        from focnerf_amd._lib import lib
+        for name in self.names:
+            orig = getattr(lib, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _orig=orig, _name=name):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _orig(*a)
+                e.record()
+                self.records.setdefault(_name, []).append((s, e))
+                return r
+            setattr(lib, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        from focnerf_amd._lib import lib
+        for name, orig in self._orig.items():
+            setattr(lib, name, orig)
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {n: (len(r), sum(s.elapsed_time(e) for s, e in r) / len(r)) for n, r in self.records.items()}
+
+
+# C-ABI entry point -> (kernel name as rocprofv3 prints it, algorithmic bytes per sample: SURVEY.md §8d / DESIGN.md §4)
+RENDER_OPS = {
+    "foc_grid_encode_forward": ("k_grid_fwd_lbc", 588.0),            # 12 r + 512 gathered + 64 w
+    "foc_nerf_field_inference": ("k_nerf_infer", 64.0 + 16.0),       # planes 64 r; sigma 4 + rgb 12 w (directions: per ray)
+    "foc_fixed_render_inference": ("k_fs_render_infer_blk", 16.0),   # sigma + rgb r (image / depth: per ray)
+    "foc_fixed_sample": ("k_fs_sample", 12.0),                       # positions w
+}
+
+
+def render_roofline(model, view_rays, rkw, n_views=2):
+    """Per-kernel launch durations of the fixed-step render with every chunk on ONE stream (FOC_RENDER_STREAMS=1: with the default two
+    streams the kernels of neighbouring chunks overlap and an event pair sees both), and the roofline entry of the dominant one."""
+    old = os.environ.get("FOC_RENDER_STREAMS")
+    os.environ["FOC_RENDER_STREAMS"] = "1"
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            model.render(*view_rays[0], return_fields=False, **rkw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with LibTimer(list(RENDER_OPS)) as lt:
+                for i in range(n_views):
+                    model.render(*view_rays[i % len(view_rays)], return_fields=False, **rkw)
+                ks = lt.summary()
+            one_stream_s = (time.perf_counter() - t0) / n_views
+    finally:
+        if old is None:
+            os.environ.pop("FOC_RENDER_STREAMS", None)
+        else:
+            os.environ["FOC_RENDER_STREAMS"] = old
+    if not ks:
+        return None
+    chunks = max(v[0] for v in ks.values()) / n_views
+    units = VIEW * VIEW * NUM_STEPS / chunks                        # samples per launch (the last chunk of a view is shorter)
+    dom = max(ks, key=lambda k: ks[k][0] * ks[k][1])
+    kern, bpu = RENDER_OPS[dom]
+    achieved = bpu * units / (ks[dom][1] * 1e-3) / 1e9
+    total = sum(v[0] * v[1] for v in ks.values())
+    return {"kernel": f"{dom} = {kern}", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic_bytes(dom, which="render_fixed", kernels=[kern]), "avg_launch_ms": ks[dom][1], "units_per_launch": units,
+            "algorithmic_bytes_per_unit": bpu, "share_of_render_kernel_time": ks[dom][0] * ks[dom][1] / total,
+            "kernels_ms_per_chunk": {RENDER_OPS[k][0]: round(v[1], 4) for k, v in ks.items()}, "one_stream_s_per_view": one_stream_s,
+            "note": "events on the launch stream around the C-ABI call, every chunk on one stream (FOC_RENDER_STREAMS=1); the rays/s figure is the "
+                    "default two-stream render. The hash tables (24 MB fp16) are cache resident: the 512 gathered bytes per sample are L2 / "
+                    "Infinity-Cache traffic, `traffic` (profiles/*_render_fixed_pmc_hbm.csv) is what reaches HBM"}
 
 
 def build_model(bound, device, cuda_ray=False, seed=0):
@@ -342,7 +423,7 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS):
+def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True):
     """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (4096-ray chunks, packed
     per-sample fields), the chunks are exchanged by ray (all-to-all over xGMI), every rank selects + composites its ray slices for both
     backgrounds, one all-gather per view assembles the images. Timed against the same view with the field evaluation alone.
@@ -353,8 +434,8 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
     n_rays = n_side * n_side
     nears, fars = model["nears"], model["fars"]
 
-    def one_view():
-        return comb.render_view([fused_fn], n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk)
+    def one_view(ov=overlap):
+        return comb.render_view([fused_fn], n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk, overlap=ov)
 
     def eval_only():
         buf = torch.empty(chunk, T, 4, dtype=torch.float32, device=device)
@@ -378,7 +459,18 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
     barrier()
     el_eval = max_over_ranks(time.perf_counter() - t0) / views
     links = max(world - 1, 1)
+    el_other = None
+    if world > 1:                                          # the other exchange mode on the same box, for an A/B on real links
+        one_view(not overlap)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(views):
+            one_view(not overlap)
+        barrier()
+        el_other = max_over_ranks(time.perf_counter() - t0) / views
     out = {"metric": "combined_render_rays_per_sec", "value": n_rays / el, "unit": "rays/s", "objects": world, "object_rays_per_sec": world * n_rays / el,
+           "world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+           "overlap": bool(overlap), "s_per_view_other_exchange_mode": el_other,
            "s_per_view": el, "views": views, "view": f"{n_side}x{n_side}", "samples_per_ray": T, "backgrounds": 2,
            "field_eval_only_s_per_view": el_eval, "exchange_and_composite_share_of_field_eval": (el - el_eval) / el_eval if el_eval > 0 else None,
            "bytes_sent_per_view_per_gpu": int(sent),
@@ -452,6 +544,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="headline step through the torch glue of NeRFRenderer.run instead of csrc/fixedstep.hip")
     ap.add_argument("--dry-run-cpu", action="store_true", help="no GPU: gloo ranks, combined-render leg on injected CPU ops (launch / collective logic only)")
     ap.add_argument("--combined-views", type=int, default=2)
+    ap.add_argument("--combined-no-overlap", action="store_true", help="combined-render leg: wait for each chunk's all-to-all before evaluating the next chunk")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -542,6 +635,30 @@ def main():
     samples_per_step = NUM_RAYS * NUM_STEPS
     value = world * samples_per_step * args.steps / el
     progress(f"headline: {1000.0 * el / args.steps:.3f} ms/step")
+    # kernel-only step time (the optimizer is excluded or reported separately): a few more steps with an event pair around
+    # EVERY C-ABI call of the library — what the step costs in this library's kernels, the rest being torch's own (fused Adam, GradScaler
+    # unscale / inf check, fp16 <-> fp32 casts of parameters and gradients, fills, the loss)
+    try:
+        from focnerf_amd import _lib
+        names = [n for n, (_, a) in _lib.SIGNATURES.items() if a and a[-1] is _lib.c_vp and not n.endswith("_bytes")]
+        n_k = 5
+        with LibTimer(names) as lt:
+            m0 = torch.cuda.Event(enable_timing=True)
+            m1 = torch.cuda.Event(enable_timing=True)
+            m0.record()
+            for i in range(n_k):
+                train_step(model, opt, scaler, *batches[i % len(batches)], fused=fused, sched=sched)
+            m1.record()
+            ks_all = lt.summary()
+        lib_ms = sum(n * avg for n, avg in ks_all.values()) / n_k
+        step_stats["library_kernels_ms_per_step"] = lib_ms
+        step_stats["torch_native_ms_per_step"] = max(0.0, m0.elapsed_time(m1) / n_k - lib_ms)
+        step_stats["kernel_only_samples_per_sec"] = samples_per_step / (lib_ms * 1e-3)
+        step_stats["kernel_only_note"] = ("library_kernels = sum of event-timed C-ABI calls per step (every kernel of this library: sample, encoder fwd + "
+                                          "count, both MLPs fwd/bwd, tail fwd/bwd, grid backward); torch_native = the step's remaining GPU time "
+                                          "(Adam, GradScaler, casts, fills, loss), measured over 5 extra steps after the timed region")
+    except Exception as e:
+        step_stats["kernel_only_error"] = repr(e)
     result = {
         "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
@@ -622,6 +739,14 @@ def main():
             result["render"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel, "unit": "rays/s",
                                 "samples_per_sec": world * VIEW * VIEW * NUM_STEPS * args.render_views / rel, "views": args.render_views,
                                 "s_per_view": rel / args.render_views, "path": "fixed-step run(), 512 samples/ray, 4096-ray chunks, image + depth; views cycle through 8 camera poses"}
+            # the render half of BASELINE's metric inside `roofline` (the driver's record keeps `roofline` and `config` whole)
+            try:
+                rr = render_roofline(model, view_rays, rkw)
+                if rr is not None and "roofline" in result:
+                    rr.update({"metric": "render_rays_per_sec", "rays_per_sec": result["render"]["value"], "s_per_view": result["render"]["s_per_view"]})
+                    result["roofline"]["render"] = rr
+            except Exception as e:
+                result.setdefault("roofline", {})["render"] = {"error": repr(e)}
             # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 model.render(rays_o, rays_d, return_fields=True, **rkw)
@@ -761,7 +886,15 @@ def main():
                 return render_field4(obj_model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=obj_yolo, out=out)
             with torch.no_grad(), half_cache_scope():
                 result["combined_render"] = combined_render_leg(rank, world, device, {"nears": vn, "fars": vf}, args.combined_views, my_object, barrier,
-                                                                max_over_ranks)
+                                                                max_over_ranks, overlap=not args.combined_no_overlap)
+            cr = result["combined_render"]
+            # the N-rank half of BASELINE's metric inside `roofline` (the driver's record keeps `roofline` and `config` whole)
+            result.setdefault("roofline", {})["combined"] = {
+                "metric": "combined_render_rays_per_sec", "rays_per_sec": cr["value"], "object_rays_per_sec": cr["object_rays_per_sec"], "n_ranks": cr["world_size"],
+                "backend": cr["backend"], "objects": cr["objects"], "s_per_view": cr["s_per_view"], "field_eval_only_s_per_view": cr["field_eval_only_s_per_view"],
+                "bytes_sent_per_view_per_gpu": cr["bytes_sent_per_view_per_gpu"], "bound": "xgmi", "achieved": cr["xgmi"]["achieved_GBps_per_gpu"],
+                "peak": cr["xgmi"]["peak_GBps_per_gpu"], "unit": "GB/s", "frac": cr["xgmi"]["frac_of_peak"], "overlap": cr["overlap"],
+                "s_per_view_other_exchange_mode": cr["s_per_view_other_exchange_mode"]}
             result["combined_render"]["objects_network"] = "focnerf_amd.network_foc.NeRFNetwork (object-conditioned, 48-wide colour input), one per rank"
             if world == 1:
                 # the single-GPU form of the same job: K = 4 objects RESIDENT on one device (COMBINED.py reloads a checkpoint per object per view)

@@ -118,7 +118,44 @@ def _load():
     return lib
 
 
-lib = _load()
+class _Stream(ctypes.c_void_p):
+    """hipStream_t handle that remembers the device of the tensor it was taken for (`stream_of`)."""
+    device_index = None
+
+
+_multi_device = None        # torch.cuda.device_count() > 1, asked once (counting devices does not initialise the GPU)
+
+
+def _on_tensor_device(fn):
+    """Entry points taking a stream run with the device of THEIR tensors current. The library's own guard (csrc/common.h FocDeviceGuard)
+    reads the device from the stream handle, and torch's default stream is the null handle on every device — `cuda:1` tensors on their
+    default stream while `cuda:0` is current would launch on device 0 with device-1 pointers. The device therefore comes from the
+    tensor `stream_of` was called with. One-GPU processes skip the check."""
+    def call(*args):
+        global _multi_device
+        if _multi_device is None:
+            _multi_device = torch.cuda.device_count() > 1
+        if _multi_device and args:
+            idx = getattr(args[-1], "device_index", None)
+            if idx is not None and idx != torch.cuda.current_device():
+                with torch.cuda.device(idx):
+                    return fn(*args)
+        return fn(*args)
+    call.__name__ = getattr(fn, "__name__", "foc_call")
+    return call
+
+
+class _Lib:
+    """The loaded library with every stream-taking entry point wrapped by `_on_tensor_device`."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (_, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            setattr(self, name, _on_tensor_device(fn) if args and args[-1] is c_vp and not name.endswith("_bytes") else fn)
+
+
+lib = _Lib(_load())
 
 
 def check(rc, what=""):
@@ -137,7 +174,9 @@ def ptr(t):
 def stream_of(t=None):
     """hipStream_t of torch's current stream on the tensor's device."""
     dev = t.device if t is not None else None
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    s = _Stream(torch.cuda.current_stream(dev).cuda_stream)
+    s.device_index = dev.index if dev is not None and dev.index is not None else torch.cuda.current_device()
+    return s
 
 
 def require_cuda(*tensors):

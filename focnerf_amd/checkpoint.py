@@ -74,7 +74,19 @@ def load_checkpoint(model, path, map_location=None):
 def load_objects(paths, build_model, device):
     """COMBINED.py:592-618 re-reads one checkpoint per object per view (`self.load_checkpoint(self.ckpt)` inside the view loop); here
     every object's network is loaded once and stays resident (K x ~100 MB of parameters). `build_model()` -> a fresh network; returns
-    the list of eval-mode models in checkpoint order (the order decides ties in the per-sample select)."""
+    the list of eval-mode models in checkpoint order (the order decides ties in the per-sample select).
+
+    `device` must be the process's current GPU: one process drives one GPU (bench.py, the RCCL combine). Objects on OTHER GPUs of the
+    same process are served by the ops (they run with their tensors' device current, `_lib._on_tensor_device`, the extension shims'
+    FocStream) but that path has not run on a multi-GPU box yet (tests/test_gpu_edge_cases.py::test_ops_follow_their_tensors_device is
+    skipped on one GPU), so it has to be asked for: FOC_ALLOW_CROSS_DEVICE=1."""
+    import os
+    dev = torch.device(device)
+    if dev.type == "cuda" and torch.cuda.is_available():
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if idx != torch.cuda.current_device() and os.environ.get("FOC_ALLOW_CROSS_DEVICE") != "1":
+            raise RuntimeError(f"load_objects: device cuda:{idx} is not the current device (cuda:{torch.cuda.current_device()}); one process drives one "
+                               "GPU. Make it current (torch.cuda.set_device) or set FOC_ALLOW_CROSS_DEVICE=1 (unverified on multi-GPU hardware)")
     models = []
     for p in paths:
         m = build_model().to(device)

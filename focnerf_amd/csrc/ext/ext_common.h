@@ -7,6 +7,7 @@
 #pragma once
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
 #include <map>
 #include <tuple>
 #include "../../../include/focnerf.h"
@@ -18,7 +19,18 @@
 #define FOC_CHECK_IS_HALF(x) TORCH_CHECK((x).scalar_type() == at::ScalarType::Half, #x " must be a Half tensor")
 #define FOC_CHECK_IS_FLOAT(x) TORCH_CHECK((x).scalar_type() == at::ScalarType::Float, #x " must be a float32 tensor")
 
-static inline void *foc_stream(const at::Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+static inline void *foc_stream_handle(const at::Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// The stream argument of a C-ABI call: torch's current stream on the TENSOR's device, and — for as long as the temporary lives, i.e. until
+// the call it is an argument of has returned — that device made current. torch's default stream is the null handle on every device, so
+// the library cannot learn the device from the handle (csrc/common.h FocDeviceGuard): cuda:1 tensors on their default stream while
+// cuda:0 is current would otherwise launch on device 0.
+struct FocStream {
+    c10::DeviceGuard guard;          // the generic guard: ROCm builds of torch register their HIP guard under the "cuda" device type
+    void *st;
+    explicit FocStream(const at::Tensor &t) : guard(t.device()), st(foc_stream_handle(t)) {}
+    operator void *() const { return st; }
+};
+static inline FocStream foc_stream(const at::Tensor &t) { return FocStream(t); }
 static inline void foc_ok(int rc, const char *what) { TORCH_CHECK(rc == 0, "focnerf_amd ", what, ": ", foc_last_error(), " (code ", rc, ")"); }
 static inline int foc_dtype(const at::Tensor &t) {
     if (t.scalar_type() == at::ScalarType::Float) return FOC_F32;
@@ -34,7 +46,7 @@ template <typename T> static inline T *foc_optr(const at::optional<at::Tensor> &
 static inline void *foc_scratch(const char *key, uint64_t bytes, const at::Tensor &like) {
     static std::map<std::tuple<std::string, int, void *>, at::Tensor> bufs;
     static std::vector<at::Tensor> retired;
-    auto k = std::make_tuple(std::string(key), (int)like.device().index(), foc_stream(like));
+    auto k = std::make_tuple(std::string(key), (int)like.device().index(), foc_stream_handle(like));
     auto it = bufs.find(k);
     if (it == bufs.end() || (uint64_t)it->second.numel() < bytes) {
         if (it != bufs.end()) retired.push_back(it->second);

@@ -784,7 +784,8 @@ template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-    bool align_corners, uint32_t interp, bool grad_bl, uint32_t fact_mask, GbSizes sz) {
+    bool align_corners, uint32_t interp, bool grad_bl, uint32_t fact_mask, GbSizes sz, uint32_t l_begin, uint32_t l_end) {
+    // [l_begin, l_end): the levels this launch scatters (all of them, or one level group of gb_run's pipelined form)
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
     // a record carries the two corners along x of one (y, z) corner pair: 4 per point, 5 when one pair straddles a segment boundary
     // (two pairs of a point cannot: their rows differ by less than 8192 and not by a multiple of it on a dense level, and a hashed
@@ -811,7 +812,12 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
     __shared__ uint32_t s_grad[2][GW][GB_PM_TILE];
     auto fetch_grad = [&](uint32_t level) {                 // wave 0 only
-        if (level < L) {
+#ifdef FOC_TIMING_NO_GRAD_PLANES
+        // TIMING BUILD (tools/ab_no_grad_planes.sh; results wrong): the scatter reads no gradient planes — the upper bound of what feeding it
+        // from the sigma network's backward (no [L,B,C] planes in memory) could gain, with the fusion itself taken as free
+        return;
+#endif
+        if (level < l_end) {
             const uint32_t *gbase = reinterpret_cast<const uint32_t *>(grad);
 #pragma unroll 4
             for (uint32_t k = 0; k < GB_PM_TILE / 64u; k++) {
@@ -834,7 +840,7 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     // wave 0 keeps the (base, end) pair of the level about to be processed in registers
     uint32_t nsb = 0, nw0 = 0, nw1 = 0;
     auto fetch_bases = [&](uint32_t level) {
-        if (threadIdx.x < GB_MAX_SEGS && level < L) {
+        if (threadIdx.x < GB_MAX_SEGS && level < l_end) {
             const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
             const uint32_t sb = hdr->base[slot];           // wg_base holds the prefix inside the slot
             const uint32_t wi = slot * n_wg + blockIdx.x;      // < 2^26 (gb_check: B * 8 * L < 2^32); a 32-bit offset from the scalar base keeps one register live
@@ -858,18 +864,18 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         gb[pbn][threadIdx.x] = nb0 - (incl - hc);
         if (threadIdx.x == GB_MAX_SEGS - 1) pre[pbn][GB_MAX_SEGS] = incl;
     };
-    fetch_bases(0);
-    if (threadIdx.x < GB_MAX_SEGS) { if (L) setup_tables(0u); fetch_bases(1); fetch_grad(0); }
+    fetch_bases(l_begin);
+    if (threadIdx.x < GB_MAX_SEGS) { if (l_begin < l_end) setup_tables(l_begin & 1u); fetch_bases(l_begin + 1u); fetch_grad(l_begin); }
     // The per-level parameters (scale, resolution, rows of the level) come out of the KERNEL ARGUMENTS with a scalar index: as vector
     // loads (`offsets[level]` from memory, `lv.scale[level]` with the level in a VGPR) each of them was followed by `s_waitcnt vmcnt(0)`,
     // which on gfx950 also waits for the gradient prefetch just issued and for every copy-out store of the level before.
-    for (uint32_t level_v = 0; level_v < L; level_v++) {
+    for (uint32_t level_v = l_begin; level_v < l_end; level_v++) {
         {
         const uint32_t level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level_v);
         const uint32_t pb = level & 1u;
         if (threadIdx.x < GB_MAX_SEGS) __builtin_amdgcn_s_waitcnt(0x0F70);       // wave 0: this level's gradients (and bases) have landed: vmcnt(0), issued a level ago
         foc_lds_barrier();
-        if (threadIdx.x < GB_MAX_SEGS && level + 1u < L) { setup_tables(pb ^ 1u); fetch_bases(level + 2u); fetch_grad(level + 1u); }
+        if (threadIdx.x < GB_MAX_SEGS && level + 1u < l_end) { setup_tables(pb ^ 1u); fetch_bases(level + 2u); fetch_grad(level + 1u); }
         float g[2];
         if constexpr (sizeof(T) == 2) {
             const uint32_t gw = s_grad[pb][0][threadIdx.x];
@@ -878,6 +884,9 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         } else {
             g[0] = __uint_as_float(s_grad[pb][0][threadIdx.x]); g[1] = __uint_as_float(s_grad[pb][GW - 1][threadIdx.x]);
         }
+#ifdef FOC_TIMING_NO_GRAD_PLANES
+        g[0] = 0.25f * (float)((threadIdx.x & 7u) + 1u); g[1] = -0.125f;     // finite stand-ins (the LDS words were never loaded)
+#endif
         if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
         const bool fact = sizeof(T) == 2 && ((fact_mask >> level) & 1u) != 0u;      // kernel-uniform per level (gb_fact_mask)
         if (fact) {
@@ -1000,7 +1009,9 @@ __device__ __forceinline__ unsigned long long gb_half_to_fixed(uint32_t h) {
 #define GB_RTHREADS 1024u
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
-                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L, uint32_t fact_mask) {
+                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L, uint32_t fact_mask,
+                                                             uint32_t l_begin, uint32_t l_end) {
+    // [l_begin, l_end): the levels whose chunks this launch reduces (all of them, or one level group of gb_run's pipelined form)
     // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64), one PLANE per channel: with the two channels
     // of a row side by side a wave instruction (one channel of 64 random rows) could only ever touch every other pair of banks —
     // half of the LDS's banks idle, twice the conflict cycles; planes spread a channel's 64 addends over all 64 banks
@@ -1008,11 +1019,11 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     unsigned long long *acci = reinterpret_cast<unsigned long long *>(acc);
     __shared__ uint32_t s_bad[GB_SEG / 32];        // fp16 tables: rows that received an inf/NaN addend (an overflowed AMP step) -> NaN out
     __shared__ uint32_t s_slot, s_lo, s_hi;
-    const uint32_t n = L * GB_MAX_SEGS;
+    const uint32_t n_lo = l_begin * GB_MAX_SEGS, n = l_end * GB_MAX_SEGS;
     const uint32_t total_chunks = hdr->chunk_prefix[n];
     // (one workgroup per chunk; a persistent form — one workgroup per CU walking the chunks with the grid's stride — measured 263 vs
     // 256 us, and with larger chunks worse: the dynamic dispatch balances the uneven chunks better than a stride does)
-    const uint32_t chunk_id = blockIdx.x;
+    const uint32_t chunk_id = blockIdx.x + hdr->chunk_prefix[n_lo];
     if (chunk_id >= total_chunks) return;
     {
     // Which (level, segment) slot and which chunk of it this workgroup owns: the slot with chunk_prefix[slot] <= blockIdx.x < chunk_prefix[slot + 1]
@@ -1020,7 +1031,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     // thread 0's eleven dependent loads of a binary search (no measurable difference: the header sits in L2; kept for the shorter chain).
     if (threadIdx.x == 0) { s_slot = 0u; s_lo = 0u; s_hi = 0u; }      // a header that matches nothing (not this launch's) reduces nothing
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += GB_RTHREADS) {
+    for (uint32_t i = n_lo + threadIdx.x; i < n; i += GB_RTHREADS) {
         const uint32_t p0 = hdr->chunk_prefix[i], p1 = hdr->chunk_prefix[i + 1];
         const uint32_t cnt = hdr->counts[i];
         const uint64_t b0 = hdr->base[i];
@@ -1335,8 +1346,11 @@ static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
     if (on < 0) { const char *e = getenv("FOC_GRID_FUSE_SMALL"); on = e ? atoi(e) : 1; }
     if (!on) return 0u;
     const uint32_t finest = on > 1 ? (uint32_t)on : 160u;            // a value above 1 is taken as the resolution threshold (A/B runs)
+    static int cap = -1;                                             // FOC_GRID_FUSE_CAP: most levels in the shared group (A/B runs; default L / 2)
+    if (cap < 0) { const char *e = getenv("FOC_GRID_FUSE_CAP"); cap = e ? atoi(e) : 0; }
+    const uint32_t most = cap > 0 ? (uint32_t)cap : L / 2;
     uint32_t lc = 0;
-    while (lc < L / 2 && lv.resolution[lc] <= finest) lc++;
+    while (lc < most && lc < L && lv.resolution[lc] <= finest) lc++;
     return lc >= 2u ? lc : 0u;
 }
 
@@ -1547,6 +1561,42 @@ static uint32_t gb_fact_mask(uint32_t L, const GeLevels &lv, const int32_t *offs
     return m;
 }
 
+// level groups of the pipelined form: cuts[0] = 0 < ... < cuts[n] = L from FOC_GB_LEVEL_SPLITS (comma-separated first levels of groups 1..n-1)
+static uint32_t gb_level_groups(uint32_t L, uint32_t *cuts) {
+    uint32_t n = 0;
+    cuts[n++] = 0;
+    const char *e = getenv("FOC_GB_LEVEL_SPLITS");         // read per call: tests and A/B runs switch it inside one process
+    if (e) {
+        const char *p = e;
+        while (*p && n < GE_MAX_LEVELS) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v > (long)cuts[n - 1] && v < (long)L) cuts[n++] = (uint32_t)v;
+            p = *end ? end + 1 : end;
+        }
+    }
+    cuts[n] = L;
+    return n;
+}
+static int gb_group_streams() { const char *e = getenv("FOC_GB_GROUP_STREAMS"); return e ? atoi(e) : 1; }
+// one side stream + events per device for the two-stream form (created on first use, kept for the life of the process)
+struct GbSide { hipStream_t stream; hipEvent_t ev[GE_MAX_LEVELS]; hipEvent_t join; };
+static GbSide *gb_side(hipStream_t st) {
+    static GbSide sides[16];
+    static bool made[16];
+    int dev = 0;
+    (void)st;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!made[dev]) {
+        if (hipStreamCreateWithFlags(&sides[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (uint32_t i = 0; i < GE_MAX_LEVELS; i++) if (hipEventCreateWithFlags(&sides[dev].ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sides[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return &sides[dev];
+}
+
 template <typename T>
 static int gb_run(const void *grad, const float *inputs, const int32_t *offsets, void *grad_emb, uint32_t B, uint32_t L, const GeLevels &lv,
                   uint32_t gridtype, bool ac, uint32_t interp, bool bl, void *workspace, bool counted, uint32_t fact_mask, const GbSizes &sz, hipStream_t st) {
@@ -1560,12 +1610,35 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
         const int rc = gb_count(inputs, offsets, B, L, lv, gridtype, ac, interp, sizeof(T) == 2 ? FOC_F16 : FOC_F32, workspace, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
-                       interp, bl, fact_mask, sz);
-    FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
-    const uint32_t ub = (uint32_t)((max_recs + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;      // chunks in the worst case
-    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L, fact_mask);
-    FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
+    // Level groups (FOC_GB_LEVEL_SPLITS="9,11,14": groups [0,9) [9,11) [11,14) [14,L)): scatter and reduce one group of levels at a time, so
+    // that a group's records (<= ~200 MB) are still in the 256 MiB Infinity Cache when the reduce reads them — the reduce of the whole
+    // batch streams 0.72 GB that fell out of it at 3.1 TB/s. FOC_GB_GROUP_STREAMS=2 runs the reduces on a side stream of
+    // the library, next to the following group's scatter. Default: one group (the measured A/B is in DESIGN.md).
+    uint32_t cuts[GE_MAX_LEVELS + 2];
+    uint32_t n_groups = gb_level_groups(L, cuts);
+    const int two_streams = n_groups > 1 && gb_group_streams() == 2;
+    GbSide *side = two_streams ? gb_side(st) : nullptr;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        const uint32_t l0 = cuts[g], l1 = cuts[g + 1];
+        hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
+                           interp, bl, fact_mask, sz, l0, l1);
+        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+        const uint32_t ub = (uint32_t)(((uint64_t)B * 5u * (l1 - l0) + GB_CHUNK - 1) / GB_CHUNK) + (l1 - l0) * GB_MAX_SEGS;      // chunks in the worst case
+        hipStream_t rs = st;
+        if (side) {
+            if (hipEventRecord(side->ev[g], st) != hipSuccess || hipStreamWaitEvent(side->stream, side->ev[g], 0) != hipSuccess) {
+                foc_set_error("grid_encode_backward: event fork failed"); return FOC_E_LAUNCH;
+            }
+            rs = side->stream;
+        }
+        hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, rs, hdr, recs, max_recs, offsets, (T *)grad_emb, L, fact_mask, l0, l1);
+        FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
+    }
+    if (side) {
+        if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
+            foc_set_error("grid_encode_backward: event join failed"); return FOC_E_LAUNCH;
+        }
+    }
     return FOC_OK;
 }
 

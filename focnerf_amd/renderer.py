@@ -325,7 +325,14 @@ class NeRFRenderer(nn.Module):
         densities = rgbs = None
         want_fields = kwargs.get("return_fields")
         if (not self.training) if want_fields is None else want_fields:
-            T = int(kwargs.get("num_steps", 512)) + int(kwargs.get("upsample_steps", 0))
+            # samples per ray of the dispatched run(): its own defaults where the caller passed none (the view buffers are made before
+            # the first chunk so that a fused path can write into them in place; a chunk that returns another T raises below)
+            import inspect
+            params = inspect.signature(type(self).run).parameters
+            defaults = {k: params[k].default for k in ("num_steps", "upsample_steps") if k in params and params[k].default is not inspect.Parameter.empty}
+            base = inspect.signature(NeRFRenderer.run).parameters
+            T = int(kwargs.get("num_steps", defaults.get("num_steps", base["num_steps"].default))) + \
+                int(kwargs.get("upsample_steps", defaults.get("upsample_steps", base["upsample_steps"].default)))
             densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
         import contextlib
         from .field import half_cache_scope
@@ -343,17 +350,24 @@ class NeRFRenderer(nn.Module):
                 sides = _side_streams(dev, n_streams)
                 for st in sides:
                     st.wait_stream(main)
+                    # the view's buffers were allocated on the caller's stream and are written on the side streams: the caching allocator must
+                    # not hand their memory out again before the side streams' work on them is done, whatever path leaves this function
+                    for buf in (depth, image, densities, rgbs):
+                        if buf is not None:
+                            buf.record_stream(st)
             chunk = 0
-            for b in range(B):
-                for lo in range(0, N, max_ray_batch):
-                    hi = min(lo + max_ray_batch, N)
-                    # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
-                    into = (depth[b, lo:hi], image[b, lo:hi]) + ((densities[b, lo:hi], rgbs[b, lo:hi]) if densities is not None else ())
-                    with (torch.cuda.stream(sides[chunk % n_streams]) if sides else contextlib.nullcontext()):
-                        part = self._render_chunk(rays_o, rays_d, b, lo, hi, yolo_details, into, kwargs)
-                    chunk += 1
-            for st in sides:
-                main.wait_stream(st)
+            try:
+                for b in range(B):
+                    for lo in range(0, N, max_ray_batch):
+                        hi = min(lo + max_ray_batch, N)
+                        # a fused path may write straight into the view's buffers (`_out`); anything else is copied in
+                        into = (depth[b, lo:hi], image[b, lo:hi]) + ((densities[b, lo:hi], rgbs[b, lo:hi]) if densities is not None else ())
+                        with (torch.cuda.stream(sides[chunk % n_streams]) if sides else contextlib.nullcontext()):
+                            part = self._render_chunk(rays_o, rays_d, b, lo, hi, yolo_details, into, kwargs)
+                        chunk += 1
+            finally:
+                for st in sides:                                              # also when a chunk raised: the caller's stream must not run ahead of
+                    main.wait_stream(st)                                      # side-stream kernels that still write the view's buffers
         out = {'depth': depth, 'image': image, 'timing': part.get('timing')}
         if densities is not None and 'densities' in part:
             out['densities'], out['rgbs'] = densities, rgbs
@@ -368,6 +382,9 @@ class NeRFRenderer(nn.Module):
         if part['image'].data_ptr() != into[1].data_ptr():
             into[1].copy_(part['image'].view(into[1].shape))
         if 'densities' in part and len(into) == 4:
+            if part['densities'].numel() != into[2].numel():
+                raise RuntimeError(f"staged render: run() returned {part['densities'].numel() // max(1, into[0].numel())} samples per ray, the view buffers "
+                                   f"hold {into[2].numel() // max(1, into[0].numel())} (pass num_steps / upsample_steps to render())")
             if part['densities'].data_ptr() != into[2].data_ptr():
                 into[2].copy_(part['densities'].view(into[2].shape))
             if part['rgbs'].data_ptr() != into[3].data_ptr():

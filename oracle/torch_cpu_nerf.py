@@ -340,6 +340,10 @@ def time_baseline(render_budget_s=10.0, train_steps=1, train_rays=512, side=400,
     return {"config": "configs[0]: nerf/network.py topology (hash grid L16 C2 2^19 + nn.Linear sigma 32-64-16 + SH16 + colour 31-64-64-3), fp32, "
                       f"fixed-step renderer num_steps={num_steps}, bound {bound}, torch {torch.__version__} CPU ops",
             "kind": "port", "cores": threads, "cpu_model": cpu,
+            "extrapolated": True,
+            "protocol": f"BOUNDED SAMPLE, rates extrapolated: BASELINE.md section 2 asks for the median of 5 full {chunk}-ray steps and a whole "
+                        f"{side}x{side} view; here {train_steps} step(s) of {train_rays} rays and the chunks that fit {render_budget_s:.0f} s are timed "
+                        "(same per-sample work) so that the default bench run finishes in minutes",
             "render": {"rays_per_sec": done / el_r, "samples_per_sec": done * num_steps / el_r, "unit": "rays/s",
                        "sample": f"{done} rays ({done // chunk} chunks of {chunk}) of a {side}x{side} view x {num_steps} samples in {el_r:.1f} s; "
                                  f"whole view = {n_view} rays -> {n_view / (done / el_r):.0f} s at this rate"},

@@ -56,6 +56,17 @@ def test_cpu_tensors_raise_like_torch_check():
     mods["_ffmlp"].free_splitk()
     with pytest.raises(TypeError):                                   # pybind11 argument checking: wrong arity is a TypeError, as with the reference module
         mods["_raymarching"].packbits(torch.zeros(8))
+    # _raymarching: the reference's functions check nothing; a CPU tensor must not reach a kernel as a bad pointer
+    rm = mods["_raymarching"]
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.near_far_from_aabb(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(6), 4, 0.2, torch.zeros(4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.packbits(torch.zeros(64), 8, 0.5, torch.zeros(8, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.composite_rays_train_forward(torch.zeros(8), torch.zeros(8, 3), torch.zeros(8, 2), torch.zeros(2, 3, dtype=torch.int32), 8, 2, 1e-4, torch.zeros(2), torch.zeros(2),
+                                        torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.morton3D(torch.zeros(4, 3, dtype=torch.int32), 4, torch.zeros(4, dtype=torch.int32))
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
@@ -185,3 +196,28 @@ def test_shims_match_the_ctypes_backend_bit_for_bit():
             torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=2e-3)
     with pytest.raises(RuntimeError, match="hidden_dim"):
         mods["_ffmlp"].ffmlp_forward(xin, w, Bp, 32, 16, 48, 2, 0, 6, fb, y)          # the library's message comes through as a RuntimeError
+
+
+@pytest.mark.gpu
+def test_raymarching_shim_rejects_wrong_dtype_and_layout():
+    """The reference's _raymarching checks nothing and dispatches on the scalar type; its wrappers only ever hand it contiguous fp32. The
+    shim refuses anything else with a RuntimeError instead of reinterpreting half / double bits as fp32 or walking a strided tensor."""
+    rm = _mods()["_raymarching"]
+    N = 64
+    o = torch.zeros(N, 3, device="cuda")
+    d = torch.nn.functional.normalize(torch.ones(N, 3, device="cuda"), dim=-1)
+    aabb = torch.tensor([-1., -1., -1., 1., 1., 1.], device="cuda")
+    nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    rm.near_far_from_aabb(o, d, aabb, N, 0.2, nears, fars)                                  # the valid call
+    with pytest.raises(RuntimeError, match="float32"):
+        rm.near_far_from_aabb(o.half(), d, aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="float32"):
+        rm.near_far_from_aabb(o, d.double(), aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        rm.near_far_from_aabb(torch.zeros(3, N, device="cuda").t(), d, aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        rm.morton3D(torch.zeros(N, 3, device="cuda"), N, torch.zeros(N, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError, match="uint8"):
+        rm.packbits(torch.zeros(64, device="cuda"), 8, 0.5, torch.zeros(8, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        rm.near_far_from_aabb(o.cpu(), d, aabb, N, 0.2, nears, fars)

@@ -165,8 +165,9 @@ def test_graph_keeps_its_scratch_when_a_later_call_needs_more():
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_ops_follow_their_tensors_device():
-    """An op on cuda:1 tensors while cuda:0 is current (K resident objects spread over the GPUs of one process): the entry points make
-    the device of their stream current (csrc/common.h FocDeviceGuard) and restore it."""
+    """An op on cuda:1 tensors while cuda:0 is current (K resident objects spread over the GPUs of one process): the Python binding runs
+    every entry point with the device of ITS TENSORS current (`_lib._on_tensor_device`; torch's default stream is the null handle on every
+    device, so the library's own FocDeviceGuard cannot learn the device from the stream) and restores the caller's."""
     from focnerf_amd.network import NeRFNetwork
     torch.manual_seed(0)
     m0 = NeRFNetwork(bound=1).to("cuda:0").eval()

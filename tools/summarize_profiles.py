@@ -32,7 +32,27 @@ def counter_avg(dirname, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
+def pmc_hbm_csv(fetch_dir, write_dir, dst):
+    fetch = counter_avg(fetch_dir, "FETCH_SIZE")
+    write = counter_avg(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        f_kb, n = fetch.get(k, (0.0, 0))
+        w_kb, nw = write.get(k, (0.0, 0))
+        fb, wb = 2.0 * f_kb * 1024.0, w_kb * 1024.0
+        rows.append((k, max(n, nw), round(f_kb), round(fb), round(wb), round(fb + wb)))
+    rows.sort(key=lambda r: -r[5])
+    with open(dst, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_raw_avg", "fetch_bytes_corrected_x2", "write_bytes", "hbm_bytes_per_launch"])
+        w.writerows(rows)
+
+
 def main():
+    if sys.argv[1] == "--pmc-only":          # summarize_profiles.py --pmc-only <fetch dir> <write dir> <dst csv>
+        pmc_hbm_csv(sys.argv[2], sys.argv[3], sys.argv[4])
+        print("wrote", sys.argv[4])
+        return
     out, tag = sys.argv[1], sys.argv[2]
     stats = newest(os.path.join(out, "stats", "**", "*kernel_stats.csv"))
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
