@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import lib, ptr, stream_of, check, require_cuda, dtype_code
+from ._lib import lib, ptr, stream_of, check, require_cuda, dtype_code, raw_stream
 
 
 def _f32(*ts):
@@ -45,7 +45,7 @@ class _Scratch:
 
     def get(self, key, nbytes, device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        k = (key, idx, torch.cuda.current_stream(idx).cuda_stream)
+        k = (key, idx, raw_stream(idx))
         capturing = torch.cuda.is_current_stream_capturing()
         ent = self._bufs.get(k)
         if ent is None or ent[0].numel() < nbytes:

@@ -497,6 +497,7 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
+    if (index < 0) return;             // a list entry marked dead (-1, as composite_rays leaves them): its slots stay zero = "terminated"
     const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
     const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
@@ -519,6 +520,178 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
     }
 }
 
+// ---------------------------------------------------------------- R9, one ray per lane, K lattice points per round
+// With hundreds of thousands of rays alive an iteration asks every ray for ONE sample: a ray inside the object evaluates one cell and is
+// done, but every iteration also has rays that have just left the object and walk ~100 empty cells to the far side of the box — a chain
+// of ~100 dependent bitfield lookups that their whole wave waits for (51 us per launch, of which the cell evaluations proper are ~3 us).
+// The values t can take are a fixed lattice per ray (see k_march_count_wave), so a lane can look K lattice points AHEAD with K
+// independent loads and then replay the loop's control flow on the K results: visits, emissions and voxel-exit skips are those of the
+// serial loop (raymarching.cu:745-795), bit for bit, with chains K times shorter. The first window is one point wide (the common case
+// costs what it did); every later window K = 8.
+struct RmWalk { float t, last_t, tt; uint32_t step; bool skipping, done; };
+
+template <int K, bool MED3>
+__device__ __forceinline__ void rm_window(RmWalk &w, const uint8_t *__restrict__ grid, const RmParams &p, float ox, float oy, float oz, float dx, float dy,
+                                          float dz, float rdx, float rdy, float rdz, float far, uint32_t n_step, float *__restrict__ px, float *__restrict__ pd,
+                                          float *__restrict__ pl) {
+    float L[K], cx[K], cy[K], cz[K], cdt[K], ex[K];
+    bool occ[K];
+    float t = w.t;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        L[j] = t;
+        const float raw = t * p.dt_gamma;
+        t += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        RmCell c;
+        occ[j] = rm_cell(grid, p, ox, oy, oz, dx, dy, dz, L[j], c);
+        cx[j] = c.x; cy[j] = c.y; cz[j] = c.z; cdt[j] = c.dt;
+        ex[j] = rm_skip_target(p, c, L[j], dx, dy, dz, rdx, rdy, rdz);
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (w.done || (w.skipping && L[j] < w.tt)) continue;                 // past the loop's end / still inside `do { t += dt } while (t < tt)`
+        w.skipping = false;
+        if (!(L[j] < far) || w.step >= n_step) { w.done = true; continue; }    // the loop condition of raymarching.cu:745
+        if (occ[j]) {
+            const float t_new = L[j] + cdt[j];
+            px[w.step * 3] = cx[j]; px[w.step * 3 + 1] = cy[j]; px[w.step * 3 + 2] = cz[j];
+            pd[w.step * 3] = dx; pd[w.step * 3 + 1] = dy; pd[w.step * 3 + 2] = dz;
+            pl[w.step * 2] = cdt[j]; pl[w.step * 2 + 1] = t_new - w.last_t;
+            w.last_t = t_new;
+            w.step++;
+        } else { w.skipping = true; w.tt = ex[j]; }        // at least one advance: the next candidate is point j + 1
+    }
+    w.t = t;
+}
+
+template <bool MED3>
+__global__ void __launch_bounds__(64) k_march_rays_spec(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    if (index < 0) return;             // dead list entry (see k_march_rays)
+    const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float *px = xyzs + (uint64_t)n * n_step * 3, *pd = dirs + (uint64_t)n * n_step * 3, *pl = deltas + (uint64_t)n * n_step * 2;
+    const float far = fars[index];
+    RmWalk w;
+    w.t = rays_t[index];
+    w.t = fmaf(rm_clamp(w.t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], w.t);
+    w.last_t = w.t; w.tt = 0.0f; w.step = 0; w.skipping = false; w.done = false;
+    rm_window<1, MED3>(w, grid, p, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, n_step, px, pd, pl);
+    for (uint32_t round = 0; round < RM_MAX_ROUNDS && !w.done; round++)
+        rm_window<8, MED3>(w, grid, p, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, n_step, px, pd, pl);
+}
+
+// ---------------------------------------------------------------- R9, G lanes per ray
+// k_march_rays above is a chain of dependent bitfield lookups per ray, and a render iteration has few rays left alive (the host loop keeps
+// live x n_step <= N, so most iterations march ~N/8 rays by 8 samples: about one wave per SIMD, nothing to hide a lookup's latency
+// behind, and the launch lasts as long as its longest ray — one that leaves the object and walks ~100 cells to the box's far side).
+// As in k_march_count_wave the values t can take are a fixed lattice per ray (both branches of the loop advance t by
+// clamp(t dt_gamma, dt_min, dt_max), raymarching.cu:758-795), so G consecutive lattice points of a ray are generated on G lanes (the
+// recurrence itself, each value entering at the row's last lane through a DPP row_shl:1 move), looked up with ONE round of loads, and the
+// loop's control flow is replayed on the G-bit masks of the ray's lane group: an occupied visited point emits (position, direction, dt,
+// t_new - last_t) into the ray's next slot and moves on by one lane; an empty one moves to the first lane whose t is not below the voxel
+// exit, carried into the next G points when there is none. Same visits, same samples, bit for bit — with chains G times shorter. A full
+// wave per ray (G = 64, the training kernel's form) would spend 64 recurrence steps for the 8 samples an iteration asks for; G = 16
+// (one DPP row, 4 rays per wave) generates what a burst of 8 typically consumes in one or two rounds.
+#define RM_ROW_MAX_ROUNDS (1u << 14)                       // x 16 lattice points: far beyond any real ray; makes the loop finite whatever the inputs
+template <bool MED3>
+__global__ void __launch_bounds__(256) k_march_rays_row(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    constexpr uint32_t G = 16u;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & (G - 1u), gbase = lane & ~(G - 1u), gshift = gbase;
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) / G;
+    const int listed = n < n_alive ? rays_alive[n] : -1;
+    const bool have = listed >= 0;     // beyond the list, or an entry marked dead (-1): nothing to march
+    const int index = have ? listed : 0;
+    const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float far = fars[index];
+    float t_cur = rays_t[index];
+    t_cur = fmaf(rm_clamp(t_cur * p.dt_gamma, p.dt_min, p.dt_max), noises[have ? n : 0u], t_cur);
+    float last_t = t_cur;
+    float *px = xyzs + (uint64_t)n * n_step * 3, *pd = dirs + (uint64_t)n * n_step * 3, *pl = deltas + (uint64_t)n * n_step * 2;
+    uint32_t step = 0;
+    bool skipping = false, live = have;                    // live: this ray's loop has not ended (uniform over the ray's G lanes)
+    float skip_to = 0.0f;
+    const uint32_t below = (1u << sub) - 1u;
+    for (uint32_t round = 0; round < RM_ROW_MAX_ROUNDS && __builtin_amdgcn_ballot_w64(live) != 0ull; round++) {
+        float T = t_cur, t_next = t_cur;
+#pragma unroll
+        for (uint32_t j = 0; j < G; j++) {
+            T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x101, 0xf, 0xf, false));
+            const float raw = t_next * p.dt_gamma;
+            t_next += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
+        }
+        // every lane of the wave evaluates its lattice point (rays that have ended idle along: their results are not looked at)
+        RmCell c;
+        const bool occupied_here = rm_cell(grid, p, ox, oy, oz, dx, dy, dz, T, c);
+        const float exit_here = rm_skip_target(p, c, T, dx, dy, dz, rdx, rdy, rdz);
+        const float t_new = T + c.dt;                      // the loop's `t += dt` of an emitting visit (== the next lattice point)
+        const uint32_t in_range = (uint32_t)(__ballot(T < far) >> gshift) & 0xFFFFu;
+        const uint32_t occ = (uint32_t)(__ballot(occupied_here) >> gshift) & 0xFFFFu;
+        uint32_t emitted = 0u;
+        if (live) {
+            uint32_t k = 0;
+            bool go = true;
+            if (skipping) {
+                const uint32_t landed = (uint32_t)(__ballot(!(T < skip_to)) >> gshift) & 0xFFFFu;
+                if (landed == 0u) {
+                    if (!((in_range >> (G - 1u)) & 1u)) live = false;      // t only grows: wherever the skip lands, it is beyond `far`
+                    go = false;
+                } else { k = (uint32_t)__builtin_ctz(landed); skipping = false; }
+            }
+            const uint32_t emit_ok = occ & in_range;
+            uint32_t room = n_step - step;
+            while (go && k < G) {
+                if (!((in_range >> k) & 1u) || room == 0u) { live = false; break; }        // the loop condition of raymarching.cu:745
+                if ((emit_ok >> k) & 1u) {                 // a run of occupied points: each emits and steps to its successor
+                    const uint32_t rest = ~(emit_ok >> k) & (0xFFFFu >> k);
+                    uint32_t len = rest ? (uint32_t)__builtin_ctz(rest) : G - k;
+                    len = len < room ? len : room;
+                    emitted |= ((1u << len) - 1u) << k;
+                    room -= len;
+                    k += len;
+                } else {
+                    const float tt = __shfl(exit_here, (int)(gbase + k), 64);
+                    const uint32_t above = k >= G - 1u ? 0u : ((0xFFFFu << (k + 1u)) & 0xFFFFu);
+                    const uint32_t landed = (uint32_t)(__ballot(!(T < tt)) >> gshift) & above;      // do { advance } while (t < tt): at least one advance
+                    if (landed == 0u) { skipping = true; skip_to = tt; break; }
+                    k = (uint32_t)__builtin_ctz(landed);
+                }
+            }
+        }
+        // the emitting lanes write their samples; delta[1] spans from the previous emitted sample's end (or the carried one)
+        const uint32_t before = emitted & below;
+        const int prev_lane = before ? (int)(gbase + 31u - (uint32_t)__builtin_clz(before)) : (int)lane;
+        const float prev_end = __shfl(t_new, prev_lane, 64);
+        if ((emitted >> sub) & 1u) {
+            const uint32_t slot = step + (uint32_t)__builtin_popcount(before);
+            px[slot * 3] = c.x; px[slot * 3 + 1] = c.y; px[slot * 3 + 2] = c.z;
+            pd[slot * 3] = dx; pd[slot * 3 + 1] = dy; pd[slot * 3 + 2] = dz;
+            pl[slot * 2] = c.dt; pl[slot * 2 + 1] = t_new - (before ? prev_end : last_t);
+        }
+        const int top_lane = emitted ? (int)(gbase + 31u - (uint32_t)__builtin_clz(emitted)) : (int)lane;
+        const float top_end = __shfl(t_new, top_lane, 64);
+        if (emitted) last_t = top_end;
+        step += (uint32_t)__builtin_popcount(emitted);
+        t_cur = t_next;
+    }
+}
+
 // ---------------------------------------------------------------- R10 (raymarching.cu:818-905)
 __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
                                  int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
@@ -527,6 +700,7 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
+    if (index < 0) return;             // already marked dead: stays dead, nothing to accumulate
     const float *s = sigmas + (uint64_t)n * n_step, *c = rgbs + (uint64_t)n * n_step * 3, *dl = deltas + (uint64_t)n * n_step * 2;
     float t = rays_t[index];
     float weight_sum = weights_sum[index], d = depth[index];
@@ -740,8 +914,19 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
                 "march_rays: unsupported C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays: C*H^3 exceeds 2^24");
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
-    hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
-                       rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    // 16 lanes per ray (k_march_rays_row) while the launch is latency-bound, one ray per lane beyond (FOC_MARCH_RAYS_ROW_MAX = most rays
+    // the row form takes; 0 = never, measured default below)
+    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");          // read per call: the tests run both forms in one process
+    const long row_max = row_env ? atol(row_env) : 262144;
+    if ((long)n_alive <= row_max && n_step <= 16u)
+        hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0,
+                           (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    else if (getenv("FOC_MARCH_RAYS_SERIAL"))              // the plain loop, one lookup at a time (A/B runs, tests)
+        hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+                           rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    else
+        hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_spec<true> : k_march_rays_spec<false>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0,
+                           (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
     FOC_CHECK_LAUNCH("march_rays");
     return FOC_OK;
 }

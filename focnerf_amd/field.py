@@ -28,6 +28,12 @@ def field_fusable(encoder, mlp):
             and mlp.padded_output_dim == 16 and os.environ.get("FOC_FUSED_FIELD", "1") != "0")
 
 
+def _raw_stream_of(device):
+    """Handle of torch's current stream on `device` (an int: cheap to take and to compare)."""
+    from ._lib import raw_stream
+    return raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 _half_scope = None          # dict id(param) -> (param, fp16 copy) while a `half_cache_scope()` is open, else None
 
 
@@ -60,15 +66,15 @@ def _half_of(param):
         return param.detach().to(torch.half).contiguous()
     hit = _half_scope.get(id(param))
     if hit is not None and hit[0] is param and hit[1].device == param.device:
-        if hit[2] is not None and torch.cuda.current_stream(param.device) != hit[3]:
+        if hit[2] is not None and _raw_stream_of(param.device) != hit[3]:
             torch.cuda.current_stream(param.device).wait_event(hit[2])      # made on another stream (staged render: chunks alternate streams)
         return hit[1]
     h = param.detach().to(torch.half).contiguous()
     ev = st = None
     if h.is_cuda:
-        st = torch.cuda.current_stream(h.device)
+        st = _raw_stream_of(h.device)
         ev = torch.cuda.Event()
-        ev.record(st)
+        ev.record()
     _half_scope[id(param)] = (param, h, ev, st)
     return h
 
@@ -80,15 +86,15 @@ def scope_cached(key, owner, make):
         return make()
     hit = _half_scope.get(key)
     if hit is not None and hit[0] is owner:
-        if hit[2] is not None and torch.cuda.current_stream(hit[1].device) != hit[3]:
+        if hit[2] is not None and _raw_stream_of(hit[1].device) != hit[3]:
             torch.cuda.current_stream(hit[1].device).wait_event(hit[2])
         return hit[1]
     v = make()
     ev = st = None
     if v.is_cuda:
-        st = torch.cuda.current_stream(v.device)
+        st = _raw_stream_of(v.device)
         ev = torch.cuda.Event()
-        ev.record(st)
+        ev.record()
     _half_scope[key] = (owner, v, ev, st)
     return v
 

@@ -156,13 +156,17 @@ composite_rays_train = CompositeTrain.apply
 # ---------------------------------------------------------------- inference
 @_fp32_op
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False,
-               dt_gamma=0, max_steps=1024):
+               dt_gamma=0, max_steps=1024, *, noises=None):
     """Up to `n_step` further samples for each of the `n_alive` rays listed in `rays_alive` (raymarching.py:297-348); slots a ray does
-    not fill keep delta 0, which `composite_rays` reads as "terminated"."""
+    not fill keep delta 0, which `composite_rays` reads as "terminated". `noises` (keyword only, not in the reference): a [>= n_alive] fp32
+    tensor to use instead of a fresh `torch.rand` / `torch.zeros` per call (the render loop hands the same zero block to every iteration)."""
     o, d = _ray_list(rays_o), _ray_list(rays_d)
     slots = _round_up(n_alive * n_step, align)
     xyzs, dirs, deltas = _sample_buffers(slots, o)
-    jitter = torch.rand(n_alive, dtype=o.dtype, device=o.device) if perturb else o.new_zeros(n_alive)
+    if noises is not None:
+        jitter = noises[:n_alive]
+    else:
+        jitter = torch.rand(n_alive, dtype=o.dtype, device=o.device) if perturb else o.new_zeros(n_alive)
     _kernels.march_rays(n_alive, n_step, rays_alive, rays_t, o, d, bound, dt_gamma, max_steps, C, H, density_bitfield, near, far, xyzs, dirs,
                         deltas, jitter)
     return xyzs, dirs, deltas
@@ -177,11 +181,13 @@ def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, we
     return tuple()
 
 
-def compact_alive(rays_alive, n_alive=None):
+def compact_alive(rays_alive, n_alive=None, pad=False):
     """Order-preserving `rays_alive[rays_alive >= 0]` on the device (no reference counterpart: its caller uses a boolean mask and a host
-    round trip, legacy/nerf/renderer.py:363). Returns (compacted list, int32[1] count tensor)."""
+    round trip, legacy/nerf/renderer.py:363). Returns (compacted list, int32[1] count tensor). `pad`: the entries behind the count are -1
+    (dead), so that a caller who does not wait for the count can hand the whole list on: `march_rays` / `composite_rays` skip them."""
     n = rays_alive.shape[0] if n_alive is None else n_alive
-    kept = torch.empty_like(rays_alive)
-    count = torch.zeros(1, dtype=torch.int32, device=rays_alive.device)
+    kept = torch.full_like(rays_alive, -1) if pad else torch.empty_like(rays_alive)
+    # the scan kernel writes the count (an empty list gets its zero from the library): no fill here
+    count = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
     _kernels.compact_alive(rays_alive, n, kept, count)
     return kept, count

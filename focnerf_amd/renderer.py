@@ -230,21 +230,43 @@ class NeRFRenderer(nn.Module):
             import contextlib
             from .field import half_cache_scope
             # the loop evaluates the same parameters once per burst: one fp16 conversion per view when nothing can write them in between
+            # device_compaction: the list of live rays is compacted on the device, and its length is read back LATE — the loop sizes
+            # iteration i by the count of iteration i - 1 - lag (an upper bound: rays only die), entries behind the true count are -1 and the
+            # kernels skip them. With the reference's `rays_alive[rays_alive >= 0]` (or an immediate `.item()`) the host waits for the GPU
+            # once per iteration and the GPU then waits for the host to enqueue the next one: 0.54 ms per iteration for 0.17 ms of kernels.
+            lag = int(os.environ.get("FOC_RENDER_COUNT_LAG", "2")) if device_compaction else 0
+            ring = torch.empty(lag + 1, dtype=torch.int32).pin_memory() if lag > 0 else None
+            waiting = []                                              # (event, ring slot) of counts on their way to the host
+            it = 0
+            still = torch.zeros(n, dtype=torch.float32, device=dev)   # "no jitter" for every iteration after the first: one fill per view
             with (half_cache_scope() if not torch.is_grad_enabled() else contextlib.nullcontext()):
                 while marched < max_steps and alive.shape[0] > 0:
                     live = alive.shape[0]
                     burst = max(min(n // live, 8), 1)                 # fewer live rays -> more samples per ray and launch
                     xyzs, dirs, deltas = raymarching.march_rays(live, burst, alive, t_now, o, d, self.bound, self.density_bitfield, self.cascade,
                                                                 self.grid_size, near, far, _MARCH_ALIGN, perturb and marched == 0, dt_gamma,
-                                                                max_steps)
+                                                                max_steps, noises=None if (perturb and marched == 0) else still)
                     sigmas, rgbs = self(xyzs, dirs)
                     raymarching.composite_rays(live, burst, alive, t_now, self._scaled(sigmas), rgbs, deltas, opacity, depth, image, T_thresh)
-                    if device_compaction:
+                    if device_compaction and lag > 0:
+                        kept, count = raymarching.compact_alive(alive, pad=True)
+                        slot = it % (lag + 1)
+                        ring[slot:slot + 1].copy_(count, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        waiting.append((ev, slot))
+                        if len(waiting) > lag:                        # the count of `lag` iterations ago: long since on the host
+                            ev0, s0 = waiting.pop(0)
+                            ev0.synchronize()
+                            live = min(live, int(ring[s0]))
+                        alive = kept[:live]
+                    elif device_compaction:
                         kept, count = raymarching.compact_alive(alive)
                         alive = kept[:int(count.item())]
                     else:
                         alive = alive[alive >= 0]
                     marched += burst
+                    it += 1
         out['image'], out['depth'] = self._finish(image, depth, opacity, near, far, background, lead)
         return out
 

@@ -262,17 +262,99 @@ def test_composite_autograd_with_unused_outputs(rm, use):
         assert grads[False][0].any()
 
 
-def test_inference_march_and_composite_loop(rm):
-    """legacy/nerf/renderer.py:323-372 loop, oracle vs GPU, with an analytic field standing in for the network."""
+def _analytic_field(x, d):
+    sig = 30 * np.exp(-(x ** 2).sum(-1) / 0.3).astype(np.float32)
+    rgb = (0.5 + 0.5 * np.sin(3 * x + d)).astype(np.float32)
+    return sig, rgb
+
+
+def _set_march_form(monkeypatch, form):
+    """R9's three forms: 16 lanes per ray (k_march_rays_row), one ray per lane looking 8 lattice points ahead (k_march_rays_spec), and
+    the plain one-lookup-at-a-time loop (k_march_rays)."""
+    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "1000000000" if form == "row" else "0")
+    if form == "serial":
+        monkeypatch.setenv("FOC_MARCH_RAYS_SERIAL", "1")
+    else:
+        monkeypatch.delenv("FOC_MARCH_RAYS_SERIAL", raising=False)
+
+
+@pytest.mark.parametrize("form", ["row", "spec", "serial"])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_inference_loop_final_image_without_resync(rm, form, perturb, monkeypatch):
+    """The whole inference loop of legacy/nerf/renderer.py:323-372 run TWICE, independently: on the oracle and on the GPU, each on its own
+    state from the first iteration to the last (device-side compaction, no per-iteration re-synchronisation) — an error that builds up in
+    composite_rays or march_rays over the iterations would show in the final image. Tolerated: the counted rays whose transmittance crosses
+    T_thresh one sample earlier or later (__expf vs expf at the boundary), each of which moves a pixel by <= ~T_thresh. All forms of R9."""
+    _set_march_form(monkeypatch, form)
+    N = 4000                                           # scene() draws from a 64 x 64 view: at most 4096 rays
+    s, n_ref, f_ref, noises = _march_case(2, N, 1 / 128, perturb, seed=13)
+    assert s["rays_o"].shape[0] == N
+    C, H, max_steps, T_thresh = s["cascade"], 128, 1024, 1e-4
+    o_np, d_np, bits_np = s["rays_o"].numpy(), s["rays_d"].numpy(), s["bits"].numpy()
+    # ---- oracle loop, its own state
+    ws = np.zeros(N, np.float32); dp = np.zeros(N, np.float32); im = np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32); rt = n_ref.copy()
+    step, its = 0, 0
+    killed_at = np.full(N, -1)
+    while step < max_steps and alive.shape[0] > 0:
+        n_alive = alive.shape[0]
+        n_step = max(min(N // n_alive, 8), 1)
+        M = n_alive * n_step
+        M += 128 - M % 128
+        nz = noises.numpy()[:n_alive] if (perturb and step == 0) else np.zeros(n_alive, np.float32)
+        x, dd, dl = oracle.march_rays(n_alive, n_step, alive, rt, o_np, d_np, s["bound"], 1 / 128, max_steps, C, H, bits_np, n_ref, f_ref, nz, M=M)
+        sig, rgb = _analytic_field(x, dd)
+        before = alive.copy()
+        alive, rt, ws, dp, im = oracle.composite_rays(n_alive, n_step, T_thresh, alive, rt, sig, rgb, dl, ws, dp, im)
+        killed_at[before[alive < 0]] = its
+        alive = alive[alive >= 0]
+        step += n_step
+        its += 1
+    # ---- GPU loop, its own state
+    dev = "cuda"
+    o, d, bits = s["rays_o"].cuda(), s["rays_d"].cuda(), s["bits"].cuda()
+    nears, fars = torch.from_numpy(n_ref).cuda(), torch.from_numpy(f_ref).cuda()
+    gws = torch.zeros(N, device=dev); gdp = torch.zeros(N, device=dev); gim = torch.zeros(N, 3, device=dev)
+    galive = torch.arange(N, dtype=torch.int32, device=dev); grt = nears.clone()
+    gstep, gits = 0, 0
+    while gstep < max_steps and galive.shape[0] > 0:
+        n_alive = galive.shape[0]
+        n_step = max(min(N // n_alive, 8), 1)
+        # the wrapper draws torch.rand when perturb is set; the oracle's noise is handed over through the backend instead
+        M = n_alive * n_step
+        M += 128 - M % 128
+        gx = torch.zeros(M, 3, device=dev); gd = torch.zeros(M, 3, device=dev); gl = torch.zeros(M, 2, device=dev)
+        nz = noises[:n_alive].cuda() if (perturb and gstep == 0) else torch.zeros(n_alive, device=dev)
+        from focnerf_amd.backend import _raymarching
+        _raymarching.march_rays(n_alive, n_step, galive, grt, o, d, s["bound"], 1 / 128, max_steps, C, H, bits, nears, fars, gx, gd, gl, nz)
+        sig, rgb = _analytic_field(to_np(gx), to_np(gd))
+        rm.composite_rays(n_alive, n_step, galive, grt, torch.from_numpy(sig).cuda(), torch.from_numpy(rgb).cuda(), gl, gws, gdp, gim, T_thresh)
+        comp, n_out = rm.compact_alive(galive)
+        galive = comp[: int(n_out.item())].contiguous()
+        gstep += n_step
+        gits += 1
+    assert its > 3 and ws.max() > 0.9 and abs(gits - its) <= 1
+    d_ws, d_im = np.abs(to_np(gws) - ws), np.abs(to_np(gim) - im).max(-1)
+    # every pixel within the threshold's reach; all but the counted flips within the kernel tolerance
+    assert d_ws.max() <= 4 * T_thresh and d_im.max() <= 4 * T_thresh, (d_ws.max(), d_im.max())
+    flips = (d_ws > RGB_TOL) | (d_im > RGB_TOL)
+    assert flips.mean() < 2e-3, f"{flips.sum()} of {N} rays differ by more than {RGB_TOL}"
+    np.testing.assert_allclose(to_np(gdp)[~flips], dp[~flips], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("form", ["row", "spec", "serial"])
+def test_inference_march_and_composite_loop(rm, form, monkeypatch):
+    """legacy/nerf/renderer.py:323-372 loop, oracle vs GPU, with an analytic field standing in for the network. Per iteration: sample
+    positions / directions / deltas bit for bit (all forms of R9), composite state within RGB_TOL; the
+    state is re-synchronised to the oracle's after each iteration so that every iteration's inputs are identical (the un-synchronised
+    end-to-end comparison is test_inference_loop_final_image_without_resync)."""
+    _set_march_form(monkeypatch, form)
     N = 3000
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
     C, H, max_steps, T_thresh = s["cascade"], 128, 1024, 1e-4
     o_np, d_np, bits_np = s["rays_o"].numpy(), s["rays_d"].numpy(), s["bits"].numpy()
 
-    def field_np(x, d):
-        sig = 30 * np.exp(-(x ** 2).sum(-1) / 0.3).astype(np.float32)
-        rgb = (0.5 + 0.5 * np.sin(3 * x + d)).astype(np.float32)
-        return sig, rgb
+    field_np = _analytic_field
 
     # oracle loop
     ws = np.zeros(N, np.float32); dp = np.zeros(N, np.float32); im = np.zeros((N, 3), np.float32)
@@ -356,3 +438,45 @@ def test_full_view_march_properties(rm):
     want = 1 - torch.exp(-0.5 * seg)
     assert torch.allclose(ws.double(), want, atol=2e-5)
     assert torch.allclose(im[:, 0].double(), 0.25 * want, atol=2e-5)
+
+
+@pytest.mark.parametrize("form", ["row", "spec", "serial"])
+def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
+    """A ray list with -1 entries (what composite_rays leaves behind, and what `compact_alive(pad=True)` puts behind the count): march_rays
+    writes nothing for them (their slots stay zero = "terminated"), composite_rays leaves them and every per-ray accumulator alone — the
+    live entries get exactly what the compacted list gets. This is what lets the render loop hand on a list whose true length it has not
+    read back yet."""
+    _set_march_form(monkeypatch, form)
+    N, n_step = 1500, 4
+    s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
+    C, H = s["cascade"], 128
+    o, d, bits = s["rays_o"].cuda(), s["rays_d"].cuda(), s["bits"].cuda()
+    nears, fars = torch.from_numpy(n_ref).cuda(), torch.from_numpy(f_ref).cuda()
+    g = torch.Generator().manual_seed(3)
+    keep = torch.rand(N, generator=g) > 0.4
+    holes = torch.where(keep, torch.arange(N), torch.full((N,), -1)).to(torch.int32).cuda()
+    dense = torch.arange(N, dtype=torch.int32)[keep].cuda()
+    kept, count = rm.compact_alive(holes, pad=True)
+    assert int(count.item()) == dense.shape[0] and torch.equal(kept[: dense.shape[0]], dense) and bool((kept[dense.shape[0]:] == -1).all())
+    out = {}
+    for name, lst in (("holes", holes), ("padded", kept), ("dense", dense)):
+        t_now = nears.clone()
+        ws = torch.zeros(N, device="cuda"); dp = torch.zeros(N, device="cuda"); im = torch.zeros(N, 3, device="cuda")
+        x, dd, dl = rm.march_rays(lst.shape[0], n_step, lst, t_now, o, d, s["bound"], bits, C, H, nears, fars, 128, False, 1 / 128, 1024)
+        sig, rgb = _analytic_field(to_np(x), to_np(dd))
+        lst2 = lst.clone()
+        rm.composite_rays(lst.shape[0], n_step, lst2, t_now, torch.from_numpy(sig).cuda(), torch.from_numpy(rgb).cuda(), dl, ws, dp, im, 1e-4)
+        out[name] = (x, dl, lst2, ws, dp, im, t_now)
+    n_live = dense.shape[0]
+    for name in ("holes", "padded"):
+        x, dl, lst2, ws, dp, im, t_now = out[name]
+        live_rows = (out[name][2] != -1) | (holes >= 0 if name == "holes" else torch.arange(N, device="cuda") < n_live)
+        sel = (holes >= 0) if name == "holes" else (torch.arange(N, device="cuda") < n_live)
+        xs, dls = x[: N * n_step].view(N, n_step, 3), dl[: N * n_step].view(N, n_step, 2)
+        assert torch.equal(xs[sel], out["dense"][0][: n_live * n_step].view(n_live, n_step, 3))
+        assert torch.equal(dls[sel], out["dense"][1][: n_live * n_step].view(n_live, n_step, 2))
+        assert not xs[~sel].any() and not dls[~sel].any(), "dead entries must leave their slots zero"
+        assert bool((lst2[~sel] == -1).all())
+        for k in (3, 4, 5, 6):
+            assert torch.equal(out[name][k], out["dense"][k]), (name, k)
+    assert out["dense"][3].max() > 0
