@@ -23,6 +23,7 @@
 //    fp32 atomics of whole 128-B row segments into a 16-KiB-per-layer workspace), replacing
 //    the reference's CUTLASS split-K GEMMs on side streams (ffmlp.cu:800-876).
 #include "common.h"
+#include "activations.h"
 #include <stdlib.h>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -61,6 +62,14 @@ __device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
         if (RELU) p = __builtin_elementwise_max(p, h2{(_Float16)0, (_Float16)0});  // one v_pk_max_f16 for the pair: max(x, 0), NaN -> 0 like `x > 0 ? x : 0`
         r[j] = p[0]; r[j + 1] = p[1];
     }
+    return r;
+}
+
+// The same with any of the reference's hidden activations (activations.h): the sum rounded to half, then the function on it.
+__device__ __forceinline__ h8 acc_to_frag_act(const f16v &acc, int s, int act) {
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = foc_act_forward((_Float16)acc[8 * s + j], act);
     return r;
 }
 
@@ -268,11 +277,31 @@ __device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t 
     }
 }
 
+// store_tile with a general activation on the half-rounded sums
+__device__ __forceinline__ void store_tile_act(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint64_t nrows, uint32_t col0, uint32_t ncols,
+                                               const f16v &acc, int h, int act) {
+    if (row >= nrows) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t col = col0 + 8 * q + 4 * h;
+        if (col < ncols) {
+            h4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = foc_act_forward((_Float16)acc[4 * q + e], act);
+            *reinterpret_cast<h4 *>(dst + row * ld + col) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- M1: fused forward / inference
-template <int HIDDEN, int NB, bool TRAIN, int IMODE>
+// GEN: a hidden activation other than ReLU / None (exponential, sine, sigmoid, squareplus, softplus — ffmlp/src/utils.h:424-470; no FOC
+// network uses one): the same MFMA chain, the activation evaluated in fp32 on the half-rounded sums. `act` is the reference's code; the
+// ReLU / None instantiations read it as a flag (act == 0) and keep their packed-max path.
+template <int HIDDEN, int NB, bool TRAIN, int IMODE, bool GEN = false>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__restrict__ inputs, const _Float16 *__restrict__ weights,
                                                        _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ outputs,
-                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu, MlpHead hd) {
+                                                       uint32_t B, uint32_t in_dim, uint32_t num_layers, int act, MlpHead hd) {
+    const int relu = act == FOC_ACT_RELU;
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     constexpr bool planar = IMODE == 1;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -354,7 +383,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) {
-                        if (relu) store_tile<true>(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
+                        if constexpr (GEN) store_tile_act(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h, act);
+                        else if (relu) store_tile<true>(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
                         else store_tile<false>(fb, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
                     }
             }
@@ -362,8 +392,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
 #pragma unroll
             for (int kc = 0; kc < KC; kc++)
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    bf[kc][nb] = relu ? acc_to_frag<true>(acc[kc >> 1][nb], kc & 1) : acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+                for (int nb = 0; nb < NB; nb++) {
+                    if constexpr (GEN) bf[kc][nb] = acc_to_frag_act(acc[kc >> 1][nb], kc & 1, act);
+                    else bf[kc][nb] = relu ? acc_to_frag<true>(acc[kc >> 1][nb], kc & 1) : acc_to_frag<false>(acc[kc >> 1][nb], kc & 1);
+                }
             if (l < num_layers) {
                 const uint32_t fbase = f_hidden + (l - 1) * MT * KC;
 #pragma unroll
@@ -411,11 +443,14 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_fwd(const _Float16 *__rest
 
 // ---------------------------------------------------------------- M2: fused activation-gradient backward
 // backward_buffer[k] = gradient w.r.t. the (post-ReLU) output of forward layer num_layers-1-k.
-template <int HIDDEN, int NB>
+// GEN: any hidden activation (warp_activation_backward, utils.h:533-589): the half-rounded delta times a factor of the stored
+// post-activation, in half arithmetic (activations.h); otherwise `act` is read as the ReLU flag.
+template <int HIDDEN, int NB, bool GEN = false>
 __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ weights,
                                                        const _Float16 *__restrict__ fwd_buf, _Float16 *__restrict__ bwd_buf,
                                                        _Float16 *__restrict__ grad_inputs, uint32_t B, uint32_t in_dim,
-                                                       uint32_t num_layers, int relu) {
+                                                       uint32_t num_layers, int act) {
+    const int relu = act == FOC_ACT_RELU;
     constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const bool with_dx = grad_inputs != nullptr;
@@ -452,7 +487,22 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
         for (uint32_t k = 0; k < num_layers; k++) {
             const uint32_t fl = num_layers - 1 - k;   // forward layer whose output gradient `acc` is
             // ---- ReLU transfer with the stored forward activations (utils.h:540-545), then store
-            if (relu) {
+            if constexpr (GEN) {
+                const _Float16 *fb = fwd_buf + (uint64_t)fl * B * HIDDEN;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t col = 32 * mt + 8 * q + 4 * h;
+                            if (col < HIDDEN) {
+                                const h4 f = *reinterpret_cast<const h4 *>(fb + min(row0 + nb * 32 + c, (uint64_t)B - 1) * HIDDEN + col);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) acc[mt][nb][4 * q + e] = (float)foc_act_backward((_Float16)acc[mt][nb][4 * q + e], f[e], act);
+                            }
+                        }
+            } else if (relu) {
                 const _Float16 *fb = fwd_buf + (uint64_t)fl * B * HIDDEN;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -1395,9 +1445,9 @@ static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
 }
 
 // hidden_dim 256 (ffmlp_wide.hip): layer-by-layer kernels with one matrix resident in LDS
-int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu, void *buffer,
+int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act, void *buffer,
                      void *outputs, hipStream_t st);
-int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu,
+int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act,
                                   void *bwd_buf, void *grad_inputs, hipStream_t st);
 
 static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
@@ -1408,7 +1458,7 @@ static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t o
                 "%s: input_dim must be a multiple of 16 up to %u (got %u)", who, hidden_dim == 256 ? 256u : 128u, input_dim);
     FOC_REQUIRE(output_dim <= 16, FOC_E_INVALID, "%s: output_dim must be <= 16 (got %u)", who, output_dim);
     FOC_REQUIRE(num_layers >= 2 && num_layers <= 16, FOC_E_INVALID, "%s: num_layers must be in [2,16] (got %u)", who, num_layers);
-    FOC_REQUIRE(activation == 0 || activation == 6, FOC_E_INVALID, "%s: hidden activation must be relu(0) or none(6) (got %u)", who, activation);
+    FOC_REQUIRE(activation <= 6, FOC_E_INVALID, "%s: hidden activation must be one of relu(0) exponential(1) sine(2) sigmoid(3) squareplus(4) softplus(5) none(6) (got %u)", who, activation);
     FOC_REQUIRE(output_activation == 6, FOC_E_INVALID, "%s: output activation must be none(6) (got %u)", who, output_activation);
     return FOC_OK;
 }
@@ -1425,13 +1475,16 @@ static size_t mlp_bwd_lds(uint32_t in_dim, uint32_t num_layers, bool dx) {
 }
 
 template <int HIDDEN, bool TRAIN>
-static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int relu,
+static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, int act,
                           void *fwd_buf, void *outputs, int planar, hipStream_t st, const MlpHead *head = nullptr) {
+    const bool gen = act != FOC_ACT_RELU && act != FOC_ACT_NONE;
+    FOC_REQUIRE(!gen || (!planar && !head), FOC_E_INVALID, "ffmlp_forward: activation %d is served on row-major inputs only", act);
     constexpr int NB = 1;                          // one 32-row tile per wave: 92 registers, 5 waves per SIMD (two tiles: 157 registers, 3 waves; 57 -> 54 us per 2 M rows)
     const size_t lds = mlp_fwd_lds<HIDDEN>(in_dim, num_layers) + (head && head->obj ? 256 : 0);       // + obj_bias [2][2][16] fp32
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_forward: weights (%zu B) do not fit the 160 KiB LDS", lds);
     FOC_REQUIRE(!(planar && TRAIN), FOC_E_INVALID, "ffmlp_forward: planar inputs go with the activation-free forward");
     auto kern = planar ? k_mlp_fwd<HIDDEN, NB, false, 1> : k_mlp_fwd<HIDDEN, NB, TRAIN, 0>;
+    if (gen) kern = k_mlp_fwd<HIDDEN, NB, TRAIN, 0, true>;
     if constexpr (HIDDEN == 64 && !TRAIN) { if (head) kern = k_mlp_fwd<HIDDEN, NB, false, 2>; }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1440,7 +1493,7 @@ static int mlp_fwd_launch(const void *inputs, const void *weights, uint32_t B, u
     const uint32_t cap = mlp_num_cus() * mlp_resident_blocks(reinterpret_cast<const void *>(kern), lds);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)inputs, (const _Float16 *)weights, (_Float16 *)fwd_buf,
-                       (_Float16 *)outputs, B, in_dim, num_layers, relu, head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
+                       (_Float16 *)outputs, B, in_dim, num_layers, act, head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
     FOC_CHECK_LAUNCH(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
     return FOC_OK;
 }
@@ -1453,16 +1506,16 @@ static int mlp_fwd(const void *inputs, const void *weights, uint32_t B, uint32_t
     if (rc) return rc;
     if (B == 0) return FOC_OK;                      // empty tensors carry null data pointers
     FOC_REQUIRE(inputs && weights && outputs && (!TRAIN || buffer), FOC_E_INVALID, "%s: null pointer", who);
-    const int relu = activation == 0;
+    const int act = (int)activation;
     hipStream_t st = (hipStream_t)stream;
     switch (hidden_dim) {
-        case 16: return mlp_fwd_launch<16, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
-        case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
-        case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
-        case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, relu, buffer, outputs, planar, st);
+        case 16: return mlp_fwd_launch<16, TRAIN>(inputs, weights, B, input_dim, num_layers, act, buffer, outputs, planar, st);
+        case 32: return mlp_fwd_launch<32, TRAIN>(inputs, weights, B, input_dim, num_layers, act, buffer, outputs, planar, st);
+        case 64: return mlp_fwd_launch<64, TRAIN>(inputs, weights, B, input_dim, num_layers, act, buffer, outputs, planar, st);
+        case 128: return mlp_fwd_launch<128, TRAIN>(inputs, weights, B, input_dim, num_layers, act, buffer, outputs, planar, st);
         case 256:                                       // one matrix fills the LDS: layer by layer (ffmlp_wide.hip)
             FOC_REQUIRE(!planar, FOC_E_INVALID, "%s: planar inputs are served up to hidden_dim 128", who);
-            return mlp_wide_forward(TRAIN, inputs, weights, B, input_dim, 256, num_layers, relu, buffer, outputs, st);
+            return mlp_wide_forward(TRAIN, inputs, weights, B, input_dim, 256, num_layers, act, buffer, outputs, st);
     }
     return FOC_E_INVALID;
 }
@@ -1530,12 +1583,14 @@ static int mlp_dw_launch(const void *grad, const void *inputs, const void *fwd_b
 
 template <int HIDDEN>
 static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim,
-                          uint32_t num_layers, int relu, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
+                          uint32_t num_layers, int act, void *bwd_buf, void *grad_inputs, void *grad_weights, float *ws, int planar, hipStream_t st) {
+    const bool gen = act != FOC_ACT_RELU && act != FOC_ACT_NONE;      // the single-pass kernel is built for ReLU / None: the others take the reference's data flow
+    const int relu = act == FOC_ACT_RELU;
     // fused single-pass kernel for the shapes the NeRF networks use; FOC_MLP_BWD_FUSED=0 forces the two-kernel form (tuning / tests)
     static int use_fused = -1;
     if (use_fused < 0) { const char *e = getenv("FOC_MLP_BWD_FUSED"); use_fused = e ? atoi(e) : 1; }
     if constexpr (HIDDEN <= 64) {
-        if (use_fused && in_dim <= 64) {
+        if (use_fused && in_dim <= 64 && !gen) {
             switch (num_layers) {
                 case 2: return mlp_bwd_fused_launch<HIDDEN, 2>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, planar, st);
                 case 3: return mlp_bwd_fused_launch<HIDDEN, 3>(grad, inputs, weights, fwd_buf, B, in_dim, relu, bwd_buf, grad_inputs, grad_weights, ws, planar, st);
@@ -1544,20 +1599,20 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
             }
         }
     }
-    FOC_REQUIRE(bwd_buf && fwd_buf, FOC_E_INVALID, "ffmlp_backward: forward_buffer and backward_buffer are required for this shape (two-kernel path)");
+    FOC_REQUIRE(bwd_buf && fwd_buf, FOC_E_INVALID, "ffmlp_backward: forward_buffer and backward_buffer are required for this shape / activation (two-kernel path)");
     FOC_REQUIRE(!planar, FOC_E_INVALID, "ffmlp_backward: planar inputs are served by the fused kernel only (hidden_dim <= 64, input_dim <= 64, 2..4 layers)");
     constexpr int NB = 2;
     const bool dx = grad_inputs != nullptr;
     const size_t lds = mlp_bwd_lds<HIDDEN>(in_dim, num_layers, dx);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: weights (%zu B) do not fit the 160 KiB LDS", lds);
-    auto kern = k_mlp_bwd<HIDDEN, NB>;
+    auto kern = gen ? k_mlp_bwd<HIDDEN, NB, true> : k_mlp_bwd<HIDDEN, NB, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_tiles = foc_div_up(B, 32 * NB);
     uint32_t grid = foc_div_up(n_tiles, MLP_WAVES);
     const uint32_t cap = mlp_num_cus() * 4;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)weights, (const _Float16 *)fwd_buf,
-                       (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, B, in_dim, num_layers, relu);
+                       (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, B, in_dim, num_layers, act);
     FOC_CHECK_LAUNCH("ffmlp_backward(activations)");
     return mlp_dw_launch<HIDDEN>(grad, inputs, fwd_buf, bwd_buf, B, in_dim, num_layers, grad_weights, ws, st);
 }
@@ -1620,7 +1675,7 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
     }
     FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
     FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
-    const int relu = activation == 0;
+    const int relu = (int)activation;                     // the reference's activation code (0 = ReLU ... 6 = None), handed on as it is
     hipStream_t st = (hipStream_t)stream;
     void *gi = calc_grad_inputs ? grad_inputs : nullptr;
     switch (hidden_dim) {
@@ -1694,7 +1749,8 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
     FOC_REQUIRE(hidden_dim == 64 && samples_per_ray >= 1, FOC_E_INVALID, "color_head_forward: hidden_dim must be 64 (got %u), samples_per_ray >= 1", hidden_dim);
     FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_forward: out_width must be 16 or 4 (got %u)", out_width);
     const MlpHead hd{(const _Float16 *)ray_sh, nullptr, samples_per_ray, out_width, (const _Float16 *)obj_feat};
-    return mlp_fwd_launch<64, false>(h, weights, B, 32, num_layers, activation == 0, nullptr, outputs, 0, (hipStream_t)stream, &hd);
+    FOC_REQUIRE(activation == FOC_ACT_RELU || activation == FOC_ACT_NONE, FOC_E_INVALID, "color_head_forward: hidden activation must be relu(0) or none(6)");
+    return mlp_fwd_launch<64, false>(h, weights, B, 32, num_layers, (int)activation, nullptr, outputs, 0, (hipStream_t)stream, &hd);
 }
 
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
@@ -1714,6 +1770,7 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
     }
     FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");
     FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_backward: out_width must be 16 or 4 (got %u)", out_width);
+    FOC_REQUIRE(activation == FOC_ACT_RELU || activation == FOC_ACT_NONE, FOC_E_INVALID, "color_head_backward: hidden activation must be relu(0) or none(6)");
     const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray, out_width, (const _Float16 *)obj_feat};
     const int relu = activation == 0;
     if (num_layers == 2) return mlp_bwd_fused_launch<64, 2>(grad, h, weights, nullptr, B, 32, relu, nullptr, grad_h, grad_weights, (float *)workspace, 0, (hipStream_t)stream, &hd, grad_obj);

@@ -11,6 +11,7 @@
 // ffmlp.py:31, :73), which this shape keeps; the weight gradients reuse the split-K kernel of ffmlp.hip (k_mlp_dw<256>, output tiles dealt over
 // blockIdx.z). Same arithmetic as the narrower widths: fp16 operands, fp32 accumulation, one rounding per layer, ReLU on the rounded value.
 #include "common.h"
+#include "activations.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -23,12 +24,14 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define WIDE_NONE 0                                 // y
 #define WIDE_RELU 1                                 // max(y, 0)                         (forward hidden layers)
 #define WIDE_MASK 2                                 // y where mask[b, n] > 0 else 0     (ReLU transfer of the backward pass, utils.h:540-545)
+#define WIDE_ACT 3                                  // act(y), any of the reference's hidden activations (activations.h)
+#define WIDE_TRANSFER 4                             // y * factor(mask[b, n]): their backward transfer on the stored post-activations
 
 // W: the layer's [n_w, k_w] row-major matrix (neuron = row). TRANS = false: output neuron n = row n, reduction over the row (N = n_w, K = k_w).
 // TRANS = true: output n = COLUMN n of W, reduction over the rows (N = k_w, K = n_w; rows of W past `n_valid` do not exist: the padded output layer).
 template <bool TRANS, int EPI>
 __global__ void __launch_bounds__(WIDE_BLOCK, 1) k_wide_layer(const _Float16 *__restrict__ X, uint32_t ldx, const _Float16 *__restrict__ W, uint32_t n_w, uint32_t k_w,
-                                                             _Float16 *__restrict__ Y, uint32_t ldy, const _Float16 *__restrict__ mask, uint32_t ldm, uint32_t B) {
+                                                             _Float16 *__restrict__ Y, uint32_t ldy, const _Float16 *__restrict__ mask, uint32_t ldm, uint32_t B, int act) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const uint32_t N = TRANS ? k_w : n_w, K = TRANS ? n_w : k_w;
     const uint32_t MT = (N + 31) / 32, KC = (K + 15) / 16;
@@ -96,6 +99,13 @@ __global__ void __launch_bounds__(WIDE_BLOCK, 1) k_wide_layer(const _Float16 *__
                                 const h4 m = *reinterpret_cast<const h4 *>(mask + row * ldm + col);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) if (!(m[e] > (_Float16)0)) v[e] = (_Float16)0;
+                            } else if (EPI == WIDE_ACT) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = foc_act_forward(v[e], act);
+                            } else if (EPI == WIDE_TRANSFER) {
+                                const h4 m = *reinterpret_cast<const h4 *>(mask + row * ldm + col);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = foc_act_backward(v[e], m[e], act);
                             }
                             *reinterpret_cast<h4 *>(Y + row * ldy + col) = v;
                         }
@@ -120,7 +130,7 @@ static uint32_t wide_num_cus() {
 
 template <bool TRANS, int EPI>
 static int wide_launch(const char *what, const void *X, uint32_t ldx, const void *W, uint32_t n_w, uint32_t k_w, void *Y, uint32_t ldy, const void *mask, uint32_t ldm,
-                       uint32_t B, hipStream_t st) {
+                       uint32_t B, hipStream_t st, int act = FOC_ACT_NONE) {
     const uint32_t N = TRANS ? k_w : n_w, K = TRANS ? n_w : k_w;
     FOC_REQUIRE(N <= 32 * WIDE_MT && K <= 256 && N % 4 == 0, FOC_E_INVALID, "%s: layer %u x %u is beyond the wide path (<= 256 x 256)", what, N, K);
     FOC_REQUIRE(ldx % 8 == 0 && ldx >= ((K + 15) / 16) * 16, FOC_E_INVALID, "%s: activation rows must hold whole 16-wide k-chunks (ld %u, K %u)", what, ldx, K);
@@ -130,14 +140,16 @@ static int wide_launch(const char *what, const void *X, uint32_t ldx, const void
     uint32_t grid = foc_div_up(foc_div_up(B, 32), 4);
     const uint32_t cap = wide_num_cus() * (lds > 80 * 1024 ? 1u : 2u);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_BLOCK), lds, st, (const _Float16 *)X, ldx, (const _Float16 *)W, n_w, k_w, (_Float16 *)Y, ldy, (const _Float16 *)mask, ldm, B);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_BLOCK), lds, st, (const _Float16 *)X, ldx, (const _Float16 *)W, n_w, k_w, (_Float16 *)Y, ldy, (const _Float16 *)mask, ldm, B, act);
     FOC_CHECK_LAUNCH(what);
     return FOC_OK;
 }
 
 // ---- forward: buffer = forward_buffer [num_layers, B, hidden] (training: every post-activation is kept) or inference_buffer [B, hidden] (layers in place)
-int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu, void *buffer,
+int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act, void *buffer,
                      void *outputs, hipStream_t st) {
+    const int relu = act == FOC_ACT_RELU;
+    const bool gen = act != FOC_ACT_RELU && act != FOC_ACT_NONE;
     const char *who = train ? "ffmlp_forward" : "ffmlp_inference";
     FOC_REQUIRE(buffer, FOC_E_INVALID, "%s: hidden_dim %u runs layer by layer and needs the %s", who, hidden, train ? "forward_buffer" : "inference_buffer [B, hidden_dim]");
     const _Float16 *W = (const _Float16 *)weights;
@@ -146,7 +158,8 @@ int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32
     uint32_t K = in_dim;
     for (uint32_t l = 0; l < num_layers; l++) {
         _Float16 *y = train ? buf + (size_t)l * B * hidden : buf;
-        const int rc = relu ? wide_launch<false, WIDE_RELU>(who, x, K, W, hidden, K, y, hidden, nullptr, 0, B, st)
+        const int rc = gen ? wide_launch<false, WIDE_ACT>(who, x, K, W, hidden, K, y, hidden, nullptr, 0, B, st, act)
+                     : relu ? wide_launch<false, WIDE_RELU>(who, x, K, W, hidden, K, y, hidden, nullptr, 0, B, st)
                             : wide_launch<false, WIDE_NONE>(who, x, K, W, hidden, K, y, hidden, nullptr, 0, B, st);
         if (rc) return rc;
         W += (size_t)hidden * K;
@@ -157,8 +170,10 @@ int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32
 }
 
 // ---- activation gradients: backward_buffer[k] = gradient w.r.t. the post-ReLU output of forward layer num_layers-1-k (ffmlp.cu:410-518); grad_inputs or NULL
-int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int relu,
+int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act,
                                   void *bwd_buf, void *grad_inputs, hipStream_t st) {
+    const int relu = act == FOC_ACT_RELU;
+    const bool gen = act != FOC_ACT_RELU && act != FOC_ACT_NONE;
     const _Float16 *W0 = (const _Float16 *)weights;
     const _Float16 *Wh = W0 + (size_t)hidden * in_dim;
     const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * hidden * hidden;
@@ -172,7 +187,8 @@ int mlp_wide_backward_activations(const void *grad, const void *weights, const v
         const uint32_t n_w = k == 0 ? 16u : hidden;
         _Float16 *dst = bb + (size_t)k * B * hidden;
         const _Float16 *m = fb + (size_t)fl * B * hidden;
-        const int rc = relu ? wide_launch<true, WIDE_MASK>("ffmlp_backward", src, ld_src, Wm, n_w, hidden, dst, hidden, m, hidden, B, st)
+        const int rc = gen ? wide_launch<true, WIDE_TRANSFER>("ffmlp_backward", src, ld_src, Wm, n_w, hidden, dst, hidden, m, hidden, B, st, act)
+                     : relu ? wide_launch<true, WIDE_MASK>("ffmlp_backward", src, ld_src, Wm, n_w, hidden, dst, hidden, m, hidden, B, st)
                             : wide_launch<true, WIDE_NONE>("ffmlp_backward", src, ld_src, Wm, n_w, hidden, dst, hidden, nullptr, 0, B, st);
         if (rc) return rc;
         src = dst;

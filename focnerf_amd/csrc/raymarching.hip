@@ -915,18 +915,22 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays: C*H^3 exceeds 2^24");
     const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     // 16 lanes per ray (k_march_rays_row) while the launch is latency-bound, one ray per lane beyond (FOC_MARCH_RAYS_ROW_MAX = most rays
-    // the row form takes; 0 = never, measured default below)
-    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");          // read per call: the tests run both forms in one process
-    const long row_max = row_env ? atol(row_env) : 262144;
+    // the row form takes; 0 = never). Measured on the 800 x 800 occupancy render (profiles/, tools/quick_render_stats.sh; 549 launches,
+    // most of them with > 262 144 rays alive and one sample per ray): one ray per lane 48.1 us average; the row form for every launch
+    // 79.9 us (16x the cell evaluations where a ray needs one); row form up to 65 536 / 131 072 rays: 26-28 us on those launches (120 of
+    // 549) against ~40 us. The 8-points-ahead lane form (k_march_rays_spec, FOC_MARCH_RAYS_SPEC=1) measured 53.8 us against 48.1: with
+    // ~10 waves per SIMD the big launches are bound by the divergent walks' instruction count, not by their lookup chains.
+    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");          // read per call: the tests run all forms in one process
+    const long row_max = row_env ? atol(row_env) : 131072;
     if ((long)n_alive <= row_max && n_step <= 16u)
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0,
                            (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
-    else if (getenv("FOC_MARCH_RAYS_SERIAL"))              // the plain loop, one lookup at a time (A/B runs, tests)
-        hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
-                           rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
-    else
+    else if (getenv("FOC_MARCH_RAYS_SPEC"))                // one ray per lane, 8 lattice points per round (A/B runs, tests)
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_spec<true> : k_march_rays_spec<false>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0,
                            (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    else
+        hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
+                           rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
     FOC_CHECK_LAUNCH("march_rays");
     return FOC_OK;
 }

@@ -31,16 +31,19 @@ def convert_activation(name):
     return ACTIVATIONS.get(name, NO_ACTIVATION)
 
 
-def single_pass_backward(input_dim, hidden_dim, num_layers):
-    """Shapes served by k_mlp_bwd_fused (activation gradients, weight gradients and input gradients in one pass)."""
-    return hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4 and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0"
+def single_pass_backward(input_dim, hidden_dim, num_layers, activation=0):
+    """Shapes served by k_mlp_bwd_fused (activation gradients, weight gradients and input gradients in one pass): ReLU / no activation —
+    every NeRF network; the reference's other hidden activations (exponential, sine, sigmoid, squareplus, softplus, utils.h:424-589) take
+    its own data flow, stored activations and a [layers, B, hidden] gradient buffer."""
+    return (activation in (ACTIVATIONS['relu'], NO_ACTIVATION) and hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4
+            and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0")
 
 
 _fused_backward_ok = single_pass_backward       # name used by focnerf_amd.field
 
 
-def _keeps_activations(input_dim, hidden_dim, num_layers):
-    return not (single_pass_backward(input_dim, hidden_dim, num_layers) and os.environ.get("FOC_MLP_RECOMPUTE", "1") != "0")
+def _keeps_activations(input_dim, hidden_dim, num_layers, activation=0):
+    return not (single_pass_backward(input_dim, hidden_dim, num_layers, activation) and os.environ.get("FOC_MLP_RECOMPUTE", "1") != "0")
 
 
 class FusedMLP(AmpOp):
@@ -58,7 +61,7 @@ class FusedMLP(AmpOp):
             # matrix fills the LDS and the layers run one launch each, in place in that buffer
             _kernels.ffmlp_inference(x, blob, n, *net, x.new_empty(n, hidden_dim) if hidden_dim > 128 else None, y)
             return y
-        kept = x.new_empty(num_layers, n, hidden_dim) if _keeps_activations(input_dim, hidden_dim, num_layers) else None
+        kept = x.new_empty(num_layers, n, hidden_dim) if _keeps_activations(input_dim, hidden_dim, num_layers, activation) else None
         _kernels.ffmlp_forward(x, blob, n, *net, kept, y)
         ctx.save_for_backward(x, blob, kept)
         ctx.net, ctx.want_dx = net, want_dx
@@ -72,7 +75,7 @@ class FusedMLP(AmpOp):
         dx = torch.empty_like(x) if ctx.want_dx else x.new_zeros(1)
         d_blob = torch.empty_like(blob)
         # the [num_layers, B, hidden] gradient buffer of ffmlp.py:73 exists only for the two-kernel form (hidden 128, > 4 layers, wide inputs)
-        scratch = None if single_pass_backward(input_dim, hidden_dim, num_layers) else x.new_empty(num_layers, n, hidden_dim)
+        scratch = None if single_pass_backward(input_dim, hidden_dim, num_layers, ctx.net[4]) else x.new_empty(num_layers, n, hidden_dim)
         _kernels.ffmlp_backward(dy.contiguous(), x, blob, kept, n, *ctx.net, ctx.want_dx, scratch, dx, d_blob)
         return (dx if ctx.want_dx else None, d_blob) + (None,) * 8
 

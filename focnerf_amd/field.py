@@ -24,7 +24,7 @@ from .gridencoder import GridEncoder
 
 def field_fusable(encoder, mlp):
     return (isinstance(encoder, GridEncoder) and isinstance(mlp, FFMLP) and encoder.input_dim == 3 and encoder.level_dim == 2
-            and mlp.input_dim == encoder.output_dim and _fused_backward_ok(mlp.input_dim, mlp.hidden_dim, mlp.num_layers)
+            and mlp.input_dim == encoder.output_dim and _fused_backward_ok(mlp.input_dim, mlp.hidden_dim, mlp.num_layers, mlp.activation)
             and mlp.padded_output_dim == 16 and os.environ.get("FOC_FUSED_FIELD", "1") != "0")
 
 

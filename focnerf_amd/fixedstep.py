@@ -143,6 +143,7 @@ def tail_fusable(model):
     cn = getattr(model, "color_net", None)
     want_in = 48 if getattr(model, "uses_object_feature", False) else 32
     return (isinstance(cn, FFMLP) and cn.input_dim == want_in and cn.hidden_dim == 64 and cn.num_layers in (2, 3) and cn.padded_output_dim == 16
+            and cn.activation in (0, 6)
             and isinstance(getattr(model, "encoder_dir", None), SHEncoder) and getattr(model, "geo_feat_dim", 0) == 15
             and (want_in == 32 or getattr(model, "yolo_encoding_dim", 0) == 16) and os.environ.get("FOC_FUSED_TAIL", "1") != "0")
 

@@ -306,3 +306,67 @@ def test_hidden_256_module_trains_and_infers():
     xh, w = x.detach().half(), net.weights.detach().half()
     with pytest.raises(RuntimeError, match="inference_buffer"):
         be.ffmlp_inference(xh, w, 333, 32, 16, 256, 2, 0, 6, None, torch.empty(333, 16, dtype=torch.float16, device="cuda"))
+
+
+ACT_NAMES = {1: "exponential", 2: "sine", 3: "sigmoid", 4: "squareplus", 5: "softplus"}
+
+
+@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (48, 32, 3), (64, 128, 2), (32, 256, 2)])
+@pytest.mark.parametrize("act", [1, 2, 3, 4, 5])
+def test_other_hidden_activations_forward_and_backward(I, Hd, nl, act):
+    """The reference's hidden activations beyond ReLU / None (ffmlp/src/utils.h:424-589; ffmlp.py:87-95 codes 1..5): forward, stored
+    activations, activation gradients, weight gradients and input gradients against the oracle's restatement — the activation in fp32 on the
+    half-rounded sum, the backward factor from the stored post-activation with the reference's half arithmetic, Sine's backward a
+    pass-through exactly as the reference leaves it. Device expf / sinf / logf differ from libm in the last fp32 bits: after the rounding to
+    half nearly every value is the oracle's, the rest one or two half-ulps away."""
+    rng = np.random.default_rng(100 * act + Hd)
+    B = 777
+    x = (rng.standard_normal((B, I)) * 0.5).astype(np.float16)
+    W = (rng.standard_normal(_n_params(I, Hd, nl)) * (0.6 / math.sqrt(Hd))).astype(np.float16)
+    out, fb = _run_forward(x, W, I, Hd, nl, act, True)
+    out_ref, fb_ref = oracle.ffmlp_forward(x, W, I, Hd, nl, act)
+    assert np.isfinite(out_ref.astype(np.float32)).all() and np.abs(fb_ref.astype(np.float32)).max() > 0.1
+    assert_half_close(fb, fb_ref, ulps=3.0, atol=2e-3, what=f"{ACT_NAMES[act]}: stored activations")
+    assert_half_close(out, out_ref, ulps=3.0, atol=4e-3, what=f"{ACT_NAMES[act]}: outputs")
+    assert (fb[0] == fb_ref[0]).mean() > 0.9, f"first layer: only {(fb[0] == fb_ref[0]).mean():.3f} of the activations are the oracle's bits"
+    out_inf = _run_forward(x, W, I, Hd, nl, act, False)
+    assert np.array_equal(out_inf, out), "inference and training forward are the same arithmetic"
+    # ---- backward on the ORACLE's forward buffer (so that both sides transfer through identical post-activations)
+    be = _be()
+    g = (rng.standard_normal((B, 16)) * 0.1).astype(np.float16)
+    gw_ref, gi_ref, bb_ref = oracle.ffmlp_backward(g, x, W, fb_ref, I, Hd, nl, act, True)
+    gt, xt, Wt, fbt = (torch.from_numpy(a).cuda() for a in (g, x, W, fb_ref))
+    bb = torch.zeros(nl, B, Hd, dtype=torch.float16, device="cuda")
+    gi = torch.zeros(B, I, dtype=torch.float16, device="cuda")
+    gw = torch.zeros_like(Wt)
+    be.ffmlp_backward(gt, xt, Wt, fbt, B, I, 16, Hd, nl, act, 6, True, bb, gi, gw)
+    s = np.abs(bb_ref.astype(np.float32)).max()
+    assert s > 0 and np.abs(to_np(bb).astype(np.float32) - bb_ref.astype(np.float32)).max() <= 4e-3 * s
+    assert (to_np(bb)[0] == bb_ref[0]).mean() > 0.97            # the first transfer sees identical operands: the half arithmetic is the reference's
+    for name, a, b in (("grad_inputs", to_np(gi), gi_ref), ("grad_weights", to_np(gw), gw_ref)):
+        s = np.abs(b.astype(np.float32)).max()
+        assert s > 0 and np.abs(a.astype(np.float32) - b.astype(np.float32)).max() <= 5e-3 * s, name
+    if act == 2:                                                # Sine: the reference's backward leaves the fragment untouched (utils.h:549-553)
+        Wo = W[Hd * I + (nl - 1) * Hd * Hd:].reshape(16, Hd).astype(np.float32)
+        plain = (g.astype(np.float32) @ Wo).astype(np.float16)
+        assert_half_close(to_np(bb)[0], plain, ulps=2.0, atol=1e-4, what="sine: gradient passes through unchanged")
+
+
+def test_other_activations_through_the_module_and_autograd():
+    """FFMLP(activation='sigmoid' | ...) trains through autograd: non-ReLU activations keep the reference's data flow (stored activations +
+    gradient buffer) instead of the single-pass backward, and the fused paths that assume ReLU stay away from them."""
+    from focnerf_amd.ffmlp import FFMLP, single_pass_backward
+    from focnerf_amd.field import field_fusable
+    from focnerf_amd.gridencoder import GridEncoder
+    assert single_pass_backward(32, 64, 2, 0) and not single_pass_backward(32, 64, 2, 3)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2).cuda()
+    for name in ("sigmoid", "softplus", "squareplus", "exponential", "sine"):
+        net = FFMLP(32, 3, 64, 2, activation=name).cuda().train()
+        assert net.activation in ACT_NAMES and not field_fusable(enc, net)
+        x = (torch.randn(500, 32, device="cuda") * 0.5).half().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = net(x)
+        (y.float() ** 2).sum().backward()
+        ref, _ = oracle.ffmlp_forward(to_np(x), to_np(net.weights).astype(np.float16), 32, 64, 2, net.activation)
+        assert_half_close(to_np(y), ref[:, :3], ulps=3.0, atol=4e-3, what=name)
+        assert torch.isfinite(net.weights.grad).all() and net.weights.grad.abs().max() > 0 and x.grad.abs().max() > 0

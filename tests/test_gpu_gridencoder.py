@@ -103,6 +103,9 @@ def test_backward(case, dtype, atomic, monkeypatch):
     grad[:, 7] = 0                                     # zero-gradient rows are skipped
     _, dy = oracle.grid_encode_forward(x, table, off, D, C, L, S, H, True, gridtype, ac, interp, acc_mode=1)
     ge_ref, gi_ref = oracle.grid_encode_backward(grad, x, off, int(off[-1]), D, C, L, S, H, dy, gridtype, ac, interp)
+    # the same (half-valued) gradients summed in fp32: what the binned path's fixed-point sums approximate (one rounding per row)
+    ge_ref32 = oracle.grid_encode_backward(grad.astype(np.float32), x, off, int(off[-1]), D, C, L, S, H, None, gridtype, ac, interp)
+    binned = atomic == "0" and D == 3 and C == 2 and gridtype == 0          # the shapes gb_check routes to the partition + LDS path
     tdt = torch.float32 if dtype == np.float32 else torch.float16
     xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
     be = _be()
@@ -118,9 +121,15 @@ def test_backward(case, dtype, atomic, monkeypatch):
             np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
             np.testing.assert_allclose(to_np(gi).astype(np.float32), gi_ref.astype(np.float32), atol=1e-3, rtol=1e-3)
         else:
-            # half atomics round the running sum at every add (as the reference's __half2 atomicAdd does)
             scale = np.abs(want).max()
-            assert np.abs(got - want).max() <= 2e-2 * scale + 1e-3
+            if binned:
+                # exact fixed-point sums rounded to half once per row: against the fp32-summed oracle, like test_backward_ray_coherent
+                want32 = ge_ref32.astype(np.float32)
+                assert np.abs(got - want32).max() <= 2e-3 * np.abs(want32).max() + 1e-3, np.abs(got - want32).max()
+            else:
+                # half atomics round the running sum at every add (as the reference's __half2 atomicAdd does, which the oracle's fp16 mode
+                # restates): order-dependent, so the bound is that of a handful of half roundings per row
+                assert np.abs(got - want).max() <= 2e-2 * scale + 1e-3
             np.testing.assert_allclose(to_np(gi).astype(np.float32), gi_ref.astype(np.float32), atol=5e-2, rtol=5e-2)
         # checksum: interpolation weights sum to 1, so per level sum(grad_embeddings) == sum(grad) over in-range points
         inb = np.all((x >= 0) & (x <= 1), axis=1)

@@ -272,10 +272,10 @@ def _set_march_form(monkeypatch, form):
     """R9's three forms: 16 lanes per ray (k_march_rays_row), one ray per lane looking 8 lattice points ahead (k_march_rays_spec), and
     the plain one-lookup-at-a-time loop (k_march_rays)."""
     monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "1000000000" if form == "row" else "0")
-    if form == "serial":
-        monkeypatch.setenv("FOC_MARCH_RAYS_SERIAL", "1")
+    if form == "spec":
+        monkeypatch.setenv("FOC_MARCH_RAYS_SPEC", "1")
     else:
-        monkeypatch.delenv("FOC_MARCH_RAYS_SERIAL", raising=False)
+        monkeypatch.delenv("FOC_MARCH_RAYS_SPEC", raising=False)
 
 
 @pytest.mark.parametrize("form", ["row", "spec", "serial"])

@@ -18,10 +18,10 @@ for n_step in (1, 3, 8):
     outs = {}
     for form, v in (("lane", "0"), ("row", "1000000000"), ("spec", "0")):
         os.environ["FOC_MARCH_RAYS_ROW_MAX"] = v
-        if form == "lane":
-            os.environ["FOC_MARCH_RAYS_SERIAL"] = "1"
+        if form == "spec":
+            os.environ["FOC_MARCH_RAYS_SPEC"] = "1"
         else:
-            os.environ.pop("FOC_MARCH_RAYS_SERIAL", None)
+            os.environ.pop("FOC_MARCH_RAYS_SPEC", None)
         M = N * n_step
         x = torch.zeros(M, 3, device="cuda"); dd = torch.zeros(M, 3, device="cuda"); dl = torch.zeros(M, 2, device="cuda")
         t0 = time.perf_counter()
