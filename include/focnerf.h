@@ -239,10 +239,12 @@ int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B
  * inputs [B,input_dim], outputs [B,16] (output_dim is the padded 16), row-major.
  * Any B >= 1 is accepted (the reference kernels need a multiple of 128 and its wrapper pads with a copy,
  * ffmlp/ffmlp.py:157-159; here the ragged last tile is handled in the kernels, so no padded copy is needed);
- * hidden_dim in {16,32,64,128}; input_dim % 16 == 0; output_dim <= 16; num_layers >= 2.
- * activation codes follow ffmlp.py:86-93 (0 = relu ... 6 = none); hidden activation
- * relu|none, output activation none (the only combinations FFMLP can construct,
- * ffmlp.py:107-108).
+ * hidden_dim in {16,32,64,128,256}; input_dim % 16 == 0; output_dim <= 16; num_layers >= 2.
+ * activation codes follow ffmlp.py:86-93: 0 relu, 1 exponential, 2 sine, 3 sigmoid, 4 squareplus, 5 softplus, 6 none — the hidden
+ * activations of ffmlp/src/utils.h:424-589, evaluated as there (fp32 function of the half-rounded sum; the backward factor from the stored
+ * post-activation in half arithmetic; Sine's backward a pass-through, as the reference leaves it). Codes 1..5 take the reference's data
+ * flow: foc_ffmlp_backward then needs forward_buffer and backward_buffer (the single-pass kernel and the planar / head / whole-field forms
+ * serve relu|none, which is what every FOC network uses). Output activation none (FFMLP can construct no other, ffmlp.py:107-108).
  * ------------------------------------------------------------------------- */
 
 /* ffmlp.cu:635-671  ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers,

@@ -345,3 +345,32 @@ def test_foc_objects_through_render_field4_and_the_combiner(monkeypatch):
     with torch.no_grad(), half_cache_scope():
         other = render_field4(objs[0], vo, vd, num_steps=T, yolo_details=(None, None, feats[1]))
     assert (other[..., 1:] - a[0][..., 1:]).abs().max() > 1e-3
+
+
+def test_object_feature_encoder_vector_path_equals_the_linear_layers():
+    """`_TinyMLP` evaluates the one-vector case as matrix-vector products in fp32 (network_foc._tiny_mlp_vec): same values and gradients as
+    its two bias-free linear layers, with and without autocast."""
+    from focnerf_amd.network_foc import _TinyMLP
+    torch.manual_seed(4)
+    m = _TinyMLP(144, 16).cuda()
+    x0 = torch.randn(1, 144, device="cuda")
+    gy = torch.randn(1, 16, device="cuda")
+    res = {}
+    for name in ("vector", "linear", "vector_autocast"):
+        x = x0.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        if name == "linear":
+            y = m.l1(torch.relu(m.l0(x)))
+        elif name == "vector":
+            y = m(x)
+        else:
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = m(x)
+        assert y.dtype == torch.float32 and y.shape == (1, 16)
+        y.backward(gy)
+        res[name] = (y.detach().clone(), x.grad.clone(), m.l0.weight.grad.clone(), m.l1.weight.grad.clone())
+    for name in ("vector", "vector_autocast"):
+        for a, b in zip(res[name], res["linear"]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), name
+    # a batch of vectors takes the linear layers
+    assert m(torch.randn(3, 144, device="cuda")).shape == (3, 16)
