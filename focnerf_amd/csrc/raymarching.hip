@@ -489,15 +489,12 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(const float *__rest
 }
 
 // ---------------------------------------------------------------- R9 (raymarching.cu:700-805)
-__global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
-                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
-                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                             const float *__restrict__ noises) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    if (index < 0) return;             // a list entry marked dead (-1, as composite_rays leaves them): its slots stay zero = "terminated"
+// The serial loop of one list entry n (ray `index`). BAIL: stop at the first empty cell and report it (the two-phase form below: such a
+// ray is a "walker" and is marched again, from its start, by the walkers' kernel).
+template <bool BAIL>
+__device__ __forceinline__ bool rm_lane_walk(uint32_t n, int index, uint32_t n_step, const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                             const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, const RmParams &p, const float *__restrict__ fars,
+                                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
     const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
     const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
@@ -516,8 +513,24 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
             pl[0] = c.dt; pl[1] = t - last_t;
             last_t = t;
             px += 3; pd += 3; pl += 2; step++;
-        } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+        } else {
+            if (BAIL) return true;
+            t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+        }
     }
+    return false;
+}
+
+__global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    if (index < 0) return;             // a list entry marked dead (-1, as composite_rays leaves them): its slots stay zero = "terminated"
+    (void)rm_lane_walk<false>(n, index, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
 }
 
 // ---------------------------------------------------------------- R9, one ray per lane, K lattice points per round
@@ -604,18 +617,13 @@ __global__ void __launch_bounds__(64) k_march_rays_spec(uint32_t n_alive, uint32
 // wave per ray (G = 64, the training kernel's form) would spend 64 recurrence steps for the 8 samples an iteration asks for; G = 16
 // (one DPP row, 4 rays per wave) generates what a burst of 8 typically consumes in one or two rounds.
 #define RM_ROW_MAX_ROUNDS (1u << 14)                       // x 16 lattice points: far beyond any real ray; makes the loop finite whatever the inputs
+// all 64 lanes of a wave call this together; `have`, `n`, `index` are uniform over each 16-lane group
 template <bool MED3>
-__global__ void __launch_bounds__(256) k_march_rays_row(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
-                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
-                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                             const float *__restrict__ noises) {
+__device__ __forceinline__ void rm_row_walk(bool have, uint32_t n, int index, uint32_t n_step, const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+                                            const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, const RmParams &p, const float *__restrict__ fars,
+                                            float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
     constexpr uint32_t G = 16u;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (G - 1u), gbase = lane & ~(G - 1u), gshift = gbase;
-    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) / G;
-    const int listed = n < n_alive ? rays_alive[n] : -1;
-    const bool have = listed >= 0;     // beyond the list, or an entry marked dead (-1): nothing to march
-    const int index = have ? listed : 0;
     const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
     const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
@@ -689,6 +697,71 @@ __global__ void __launch_bounds__(256) k_march_rays_row(uint32_t n_alive, uint32
         if (emitted) last_t = top_end;
         step += (uint32_t)__builtin_popcount(emitted);
         t_cur = t_next;
+    }
+}
+
+template <bool MED3>
+__global__ void __launch_bounds__(256) k_march_rays_row(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    const uint32_t n = (blockIdx.x * 256u + threadIdx.x) / 16u;
+    const int listed = n < n_alive ? rays_alive[n] : -1;
+    const bool have = listed >= 0;     // beyond the list, or an entry marked dead (-1): nothing to march
+    rm_row_walk<MED3>(have, n, have ? listed : 0, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+}
+
+// ---------------------------------------------------------------- R9 in two phases (the native render step, csrc/occrender.hip)
+// A launch with hundreds of thousands of live rays asks each of them for one sample: a ray inside the object evaluates one cell and is
+// done, while the few percent that have just left it walk ~100 empty cells to the far side of the box — and every wave runs as long as
+// its longest lane (48 us per launch, of which the cell evaluations proper are ~3 us). Phase 1 (k_march_rays_first): the serial loop
+// per lane, but a ray that meets an EMPTY cell stops there and puts its list entry on a worklist (one atomic per wave). Phase 2
+// (k_march_walkers): the worklist's rays are marched again from their start — densely packed: 16 lanes per ray while there are few of them
+// (chains 16 times shorter), one ray per lane when the list is long (the first iteration of a view, where every ray starts in empty
+// space). Same samples as the single kernel, bit for bit: a walker's slots are simply written twice with the same values.
+__global__ void __launch_bounds__(256) k_march_rays_first(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises, int32_t *__restrict__ worklist, int32_t *__restrict__ wl_count) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    bool walker = false;
+    if (n < n_alive) {
+        const int index = rays_alive[n];
+        if (index >= 0) walker = rm_lane_walk<true>(n, index, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    }
+    const uint64_t mask = __ballot(walker);
+    if (mask != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        int base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(wl_count, (int)__builtin_popcountll(mask));
+        base = __shfl(base, (int)__builtin_ctzll(mask), 64);
+        if (walker) worklist[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)n;
+    }
+}
+
+template <bool MED3>
+__global__ void __launch_bounds__(256) k_march_walkers(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises, const int32_t *__restrict__ worklist, const int32_t *__restrict__ wl_count, uint32_t row_max) {
+    const uint32_t count = min((uint32_t)max(*wl_count, 0), n_alive);         // grid-uniform
+    if (count <= row_max) {
+        const uint32_t groups_total = gridDim.x * 16u;                          // 16-lane groups of the grid
+        const uint32_t wave_first = (blockIdx.x * 256u + (threadIdx.x & ~63u)) / 16u;
+        for (uint32_t base = wave_first; base < count; base += groups_total) {  // wave-uniform trip count: the four groups walk together
+            const uint32_t i = base + ((threadIdx.x & 63u) >> 4);
+            const bool have = i < count;
+            const uint32_t n = have ? (uint32_t)worklist[i] : 0u;
+            rm_row_walk<MED3>(have, n, have ? rays_alive[n] : 0, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+            const uint32_t n = (uint32_t)worklist[i];
+            (void)rm_lane_walk<false>(n, rays_alive[n], n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+        }
     }
 }
 
@@ -932,6 +1005,36 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
         hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
                            rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
     FOC_CHECK_LAUNCH("march_rays");
+    return FOC_OK;
+}
+
+/* R9 in two phases (k_march_rays_first + k_march_walkers): `scratch` = int32[n_alive + 4], its first word the worklist length, which the
+ * caller has zeroed on this stream. Same arguments and results as foc_march_rays. */
+int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                             const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                             const float *noises, int32_t *scratch, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    (void)nears;
+    if (n_alive == 0) return FOC_OK;
+    FOC_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises && scratch, FOC_E_INVALID,
+                "march_rays_two_phase: null pointer");
+    FOC_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 512 && max_steps >= 1 && n_step >= 1 && n_step <= 16, FOC_E_INVALID,
+                "march_rays_two_phase: unsupported C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
+    FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_two_phase: C*H^3 exceeds 2^24");
+    const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *wl_count = scratch, *worklist = scratch + 4;
+    hipLaunchKernelGGL(k_march_rays_first, dim3(foc_div_up(n_alive, 256)), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars,
+                       xyzs, dirs, deltas, noises, worklist, wl_count);
+    FOC_CHECK_LAUNCH("march_rays(first visits)");
+    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");
+    const uint32_t row_max = (uint32_t)(row_env ? atol(row_env) : 131072);
+    uint32_t blocks = foc_div_up((uint64_t)n_alive * 16u, 256);
+    if (blocks > 4096u) blocks = 4096u;                     // 16 workgroups per CU; longer worklists are walked grid-stride
+    hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_walkers<true> : k_march_walkers<false>, dim3(blocks), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises, worklist, wl_count, row_max);
+    FOC_CHECK_LAUNCH("march_rays(walkers)");
     return FOC_OK;
 }
 

@@ -227,6 +227,9 @@ class NeRFRenderer(nn.Module):
             alive = torch.arange(n, dtype=torch.int32, device=dev)
             t_now = near.clone()
             marched = 0
+            if device_compaction and self._native_loop_ok(o):
+                self._native_inference_loop(o, d, near, far, alive, t_now, opacity, depth, image, perturb, dt_gamma, max_steps, T_thresh)
+                marched = max_steps                                   # the Python loop below has nothing left to do
             import contextlib
             from .field import half_cache_scope
             # the loop evaluates the same parameters once per burst: one fp16 conversion per view when nothing can write them in between
@@ -269,6 +272,61 @@ class NeRFRenderer(nn.Module):
                     it += 1
         out['image'], out['depth'] = self._finish(image, depth, opacity, near, far, background, lead)
         return out
+
+    # ------------------------------------------------------------------ the inference loop, one native call per iteration
+    def _native_loop_ok(self, o):
+        """`foc_occ_render_step` serves the networks of the whole-field kernel (hash grid D = 3, C = 2 -> 64-wide sigma net -> SH + 64-wide
+        colour net) at density_scale 1, on the GPU, under autocast (fp16 table and weights)."""
+        from .field import infer_fusable
+        return (o.is_cuda and torch.is_autocast_enabled() and not torch.is_grad_enabled() and infer_fusable(self) and self.density_scale == 1
+                and not getattr(self, "uses_object_feature", False) and self.encoder.gridtype_id == 0 and not self.encoder.align_corners
+                and self.encoder.interp_id == 0 and os.environ.get("FOC_RENDER_NATIVE", "1") != "0")
+
+    def _native_inference_loop(self, o, d, near, far, alive, t_now, opacity, depth, image, perturb, dt_gamma, max_steps, T_thresh):
+        """The loop of legacy/nerf/renderer.py:323-372 with every iteration ONE call into the library (csrc/occrender.hip: march in two
+        phases, encode, whole-field kernel, composite, compaction) on buffers allocated once per view; the live count is read
+        `FOC_RENDER_COUNT_LAG` iterations late, as in the Python form of the loop. Same samples, same per-ray accumulation order."""
+        import numpy as np
+        from ._lib import lib, ptr, stream_of, check
+        from .field import _half_of, half_cache_scope
+        n, dev = o.shape[0], o.device
+        enc, sn, cn = self.encoder, self.sigma_net, self.color_net
+        L = enc.offsets.shape[0] - 1
+        lag = max(1, int(os.environ.get("FOC_RENDER_COUNT_LAG", "2")))
+        samples = torch.empty(n * 8, dtype=torch.float32, device=dev)
+        xn = torch.empty(n * 3, dtype=torch.float32, device=dev)
+        planes = torch.empty(L * n * 2, dtype=torch.float16, device=dev)
+        sigma, rgb = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n * 3, dtype=torch.float32, device=dev)
+        lists = [alive, torch.empty_like(alive)]
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.foc_occ_render_step_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        still = torch.zeros(n, dtype=torch.float32, device=dev)
+        jitter = torch.rand(n, dtype=torch.float32, device=dev) if perturb else still
+        ring = torch.empty(lag + 1, dtype=torch.int32).pin_memory()
+        waiting, live, marched, it = [], n, 0, 0
+        S = float(np.log2(enc.per_level_scale))
+        with half_cache_scope():
+            emb, ws, wc = _half_of(enc.embeddings), _half_of(sn.weights), _half_of(cn.weights)
+            st = stream_of(o)
+            while marched < max_steps and live > 0:
+                burst = max(min(n // live, 8), 1)
+                src, dst = lists[it & 1], lists[(it & 1) ^ 1]
+                check(lib.foc_occ_render_step(live, burst, ptr(src), ptr(dst), ptr(count), ptr(t_now), ptr(o), ptr(d), float(self.bound), float(dt_gamma),
+                                              int(max_steps), self.cascade, self.grid_size, ptr(self.density_bitfield), ptr(near), ptr(far),
+                                              ptr(jitter if marched == 0 else still), ptr(samples), ptr(xn), ptr(planes), ptr(sigma), ptr(rgb), ptr(emb),
+                                              ptr(enc.offsets), None, L, S, enc.base_resolution, ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, sn.activation,
+                                              None, float(T_thresh), ptr(opacity), ptr(depth), ptr(image), ptr(scratch), st), "occ_render_step")
+                slot = it % (lag + 1)
+                ring[slot:slot + 1].copy_(count, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                waiting.append((ev, slot))
+                if len(waiting) > lag:
+                    ev0, s0 = waiting.pop(0)
+                    ev0.synchronize()
+                    live = min(live, int(ring[s0]))
+                marched += burst
+                it += 1
 
     # ------------------------------------------------------------------ occupancy-grid maintenance (device side)
     def _require_grid(self, what):

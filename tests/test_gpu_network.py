@@ -89,21 +89,31 @@ def test_cuda_ray_training_reduces_loss():
     assert m.density_bitfield.dtype == torch.uint8 and torch.isfinite(m.density_grid).all()
 
 
-def test_inference_loop_matches_training_composite():
+def test_inference_loop_matches_training_composite(monkeypatch):
     """The incremental inference path (march_rays / composite_rays) and the one-shot training path
-    (march_rays_train / composite_rays_train) render the same image for the same network."""
+    (march_rays_train / composite_rays_train) render the same image for the same network; and the three forms of the inference loop — the
+    reference's boolean-mask compaction with a host round trip per iteration, device compaction with the count read late (Python loop), and
+    one native call per iteration (csrc/occrender.hip: two-phase march, encode, whole-field kernel, composite, compaction) — give the SAME
+    BITS: every ray sees the same samples in the same order whatever the burst schedule."""
     from focnerf_amd import synthetic
     bound = 2
     m = _model(bound, True, seed=3)
     o, d = synthetic.make_view_rays(48, 48, bound, 1, seed=2, device="cuda")
+    kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         m.train()
         a = m.render(o, d, staged=False, perturb=False, force_all_rays=True, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0)
         m.eval()
-        b = m.render(o, d, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
-        c = m.render(o, d, staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4, device_compaction=True)
+        b = m.render(o, d, **kw)
+        assert m._native_loop_ok(o.view(-1, 3))
+        c = m.render(o, d, device_compaction=True, **kw)                  # native loop
+        monkeypatch.setenv("FOC_RENDER_NATIVE", "0")
+        e = m.render(o, d, device_compaction=True, **kw)                  # Python loop, late count
+        monkeypatch.setenv("FOC_RENDER_COUNT_LAG", "0")
+        f = m.render(o, d, device_compaction=True, **kw)                  # Python loop, count read every iteration
     assert torch.allclose(a["image"], b["image"], atol=2e-3)
-    assert torch.equal(b["image"], c["image"])
+    for other in (c, e, f):
+        assert torch.equal(b["image"], other["image"]) and torch.equal(b["depth"], other["depth"])
     assert (a["image"] < 0.99).any(), "the view should hit the object"
 
 

@@ -18,7 +18,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_wr
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 "$R/bench.py" $BENCH_ARGS > "$OUT/pmc_mfma.log" 2>&1
 python3 "$R/tools/summarize_profiles.py" "$OUT" "$TAG"
 # kernel-trace summaries of the three other measured paths (configs[2] training step, both render loops)
-for pair in occupancy_train:prof_occupancy.py render_fixed:time_render_fixed.py render_occupancy:time_render_occ.py; do
+for pair in occupancy_train:prof_occupancy.py render_fixed:time_render_fixed.py render_occupancy:time_render_occ.py; do   # (render_occupancy: the native loop, one C call per iteration)
   name=${pair%%:*}; script=${pair##*:}
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$R/tools/$script" > "$OUT/$name.log" 2>&1
   cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${name}_kernel_stats.csv"
