@@ -1384,7 +1384,12 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
         const uint32_t chunks = foc_div_up(B, 256);
         const uint32_t lc = lm_plain ? ge_small_levels(L, lv) : 0u;
         const uint32_t groups = lc >= 2u ? L - lc + 1u : L;
-        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), 0, st, inputs, (const T *)emb, offsets,
+        // FOC_GRID_FWD_LDS=<bytes>: unused dynamic LDS per workgroup — caps the resident workgroups per CU (occupancy experiments: what the
+        // forward's gathers cost with fewer waves in flight)
+        static int pad_lds = -1;
+        if (pad_lds < 0) { const char *e = getenv("FOC_GRID_FWD_LDS"); pad_lds = e ? atoi(e) : 0; }
+        if (pad_lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grid_fwd_lbc<T, D, C>), hipFuncAttributeMaxDynamicSharedMemorySize, pad_lds);
+        hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), (size_t)pad_lds, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,
                            ge_pairs_mode(emb, dy_dx, sizeof(T), D, C, gridtype, ac, interp), lc);
     }

@@ -470,7 +470,6 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
     n_live = dense.shape[0]
     for name in ("holes", "padded"):
         x, dl, lst2, ws, dp, im, t_now = out[name]
-        live_rows = (out[name][2] != -1) | (holes >= 0 if name == "holes" else torch.arange(N, device="cuda") < n_live)
         sel = (holes >= 0) if name == "holes" else (torch.arange(N, device="cuda") < n_live)
         xs, dls = x[: N * n_step].view(N, n_step, 3), dl[: N * n_step].view(N, n_step, 2)
         assert torch.equal(xs[sel], out["dense"][0][: n_live * n_step].view(n_live, n_step, 3))
