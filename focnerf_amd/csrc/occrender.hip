@@ -6,27 +6,25 @@
 // nine launches — from C, on buffers the caller allocated once per view:
 //
 //   prepare   zero the iteration's sample slots (the reference's torch.zeros, raymarching.py:334-336), fill the output list with -1,
-//             reset the walkers' worklist
-//   march     foc_march_rays_two_phase (raymarching.hip): first visits per lane, walkers densely packed
-//   normalise x -> (x + bound) * (1 / (2 bound))      (gridencoder/grid.py:149 as torch evaluates it: division by a scalar = multiply by its reciprocal)
+//             reset the walkers' worklist and the compaction's block counts
+//   march     foc_march_rays_two_phase (raymarching.hip): first visits per lane, walkers densely packed; the positions leave already
+//             normalised, x -> (x + bound) * (1 / (2 bound))  (gridencoder/grid.py:149 as torch evaluates it: division by a scalar =
+//             multiplication by its reciprocal) — nobody but the encoder reads them here
 //   encode    foc_grid_encode_forward ([L, M, 2] planes)
 //   field     foc_nerf_field_inference (sigma net -> head -> colour net, per-sample directions)
-//   composite foc_composite_rays (in place: weights_sum, depth, image, rays_t; finished rays marked -1)
-//   compact   foc_compact_alive into the output list, whose tail stays -1 (march / composite skip such entries)
+//   composite foc_composite_compact: composite_rays in place (weights_sum, depth, image, rays_t; finished rays marked -1), its waves counting
+//             their survivors, then scan + ordered scatter into the output list, whose tail stays -1 (march / composite skip such entries)
 //
 // The live count stays on the device (`count`, one int); the caller reads it late (focnerf_amd/renderer.py) and passes an upper bound.
 #include "common.h"
 
 __global__ void __launch_bounds__(256) k_occ_prepare(uint32_t *__restrict__ samples, uint64_t n_sample_words, int32_t *__restrict__ list_out, uint32_t n_list,
-                                                     int32_t *__restrict__ wl_count) {
+                                                     int32_t *__restrict__ wl_count, int32_t *__restrict__ block_counts, uint32_t n_blocks) {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_sample_words; i += stride) samples[i] = 0u;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_list; i += stride) list_out[i] = -1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_blocks; i += stride) block_counts[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *wl_count = 0;
-}
-
-__global__ void __launch_bounds__(256) k_occ_normalise(const float *__restrict__ xyzs, float *__restrict__ xn, uint64_t n, float bound, float inv) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) xn[i] = (xyzs[i] + bound) * inv;
 }
 
 extern "C" {
@@ -35,7 +33,10 @@ extern "C" {
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                             const float *noises, int32_t *scratch, void *stream);
+                             const float *noises, int32_t *scratch, int normalised, void *stream);
+int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                          const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream);
 
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays) {
     // int32[n + 4] worklist | compaction block counts int32[n / 1024 + 2], both 256-byte aligned
@@ -47,7 +48,7 @@ uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays) {
 int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, int32_t *rays_alive_out, int32_t *count,
                         float *rays_t, const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
                         uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, const float *noises,
-                        float *samples /* [n_alive*n_step*8]: xyzs | dirs | deltas */, float *xn /* [n_alive*n_step*3] */,
+                        float *samples /* [n_alive*n_step*8]: normalised xyzs | dirs | deltas */,
                         void *planes /* fp16 [L, n_alive*n_step, 2] */, float *sigma, float *rgb,
                         const void *embeddings, const int32_t *offsets, const int32_t *offsets_host, uint32_t L, float S, uint32_t base_res,
                         const void *sigma_weights, uint32_t sigma_layers, const void *color_weights, uint32_t color_layers, uint32_t activation,
@@ -56,7 +57,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     FOC_REQUIRE(count, FOC_E_INVALID, "occ_render_step: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (n_alive == 0) return foc_zero_async(count, sizeof(int32_t), st) == hipSuccess ? FOC_OK : FOC_E_LAUNCH;
-    FOC_REQUIRE(rays_alive && rays_alive_out && rays_t && rays_o && rays_d && grid && fars && noises && samples && xn && planes && sigma && rgb && embeddings &&
+    FOC_REQUIRE(rays_alive && rays_alive_out && rays_t && rays_o && rays_d && grid && fars && noises && samples && planes && sigma && rgb && embeddings &&
                 offsets && sigma_weights && color_weights && weights_sum && depth && image && scratch, FOC_E_INVALID, "occ_render_step: null pointer");
     FOC_REQUIRE(n_step >= 1 && n_step <= 16, FOC_E_INVALID, "occ_render_step: n_step must be in [1, 16] (got %u)", n_step);
     const uint64_t M = (uint64_t)n_alive * n_step;
@@ -64,22 +65,20 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     float *xyzs = samples, *dirs = samples + 3 * M, *deltas = samples + 6 * M;
     int32_t *worklist = reinterpret_cast<int32_t *>(scratch);
     int32_t *compact_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scratch) + ((((uint64_t)n_alive + 4) * 4 + 255) & ~(uint64_t)255));
-    hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d(M * 8, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), M * 8, rays_alive_out, n_alive, worklist);
+    hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d(M * 8, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), M * 8, rays_alive_out, n_alive, worklist,
+                       compact_scratch, n_alive / 1024 + 2);
     FOC_CHECK_LAUNCH("occ_render_step(prepare)");
     int rc = foc_march_rays_two_phase(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas,
-                                      noises, worklist, stream);
+                                      noises, worklist, 1, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_occ_normalise, dim3(foc_grid_1d(M * 3, 256)), dim3(256), 0, st, xyzs, xn, M * 3, bound, 1.0f / (2.0f * bound));
-    FOC_CHECK_LAUNCH("occ_render_step(normalise)");
-    rc = foc_grid_encode_forward(xn, embeddings, offsets, planes, (uint32_t)M, 3, 2, L, S, base_res, nullptr, 0, 0, 0, FOC_F16, offsets_host, stream);
+    rc = foc_grid_encode_forward(xyzs, embeddings, offsets, planes, (uint32_t)M, 3, 2, L, S, base_res, nullptr, 0, 0, 0, FOC_F16, offsets_host, stream);
     if (rc) return rc;
     rc = foc_nerf_field_inference(planes, 1, dirs, 1, 0, (uint32_t)M, sigma_weights, sigma_layers, color_weights, color_layers, 64, activation, (uint32_t)M, sigma, rgb,
                                   obj_feat, stream);
     if (rc) return rc;
     // composite marks finished rays in the INPUT list; the compaction then writes the survivors to the output list
-    rc = foc_composite_rays(n_alive, n_step, T_thresh, const_cast<int32_t *>(rays_alive), rays_t, sigma, rgb, deltas, weights_sum, depth, image, stream);
-    if (rc) return rc;
-    return foc_compact_alive(rays_alive, n_alive, rays_alive_out, count, compact_scratch, stream);
+    return foc_composite_compact(n_alive, n_step, T_thresh, const_cast<int32_t *>(rays_alive), rays_t, sigma, rgb, deltas, weights_sum, depth, image, rays_alive_out,
+                                 count, compact_scratch, stream);
 }
 
 } // extern "C"

@@ -146,7 +146,10 @@ struct RmCell { float x, y, z, dt, mip_bound; int nx, ny, nz; };
 struct RmParams {
     float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
     uint32_t H;
+    float norm_inv;                    // 0: sample positions leave as they are; else they leave as (x + bound) * norm_inv, the encoder's [0,1] coordinates
 };
+// position of an emitted sample as it is stored (the native render step asks for the normalised form: csrc/occrender.hip)
+__device__ __forceinline__ float rm_out(const RmParams &p, float x) { return p.norm_inv != 0.0f ? (x + p.bound) * p.norm_inv : x; }
 
 __device__ __forceinline__ bool rm_cell(const uint8_t *__restrict__ grid, const RmParams &p, float ox, float oy, float oz,
                                         float dx, float dy, float dz, float t, RmCell &c) {
@@ -197,6 +200,7 @@ static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, 
     p.H3 = (float)(H * H * H);
     p.Hf = (float)H; p.Cf = (float)C; p.Hm1 = (float)(H - 1);
     p.H = H;
+    p.norm_inv = 0.0f;
     return p;
 }
 
@@ -507,7 +511,7 @@ __device__ __forceinline__ bool rm_lane_walk(uint32_t n, int index, uint32_t n_s
     RmCell c;
     while (t < far && step < n_step) {
         if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
-            px[0] = c.x; px[1] = c.y; px[2] = c.z;
+            px[0] = rm_out(p, c.x); px[1] = rm_out(p, c.y); px[2] = rm_out(p, c.z);
             pd[0] = dx; pd[1] = dy; pd[2] = dz;
             t += c.dt;
             pl[0] = c.dt; pl[1] = t - last_t;
@@ -570,7 +574,7 @@ __device__ __forceinline__ void rm_window(RmWalk &w, const uint8_t *__restrict__
         if (!(L[j] < far) || w.step >= n_step) { w.done = true; continue; }    // the loop condition of raymarching.cu:745
         if (occ[j]) {
             const float t_new = L[j] + cdt[j];
-            px[w.step * 3] = cx[j]; px[w.step * 3 + 1] = cy[j]; px[w.step * 3 + 2] = cz[j];
+            px[w.step * 3] = rm_out(p, cx[j]); px[w.step * 3 + 1] = rm_out(p, cy[j]); px[w.step * 3 + 2] = rm_out(p, cz[j]);
             pd[w.step * 3] = dx; pd[w.step * 3 + 1] = dy; pd[w.step * 3 + 2] = dz;
             pl[w.step * 2] = cdt[j]; pl[w.step * 2 + 1] = t_new - w.last_t;
             w.last_t = t_new;
@@ -688,7 +692,7 @@ __device__ __forceinline__ void rm_row_walk(bool have, uint32_t n, int index, ui
         const float prev_end = __shfl(t_new, prev_lane, 64);
         if ((emitted >> sub) & 1u) {
             const uint32_t slot = step + (uint32_t)__builtin_popcount(before);
-            px[slot * 3] = c.x; px[slot * 3 + 1] = c.y; px[slot * 3 + 2] = c.z;
+            px[slot * 3] = rm_out(p, c.x); px[slot * 3 + 1] = rm_out(p, c.y); px[slot * 3 + 2] = rm_out(p, c.z);
             pd[slot * 3] = dx; pd[slot * 3 + 1] = dy; pd[slot * 3 + 2] = dz;
             pl[slot * 2] = c.dt; pl[slot * 2 + 1] = t_new - (before ? prev_end : last_t);
         }
@@ -766,14 +770,17 @@ __global__ void __launch_bounds__(256) k_march_walkers(uint32_t n_alive, uint32_
 }
 
 // ---------------------------------------------------------------- R10 (raymarching.cu:818-905)
+// COUNT: the wave also adds its number of surviving entries to block_counts[n / 1024] (zeroed by the caller) — the first pass of the ordered
+// compaction that follows in the native render step (k_compact_count otherwise)
+template <bool COUNT>
 __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
                                  int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
                                  const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                                 float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image) {
+                                 float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    if (index < 0) return;             // already marked dead: stays dead, nothing to accumulate
+    const int index = n < n_alive ? rays_alive[n] : -1;
+    bool survives = false;
+    if (index >= 0) {                  // beyond the list or already marked dead (stays dead, nothing to accumulate)
     const float *s = sigmas + (uint64_t)n * n_step, *c = rgbs + (uint64_t)n * n_step * 3, *dl = deltas + (uint64_t)n * n_step * 2;
     float t = rays_t[index];
     float weight_sum = weights_sum[index], d = depth[index];
@@ -791,9 +798,14 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
         if (T < T_thresh) break;
         s++; c += 3; dl += 2; step++;
     }
-    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    if (step < n_step) rays_alive[n] = -1; else { rays_t[index] = t; survives = true; }
     weights_sum[index] = weight_sum; depth[index] = d;
     image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+    if (COUNT) {
+        const uint64_t alive = __ballot(survives);
+        if ((threadIdx.x & 63u) == 0u && alive != 0ull) atomicAdd(&block_counts[n >> 10], (int)__builtin_popcountll(alive));
+    }
 }
 
 // ---------------------------------------------------------------- ordered compaction of rays_alive >= 0
@@ -1013,7 +1025,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                             const float *noises, int32_t *scratch, void *stream) {
+                             const float *noises, int32_t *scratch, int normalised, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     (void)nears;
     if (n_alive == 0) return FOC_OK;
@@ -1022,7 +1034,8 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
     FOC_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 512 && max_steps >= 1 && n_step >= 1 && n_step <= 16, FOC_E_INVALID,
                 "march_rays_two_phase: unsupported C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_two_phase: C*H^3 exceeds 2^24");
-    const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    if (normalised) p.norm_inv = 1.0f / (2.0f * bound);    // `xyzs` receives (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
     hipStream_t st = (hipStream_t)stream;
     int32_t *wl_count = scratch, *worklist = scratch + 4;
     hipLaunchKernelGGL(k_march_rays_first, dim3(foc_div_up(n_alive, 256)), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars,
@@ -1045,9 +1058,29 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, FOC_E_INVALID,
                 "composite_rays: null pointer");
-    hipLaunchKernelGGL(k_composite_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    hipLaunchKernelGGL(k_composite_rays<false>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, (int32_t *)nullptr);
     FOC_CHECK_LAUNCH("composite_rays");
+    return FOC_OK;
+}
+
+/* foc_composite_rays + the ordered compaction of the survivors into `out` (count in n_out), the compaction's counting pass done by the
+ * composite kernel itself: block_counts = int32[n_alive / 1024 + 2], ZEROED by the caller on this stream. (csrc/occrender.hip) */
+int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                          const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    FOC_REQUIRE(n_alive > 0 && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && out && n_out && block_counts, FOC_E_INVALID,
+                "composite_compact: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_composite_rays<true>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
+                       weights_sum, depth, image, block_counts);
+    FOC_CHECK_LAUNCH("composite_compact(composite)");
+    const uint32_t nb = foc_div_up(n_alive, 1024);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, n_out);
+    FOC_CHECK_LAUNCH("composite_compact(scan)");
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(1024), 0, st, rays_alive, n_alive, block_counts, out);
+    FOC_CHECK_LAUNCH("composite_compact(scatter)");
     return FOC_OK;
 }
 

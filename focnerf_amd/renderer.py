@@ -294,7 +294,6 @@ class NeRFRenderer(nn.Module):
         L = enc.offsets.shape[0] - 1
         lag = max(1, int(os.environ.get("FOC_RENDER_COUNT_LAG", "2")))
         samples = torch.empty(n * 8, dtype=torch.float32, device=dev)
-        xn = torch.empty(n * 3, dtype=torch.float32, device=dev)
         planes = torch.empty(L * n * 2, dtype=torch.float16, device=dev)
         sigma, rgb = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n * 3, dtype=torch.float32, device=dev)
         lists = [alive, torch.empty_like(alive)]
@@ -313,7 +312,7 @@ class NeRFRenderer(nn.Module):
                 src, dst = lists[it & 1], lists[(it & 1) ^ 1]
                 check(lib.foc_occ_render_step(live, burst, ptr(src), ptr(dst), ptr(count), ptr(t_now), ptr(o), ptr(d), float(self.bound), float(dt_gamma),
                                               int(max_steps), self.cascade, self.grid_size, ptr(self.density_bitfield), ptr(near), ptr(far),
-                                              ptr(jitter if marched == 0 else still), ptr(samples), ptr(xn), ptr(planes), ptr(sigma), ptr(rgb), ptr(emb),
+                                              ptr(jitter if marched == 0 else still), ptr(samples), ptr(planes), ptr(sigma), ptr(rgb), ptr(emb),
                                               ptr(enc.offsets), None, L, S, enc.base_resolution, ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, sn.activation,
                                               None, float(T_thresh), ptr(opacity), ptr(depth), ptr(image), ptr(scratch), st), "occ_render_step")
                 slot = it % (lag + 1)

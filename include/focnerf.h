@@ -131,14 +131,14 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  * foc_nerf_field_inference (per-sample directions) -> composite_rays (in place; finished rays marked -1 in rays_alive) -> ordered
  * compaction into rays_alive_out, whose entries behind the count are -1. M = n_alive * n_step.
  * n_alive may be an UPPER BOUND of the live count: entries of rays_alive that are -1 are skipped by every stage, so a caller may read
- * `count` (device int) late. samples: fp32 [M * 8] = xyzs [M,3] | dirs [M,3] | deltas [M,2]; xn fp32 [M,3]; planes fp16 [L,M,2];
+ * `count` (device int) late. samples: fp32 [M * 8] = positions [M,3] (in the encoder's [0,1] coordinates) | dirs [M,3] | deltas [M,2]; planes fp16 [L,M,2];
  * sigma [M], rgb [M,3] fp32; scratch: foc_occ_render_step_scratch_bytes(n_alive of the FIRST iteration) bytes. Hash grid D = 3, C = 2,
  * fp16 table (embeddings), linear interpolation; networks as foc_nerf_field_inference (hidden 64; obj_feat may be NULL). density_scale 1. */
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays);
 int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, int32_t *rays_alive_out, int32_t *count,
                         float *rays_t, const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
                         uint32_t C, uint32_t H, const uint8_t *grid, const float *nears, const float *fars, const float *noises,
-                        float *samples, float *xn, void *planes, float *sigma, float *rgb,
+                        float *samples, void *planes, float *sigma, float *rgb,
                         const void *embeddings, const int32_t *offsets, const int32_t *offsets_host, uint32_t L, float S, uint32_t base_res,
                         const void *sigma_weights, uint32_t sigma_layers, const void *color_weights, uint32_t color_layers, uint32_t activation,
                         const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, void *stream);
