@@ -29,14 +29,6 @@ __global__ void __launch_bounds__(256) k_occ_prepare(uint32_t *__restrict__ samp
 
 extern "C" {
 
-// raymarching.hip (internal: not part of include/focnerf.h)
-int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
-                             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
-                             const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                             const float *noises, int32_t *scratch, int normalised, void *stream);
-int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
-                          const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
-                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream);
 
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays) {
     // int32[n + 4] worklist | compaction block counts int32[n / 1024 + 2], both 256-byte aligned

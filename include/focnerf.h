@@ -134,6 +134,20 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  * `count` (device int) late. samples: fp32 [M * 8] = positions [M,3] (in the encoder's [0,1] coordinates) | dirs [M,3] | deltas [M,2]; planes fp16 [L,M,2];
  * sigma [M], rgb [M,3] fp32; scratch: foc_occ_render_step_scratch_bytes(n_alive of the FIRST iteration) bytes. Hash grid D = 3, C = 2,
  * fp16 table (embeddings), linear interpolation; networks as foc_nerf_field_inference (hidden 64; obj_feat may be NULL). density_scale 1. */
+/* The two building blocks of the step that have no reference counterpart, usable on their own:
+ * foc_march_rays_two_phase — foc_march_rays with the same arguments and results (bit for bit), as two launches: first visits per lane, then
+ *   the rays that met an empty cell ("walkers") compacted on a worklist and marched 16 lanes per ray (one ray per lane when the list is
+ *   long). scratch: int32[n_alive + 4] whose first word the caller has zeroed on this stream. normalised != 0: xyzs receives
+ *   (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x.
+ * foc_composite_compact — foc_composite_rays followed by the ordered compaction of the surviving list entries into `out` (count in n_out),
+ *   the compaction's counting pass done by the composite kernel. block_counts: int32[n_alive / 1024 + 2], zeroed by the caller. */
+int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
+                             const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                             const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                             const float *noises, int32_t *scratch, int normalised, void *stream);
+int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
+                          const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
+                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream);
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays);
 int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, int32_t *rays_alive_out, int32_t *count,
                         float *rays_t, const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,

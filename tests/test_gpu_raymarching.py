@@ -479,3 +479,51 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
         for k in (3, 4, 5, 6):
             assert torch.equal(out[name][k], out["dense"][k]), (name, k)
     assert out["dense"][3].max() > 0
+
+
+@pytest.mark.parametrize("n_step", [1, 4, 8])
+@pytest.mark.parametrize("row_max", ["1000000000", "0"])          # walkers 16 lanes per ray / one ray per lane
+def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, monkeypatch):
+    """foc_march_rays_two_phase (first visits per lane, walkers compacted and marched again) == foc_march_rays bit for bit, its normalised
+    form == (x + bound) * (1 / (2 bound)); foc_composite_compact == composite_rays + compact_alive (list, count, every accumulator)."""
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
+    N = 3000
+    s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
+    C, H = s["cascade"], 128
+    o, d, bits = s["rays_o"].cuda(), s["rays_d"].cuda(), s["bits"].cuda()
+    nears, fars = torch.from_numpy(n_ref).cuda(), torch.from_numpy(f_ref).cuda()
+    g = torch.Generator().manual_seed(5)
+    lst = torch.where(torch.rand(N, generator=g) > 0.2, torch.arange(N), torch.full((N,), -1)).to(torch.int32).cuda()      # with dead entries
+    t_now = nears.clone()
+    noises = torch.zeros(N, device="cuda")
+    M = N * n_step
+    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "0")             # reference call: the plain serial kernel
+    x0, d0, l0 = rm.march_rays(N, n_step, lst, t_now, o, d, s["bound"], bits, C, H, nears, fars, -1, False, 1 / 128, 1024)
+    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
+    st = stream_of(o)
+    for normalised in (0, 1):
+        x1, d1, l1 = torch.zeros(M, 3, device="cuda"), torch.zeros(M, 3, device="cuda"), torch.zeros(M, 2, device="cuda")
+        scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
+        check(lib.foc_march_rays_two_phase(N, n_step, ptr(lst), ptr(t_now), ptr(o), ptr(d), float(s["bound"]), 1 / 128, 1024, C, H, ptr(bits), ptr(nears), ptr(fars),
+                                           ptr(x1), ptr(d1), ptr(l1), ptr(noises), ptr(scratch), normalised, st), "two_phase")
+        want = x0 if not normalised else torch.where(l0[:, :1] != 0, (x0 + s["bound"]) * (1.0 / (2.0 * s["bound"])), torch.zeros_like(x0))
+        assert torch.equal(x1, want) and torch.equal(d1, d0) and torch.equal(l1, l0)
+        assert int(scratch[0]) > 0, "some rays must have been walkers"
+    # composite + compaction in one call vs the two calls
+    sig, rgb = _analytic_field(to_np(x0), to_np(d0))
+    sig, rgb = torch.from_numpy(sig).cuda(), torch.from_numpy(rgb).cuda()
+    a_list, a_t = lst.clone(), t_now.clone()
+    a_ws, a_dp, a_im = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda")
+    rm.composite_rays(N, n_step, a_list, a_t, sig, rgb, l0, a_ws, a_dp, a_im, 1e-4)
+    kept, count = rm.compact_alive(a_list, pad=True)
+    b_list, b_t = lst.clone(), t_now.clone()
+    b_ws, b_dp, b_im = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda")
+    out = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    blocks = torch.zeros(N // 1024 + 2, dtype=torch.int32, device="cuda")
+    check(lib.foc_composite_compact(N, n_step, 1e-4, ptr(b_list), ptr(b_t), ptr(sig), ptr(rgb), ptr(l0), ptr(b_ws), ptr(b_dp), ptr(b_im), ptr(out), ptr(n_out),
+                                    ptr(blocks), st), "composite_compact")
+    assert int(n_out) == int(count) and torch.equal(out, kept) and torch.equal(b_list, a_list)
+    for a, b in ((a_t, b_t), (a_ws, b_ws), (a_dp, b_dp), (a_im, b_im)):
+        assert torch.equal(a, b)
