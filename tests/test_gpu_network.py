@@ -313,3 +313,30 @@ def test_half_cache_scope_is_the_only_cache():
         assert _half_of(p) is h1
     p.data.mul_(0.5)
     assert torch.equal(_half_of(p), p.detach().half())
+
+
+def test_native_inference_loop_edge_cases():
+    """foc_occ_render_step through run_cuda: jittered first samples (perturb), a handful of rays, rays that all miss the box, and a view
+    whose ray count is not a multiple of anything — against the Python loop with the reference's boolean-mask compaction."""
+    from focnerf_amd import synthetic
+    bound = 2
+    m = _model(bound, True, seed=4).eval()
+    o, d = synthetic.make_view_rays(40, 40, bound, 1, seed=6, device="cuda")
+    kw = dict(staged=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for n in (1, 7, 1599):
+            a = m.render(o[:, :n], d[:, :n], perturb=False, **kw)
+            b = m.render(o[:, :n], d[:, :n], perturb=False, device_compaction=True, **kw)
+            assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"]), n
+        # rays pointing away from the box: nothing to march, the background comes back
+        away = -d[:, :500]
+        far_o = o[:, :500] * 4.0
+        a = m.render(far_o, away, perturb=False, **kw)
+        b = m.render(far_o, away, perturb=False, device_compaction=True, **kw)
+        assert torch.equal(a["image"], b["image"]) and bool((b["image"] == 1.0).all())
+        # jitter: another draw of the same distribution per loop form — close to each other and to the unjittered image, not equal
+        torch.manual_seed(0)
+        p = m.render(o, d, perturb=True, device_compaction=True, **kw)
+        q = m.render(o, d, perturb=False, device_compaction=True, **kw)
+        assert torch.isfinite(p["image"]).all() and not torch.equal(p["image"], q["image"])
+        assert (p["image"] - q["image"]).abs().mean() < 2e-2
