@@ -264,22 +264,62 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
     // rows as 32-bit BYTE offsets from the level's base: the loads take the base from scalar registers (global_load ... v_off, s[base])
     // instead of a 64-bit address per lane and load (the launch wrapper admits this path for levels below 2^30 rows only)
     const char *tb = reinterpret_cast<const char *>(tw);
-    uint32_t r0[4], r1[4];                               // rows of the corners (x, y_j, z_j) and (x + 1, y_j, z_j), j = y bit | z bit << 1
+    // b0[j]: BYTE offset of the row of corner (x, y_j, z_j), j = y bit | z bit << 1; the row pair it belongs to starts at b0 & ~7.
+    uint32_t b0[4];
     uint2 wide[4];
     uint32_t nar[4] = {0u, 0u, 0u, 0u};
     bool pr[4];
-    if (hashed) {
+    if (hashmap_size <= (1u << 22)) {
+        // Tables of at most 2^22 rows (every NeRF grid: log2_hashmap_size 19): the index arithmetic runs on byte offsets below 2^24 with
+        // FULL-RATE 24-bit multiplies. Only the low bits of the hash survive the `% hashmap_size` (a power of two here), and they depend on
+        // the low bits of the factors alone: (x ^ y P1 ^ z P2) & m, times 4, == ((x << 2) ^ y (4 (P1 & m)) ^ z (4 (P2 & m))) & (m << 2). The
+        // generic form below spends two quarter-rate 32-bit multiplies, a shift and a mask per corner; this one a shift for x, two
+        // v_mul_u32_u24 and one xor + and per corner (~20 of the ~100 VALU slots per point and level). A dense level likewise: strides
+        // below 2^22, rows below the table size.
+        const uint32_t x4 = pg[0] << 2;
+        uint32_t yz4[4];
+        if (hashed) {
+            const uint32_t m = hashmap_size - 1u, m4 = m << 2;
+            const uint32_t p1 = (2654435761u & m) << 2, p2 = (805459861u & m) << 2;
+            const uint32_t t1 = __umul24(pg[1], p1), t2 = __umul24(pg[2], p2);
+            yz4[0] = t1 ^ t2; yz4[1] = (t1 + p1) ^ t2; yz4[2] = t1 ^ (t2 + p2); yz4[3] = (t1 + p1) ^ (t2 + p2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b0[j] = (x4 ^ yz4[j]) & m4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + (b0[j] & ~7u));
+            const bool even = (x4 & 4u) == 0u;           // x even: x + 1 == x ^ 1, every (x, x+1) corner pair is an aligned row pair
+            if (!even) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (((x4 + 4u) ^ yz4[j]) & m4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) pr[j] = even;
+        } else {
+            const uint32_t s1 = st1 << 2, s2 = st2 << 2;
+            const uint32_t t1 = __umul24(pg[1], s1), t2 = __umul24(pg[2], s2);
+            yz4[0] = t1 + t2; yz4[1] = (t1 + s1) + t2; yz4[2] = t1 + (t2 + s2); yz4[3] = (t1 + s1) + (t2 + s2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b0[j] = x4 + yz4[j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + (b0[j] & ~7u));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                pr[j] = (b0[j] & 4u) == 0u;
+                if (!pr[j]) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (b0[j] + 4u));
+            }
+        }
+    } else if (hashed) {
         const uint32_t mask = hashmap_size - 1u;
         const uint32_t t1 = pg[1] * 2654435761u, t2 = pg[2] * 805459861u;
         const uint32_t yz[4] = {t1 ^ t2, (t1 + 2654435761u) ^ t2, t1 ^ (t2 + 805459861u), (t1 + 2654435761u) ^ (t2 + 805459861u)};
 #pragma unroll
-        for (int j = 0; j < 4; j++) { r0[j] = (pg[0] ^ yz[j]) & mask; r1[j] = ((pg[0] + 1u) ^ yz[j]) & mask; }
+        for (int j = 0; j < 4; j++) b0[j] = ((pg[0] ^ yz[j]) & mask) << 2;
 #pragma unroll
-        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + ((r0[j] & ~1u) << 2));
-        const bool even = (pg[0] & 1u) == 0u;            // x even: x + 1 == x ^ 1, every (x, x+1) corner pair is an aligned row pair
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + (b0[j] & ~7u));
+        const bool even = (pg[0] & 1u) == 0u;
         if (!even) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (r1[j] << 2));
+            for (int j = 0; j < 4; j++) nar[j] = *reinterpret_cast<const uint32_t *>(tb + ((((pg[0] + 1u) ^ yz[j]) & mask) << 2));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) pr[j] = even;
@@ -287,20 +327,20 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
         const uint32_t t1 = pg[1] * st1, t2 = pg[2] * st2;
         const uint32_t yz[4] = {t1 + t2, (t1 + st1) + t2, t1 + (t2 + st2), (t1 + st1) + (t2 + st2)};
 #pragma unroll
-        for (int j = 0; j < 4; j++) { r0[j] = pg[0] + yz[j]; r1[j] = r0[j] + 1u; }
+        for (int j = 0; j < 4; j++) b0[j] = (pg[0] + yz[j]) << 2;
 #pragma unroll
-        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + ((r0[j] & ~1u) << 2));
+        for (int j = 0; j < 4; j++) wide[j] = *reinterpret_cast<const uint2 *>(tb + (b0[j] & ~7u));
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            pr[j] = (r0[j] & 1u) == 0u;
-            if (!pr[j]) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (r1[j] << 2));
+            pr[j] = (b0[j] & 4u) == 0u;
+            if (!pr[j]) nar[j] = *reinterpret_cast<const uint32_t *>(tb + (b0[j] + 4u));
         }
     }
     const float wx[2] = {1 - pos[0], pos[0]}, wy[2] = {1 - pos[1], pos[1]}, wz[2] = {1 - pos[2], pos[2]};
     float res0 = 0.0f, res1 = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const bool odd = (r0[j] & 1u) != 0u;
+        const bool odd = (b0[j] & 4u) != 0u;
         const uint32_t v0 = odd ? wide[j].y : wide[j].x;
         const uint32_t v1 = pr[j] ? (odd ? wide[j].x : wide[j].y) : nar[j];
         const __half2 h0 = *reinterpret_cast<const __half2 *>(&v0), h1 = *reinterpret_cast<const __half2 *>(&v1);
