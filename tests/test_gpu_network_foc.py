@@ -374,3 +374,41 @@ def test_object_feature_encoder_vector_path_equals_the_linear_layers():
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), name
     # a batch of vectors takes the linear layers
     assert m(torch.randn(3, 144, device="cuda")).shape == (3, 16)
+
+
+def test_foc_fused_step_at_baseline_size_rows_are_those_of_the_materialised_path(monkeypatch):
+    """BASELINE configs[1] size — 4096 rays x 512 samples — on the FOC network: the fused tail's image rows for a random subset of the rays
+    must be what the materialised path (cin [M,48] in memory, general kernels) gives for those rays alone (rays are independent of each
+    other: a size-independent property), and the gradient of the object-feature encoder must be the batch-linear sum of two half batches."""
+    from focnerf_amd.fixedstep import render_fixed_steps
+    m = _foc(7).train()
+    from focnerf_amd import synthetic
+    gen = torch.Generator().manual_seed(2)
+    poses = synthetic.rand_poses(1, "cuda", radius=2.0, generator=gen)
+    ro, rd = synthetic.get_rays(poses, synthetic.intrinsics(800, 800), 800, 800, torch.randint(0, 640000, (1, 4096), generator=gen).cuda())
+    feat = torch.randn(144, generator=gen).cuda()
+    T = 512
+    with torch.autocast("cuda", dtype=torch.float16):
+        full = render_fixed_steps(m, ro, rd, (None, None, feat), num_steps=T, bg_color=1.0, perturb=False)
+    pick = torch.randperm(4096, generator=gen)[:48].cuda()
+    monkeypatch.setenv("FOC_FUSED_TAIL", "0")
+    with torch.autocast("cuda", dtype=torch.float16):
+        part = render_fixed_steps(m, ro[:, pick], rd[:, pick], (None, None, feat), num_steps=T, bg_color=1.0, perturb=False)
+    monkeypatch.delenv("FOC_FUSED_TAIL")
+    assert torch.allclose(full["image"][0, pick], part["image"][0], atol=1e-4), (full["image"][0, pick] - part["image"][0]).abs().max()
+    assert torch.equal(full["depth"][0, pick].nan_to_num(), part["depth"][0].nan_to_num())
+    # batch linearity of the parameter gradients that the colsum trick produces (object columns of dW0, the encoder's weights)
+    target = torch.rand(1, 4096, 3, device="cuda")
+
+    def grads(sel):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            res = render_fixed_steps(m, ro[:, sel], rd[:, sel], (None, None, feat), num_steps=T, bg_color=1.0, perturb=False)
+            loss = ((res["image"] - target[:, sel]) ** 2).sum()
+        (loss * 64.0).backward()
+        w0 = m.color_net.weights.grad[:64 * 48].view(64, 48)[:, 31:47].float().clone()
+        return w0, m.yolo_feat_encoder.l1.weight.grad.clone()
+    a, b, c = grads(slice(0, 2048)), grads(slice(2048, 4096)), grads(slice(0, 4096))
+    for x, y, z, name in ((a[0], b[0], c[0], "dW0[:, 31:47]"), (a[1], b[1], c[1], "object-feature encoder")):
+        s = z.abs().max().item()
+        assert s > 0 and (x + y - z).abs().max().item() <= 1e-2 * s, name
