@@ -17,6 +17,7 @@
 //
 // The live count stays on the device (`count`, one int); the caller reads it late (focnerf_amd/renderer.py) and passes an upper bound.
 #include "common.h"
+#include <cstdlib>
 
 __global__ void __launch_bounds__(256) k_occ_prepare(uint32_t *__restrict__ samples, uint64_t n_sample_words, int32_t *__restrict__ list_out, uint32_t n_list,
                                                      int32_t *__restrict__ wl_count, int32_t *__restrict__ block_counts, uint32_t n_blocks) {
@@ -57,17 +58,29 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     float *xyzs = samples, *dirs = samples + 3 * M, *deltas = samples + 6 * M;
     int32_t *worklist = reinterpret_cast<int32_t *>(scratch);
     int32_t *compact_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scratch) + ((((uint64_t)n_alive + 4) * 4 + 255) & ~(uint64_t)255));
-    hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d(M * 8, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), M * 8, rays_alive_out, n_alive, worklist,
-                       compact_scratch, n_alive / 1024 + 2);
+    // the sample slots are zeroed here (the reference's torch.zeros) unless the march kernel of this burst length writes every one of them itself
+    const uint64_t to_zero = foc_march_rays_two_phase_fills(n_step) ? 0 : M * 8;
+    hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d((to_zero > n_alive ? to_zero : n_alive) + 1, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), to_zero,
+                       rays_alive_out, n_alive, worklist, compact_scratch, n_alive / 1024 + 2);
     FOC_CHECK_LAUNCH("occ_render_step(prepare)");
     int rc = foc_march_rays_two_phase(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas,
                                       noises, worklist, 1, stream);
     if (rc) return rc;
-    rc = foc_grid_encode_forward(xyzs, embeddings, offsets, planes, (uint32_t)M, 3, 2, L, S, base_res, nullptr, 0, 0, 0, FOC_F16, offsets_host, stream);
-    if (rc) return rc;
-    rc = foc_nerf_field_inference(planes, 1, dirs, 1, 0, (uint32_t)M, sigma_weights, sigma_layers, color_weights, color_layers, 64, activation, (uint32_t)M, sigma, rgb,
-                                  obj_feat, stream);
-    if (rc) return rc;
+    // the field in pieces of at most `piece` samples: the [L, piece, 2] planes between the encoder and the whole-field kernel (64 B per sample)
+    // are bounded whatever the burst length (FOC_OCC_FIELD_PIECE, samples; default 2^23. Measured on the 800 x 800 view, 5.1 M samples per iteration:
+    // one piece 18.5 ms per view, pieces of 2^21 — planes that fit the 256 MiB Infinity Cache — 19.3, of 2^20 20.0: fewer launches win)
+    const char *piece_env = getenv("FOC_OCC_FIELD_PIECE");
+    uint64_t piece = piece_env ? (uint64_t)atoll(piece_env) : (1ull << 23);
+    if (piece < 1024) piece = 1024;
+    piece &= ~(uint64_t)63;
+    for (uint64_t m0 = 0; m0 < M; m0 += piece) {
+        const uint32_t mc = (uint32_t)(M - m0 < piece ? M - m0 : piece);
+        rc = foc_grid_encode_forward(xyzs + 3 * m0, embeddings, offsets, planes, mc, 3, 2, L, S, base_res, nullptr, 0, 0, 0, FOC_F16, offsets_host, stream);
+        if (rc) return rc;
+        rc = foc_nerf_field_inference(planes, 1, dirs + 3 * m0, 1, 0, mc, sigma_weights, sigma_layers, color_weights, color_layers, 64, activation, mc, sigma + m0,
+                                      rgb + 3 * m0, obj_feat, stream);
+        if (rc) return rc;
+    }
     // composite marks finished rays in the INPUT list; the compaction then writes the survivors to the output list
     return foc_composite_compact(n_alive, n_step, T_thresh, const_cast<int32_t *>(rays_alive), rays_t, sigma, rgb, deltas, weights_sum, depth, image, rays_alive_out,
                                  count, compact_scratch, stream);

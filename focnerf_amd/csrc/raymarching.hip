@@ -622,10 +622,13 @@ __global__ void __launch_bounds__(64) k_march_rays_spec(uint32_t n_alive, uint32
 // (one DPP row, 4 rays per wave) generates what a burst of 8 typically consumes in one or two rounds.
 #define RM_ROW_MAX_ROUNDS (1u << 14)                       // x 16 lattice points: far beyond any real ray; makes the loop finite whatever the inputs
 // all 64 lanes of a wave call this together; `have`, `n`, `index` are uniform over each 16-lane group
-template <bool MED3>
-__device__ __forceinline__ void rm_row_walk(bool have, uint32_t n, int index, uint32_t n_step, const float *__restrict__ rays_t, const float *__restrict__ rays_o,
+// STAGE: the samples of a ray are collected in LDS (`stage`: 5 n_step floats per 16-lane group) and leave in rm_row_flush — whole runs of
+// consecutive floats per group, zeros in the slots the ray did not fill — instead of as single dwords at a 32 n_step-byte lane stride.
+template <bool MED3, bool STAGE = false>
+__device__ __forceinline__ uint32_t rm_row_walk(bool have, uint32_t n, int index, uint32_t n_step, const float *__restrict__ rays_t, const float *__restrict__ rays_o,
                                             const float *__restrict__ rays_d, const uint8_t *__restrict__ grid, const RmParams &p, const float *__restrict__ fars,
-                                            float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises) {
+                                            float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas, const float *__restrict__ noises,
+                                            float *stage = nullptr) {
     constexpr uint32_t G = 16u;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (G - 1u), gbase = lane & ~(G - 1u), gshift = gbase;
     const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
@@ -692,9 +695,14 @@ __device__ __forceinline__ void rm_row_walk(bool have, uint32_t n, int index, ui
         const float prev_end = __shfl(t_new, prev_lane, 64);
         if ((emitted >> sub) & 1u) {
             const uint32_t slot = step + (uint32_t)__builtin_popcount(before);
-            px[slot * 3] = rm_out(p, c.x); px[slot * 3 + 1] = rm_out(p, c.y); px[slot * 3 + 2] = rm_out(p, c.z);
-            pd[slot * 3] = dx; pd[slot * 3 + 1] = dy; pd[slot * 3 + 2] = dz;
-            pl[slot * 2] = c.dt; pl[slot * 2 + 1] = t_new - (before ? prev_end : last_t);
+            if (STAGE) {
+                stage[slot * 3] = rm_out(p, c.x); stage[slot * 3 + 1] = rm_out(p, c.y); stage[slot * 3 + 2] = rm_out(p, c.z);
+                stage[3 * n_step + slot * 2] = c.dt; stage[3 * n_step + slot * 2 + 1] = t_new - (before ? prev_end : last_t);
+            } else {
+                px[slot * 3] = rm_out(p, c.x); px[slot * 3 + 1] = rm_out(p, c.y); px[slot * 3 + 2] = rm_out(p, c.z);
+                pd[slot * 3] = dx; pd[slot * 3 + 1] = dy; pd[slot * 3 + 2] = dz;
+                pl[slot * 2] = c.dt; pl[slot * 2 + 1] = t_new - (before ? prev_end : last_t);
+            }
         }
         const int top_lane = emitted ? (int)(gbase + 31u - (uint32_t)__builtin_clz(emitted)) : (int)lane;
         const float top_end = __shfl(t_new, top_lane, 64);
@@ -702,6 +710,22 @@ __device__ __forceinline__ void rm_row_walk(bool have, uint32_t n, int index, ui
         step += (uint32_t)__builtin_popcount(emitted);
         t_cur = t_next;
     }
+    return step;
+}
+
+// the staged samples of list entry n (`filled` of its n_step slots) -> memory; every lane of the 16-lane group calls this after the block's barrier
+__device__ __forceinline__ void rm_row_flush(uint32_t n, int index, uint32_t n_step, uint32_t filled, const float *__restrict__ rays_d, const float *stage,
+                                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+    const uint32_t sub = threadIdx.x & 15u;
+    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
+    float *px = xyzs + (uint64_t)n * n_step * 3, *pd = dirs + (uint64_t)n * n_step * 3, *pl = deltas + (uint64_t)n * n_step * 2;
+    for (uint32_t i = sub; i < n_step * 3u; i += 16u) {
+        const uint32_t slot = i / 3u, c = i - slot * 3u;
+        const bool on = slot < filled;
+        px[i] = on ? stage[i] : 0.0f;
+        pd[i] = on ? (c == 0u ? dx : c == 1u ? dy : dz) : 0.0f;
+    }
+    for (uint32_t i = sub; i < n_step * 2u; i += 16u) pl[i] = (i >> 1) < filled ? stage[3 * n_step + i] : 0.0f;
 }
 
 template <bool MED3>
@@ -710,10 +734,15 @@ __global__ void __launch_bounds__(256) k_march_rays_row(uint32_t n_alive, uint32
                              const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
                              const float *__restrict__ noises) {
+    __shared__ float stage[16][5 * 16];                     // per 16-lane group: positions [n_step, 3] | deltas [n_step, 2], n_step <= 16
     const uint32_t n = (blockIdx.x * 256u + threadIdx.x) / 16u;
     const int listed = n < n_alive ? rays_alive[n] : -1;
     const bool have = listed >= 0;     // beyond the list, or an entry marked dead (-1): nothing to march
-    rm_row_walk<MED3>(have, n, have ? listed : 0, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+    float *mine = stage[threadIdx.x >> 4];
+    const uint32_t filled = rm_row_walk<MED3, true>(have, n, have ? listed : 0, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises, mine);
+    __syncthreads();
+    // every entry of the list leaves with all of its slots written (a dead one: zeros = "terminated"), so the caller need not have zeroed them
+    if (n < n_alive) rm_row_flush(n, have ? listed : 0, n_step, have ? filled : 0u, rays_d, mine, xyzs, dirs, deltas);
 }
 
 // ---------------------------------------------------------------- R9 in two phases (the native render step, csrc/occrender.hip)
@@ -806,6 +835,75 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
         const uint64_t alive = __ballot(survives);
         if ((threadIdx.x & 63u) == 0u && alive != 0ull) atomicAdd(&block_counts[n >> 10], (int)__builtin_popcountll(alive));
     }
+}
+
+// The same with a compile-time burst length that is a multiple of 4: the lane first loads ALL of its ray's sigmas / colours / deltas with
+// 16-byte loads (NS, 3 NS and 2 NS consecutive floats: whole cache lines per lane, every load in flight at once) and then runs the serial
+// accumulation on registers — with the pointer-chasing loop above a burst of 8 is 8 dependent rounds of 4-byte loads at a 32-byte lane stride
+// (86 us per 5.1 M samples, 1.4 TB/s). Same operations in the same order: same bits.
+template <int NS, bool COUNT>
+__global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, float T_thresh, int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
+                                     const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
+                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts) {
+    static_assert(NS % 4 == 0, "whole float4 loads");
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int index = n < n_alive ? rays_alive[n] : -1;
+    bool survives = false;
+    if (index >= 0) {
+        float sg[NS], cl[3 * NS], dl[2 * NS];
+        const float4 *ps = reinterpret_cast<const float4 *>(sigmas + (uint64_t)n * NS);
+        const float4 *pc = reinterpret_cast<const float4 *>(rgbs + (uint64_t)n * NS * 3);
+        const float4 *pd = reinterpret_cast<const float4 *>(deltas + (uint64_t)n * NS * 2);
+#pragma unroll
+        for (int i = 0; i < NS / 4; i++) { const float4 v = ps[i]; sg[4 * i] = v.x; sg[4 * i + 1] = v.y; sg[4 * i + 2] = v.z; sg[4 * i + 3] = v.w; }
+#pragma unroll
+        for (int i = 0; i < 3 * NS / 4; i++) { const float4 v = pc[i]; cl[4 * i] = v.x; cl[4 * i + 1] = v.y; cl[4 * i + 2] = v.z; cl[4 * i + 3] = v.w; }
+#pragma unroll
+        for (int i = 0; i < 2 * NS / 4; i++) { const float4 v = pd[i]; dl[4 * i] = v.x; dl[4 * i + 1] = v.y; dl[4 * i + 2] = v.z; dl[4 * i + 3] = v.w; }
+        float t = rays_t[index];
+        float weight_sum = weights_sum[index], d = depth[index];
+        float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+        bool ended = false;
+#pragma unroll
+        for (int step = 0; step < NS; step++) {
+            if (!ended) {
+                if (dl[2 * step] == 0) ended = true;
+                else {
+                    const float alpha = 1.0f - __expf(-sg[step] * dl[2 * step]);
+                    const float T = 1 - weight_sum;
+                    const float weight = alpha * T;
+                    weight_sum += weight;
+                    t += dl[2 * step + 1];
+                    d = fmaf(weight, t, d);
+                    r = fmaf(weight, cl[3 * step], r); g = fmaf(weight, cl[3 * step + 1], g); b = fmaf(weight, cl[3 * step + 2], b);
+                    if (T < T_thresh) ended = true;
+                }
+            }
+        }
+        if (ended) rays_alive[n] = -1; else { rays_t[index] = t; survives = true; }
+        weights_sum[index] = weight_sum; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+    if (COUNT) {
+        const uint64_t alive = __ballot(survives);
+        if ((threadIdx.x & 63u) == 0u && alive != 0ull) atomicAdd(&block_counts[n >> 10], (int)__builtin_popcountll(alive));
+    }
+}
+
+template <bool COUNT>
+static void rm_launch_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas, const float *rgbs,
+                                const float *deltas, float *weights_sum, float *depth, float *image, int32_t *block_counts, hipStream_t st) {
+    const dim3 grid(foc_div_up(n_alive, 64)), block(64);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(sigmas) | reinterpret_cast<uintptr_t>(rgbs) | reinterpret_cast<uintptr_t>(deltas)) & 15u) == 0;
+    if (aligned && n_step == 4u)
+        hipLaunchKernelGGL((k_composite_rays_pre<4, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+    else if (aligned && n_step == 8u)
+        hipLaunchKernelGGL((k_composite_rays_pre<8, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+    else if (aligned && n_step == 16u)
+        hipLaunchKernelGGL((k_composite_rays_pre<16, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+    else
+        hipLaunchKernelGGL(k_composite_rays<COUNT>, grid, block, 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                           block_counts);
 }
 
 // ---------------------------------------------------------------- ordered compaction of rays_alive >= 0
@@ -1020,6 +1118,14 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
     return FOC_OK;
 }
 
+// which kernels foc_march_rays_two_phase takes for a burst of n_step samples: 0 = the two phases, 1 = 16 lanes per ray, 2 = one ray per lane
+static int rm_burst_form(uint32_t n_step) {
+    const char *form_env = getenv("FOC_OCC_MARCH_FORM");
+    return form_env ? (form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : 0) : (n_step <= 2u ? 0 : 1);
+}
+/* 1 when foc_march_rays_two_phase writes every slot of every list entry for this burst length (the caller need not zero them) */
+int foc_march_rays_two_phase_fills(uint32_t n_step) { return rm_burst_form(n_step) == 1 ? 1 : 0; }
+
 /* R9 in two phases (k_march_rays_first + k_march_walkers): `scratch` = int32[n_alive + 4], its first word the worklist length, which the
  * caller has zeroed on this stream. Same arguments and results as foc_march_rays. */
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
@@ -1037,6 +1143,22 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
     RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     if (normalised) p.norm_inv = 1.0f / (2.0f * bound);    // `xyzs` receives (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
     hipStream_t st = (hipStream_t)stream;
+    // A burst of several samples per ray meets an empty cell on most rays (every one of them would be marched twice): the two phases are
+    // for bursts of one or two samples. Longer bursts take the 16-lanes-per-ray form ("row") or one ray per lane ("lane");
+    // FOC_OCC_MARCH_FORM = two | row | lane overrides the choice (A/B runs, tests).
+    const int form = rm_burst_form(n_step);
+    if (form == 1) {
+        hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0, st,
+                           n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+        FOC_CHECK_LAUNCH("march_rays(row form)");
+        return FOC_OK;
+    }
+    if (form == 2) {
+        hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs,
+                           dirs, deltas, noises);
+        FOC_CHECK_LAUNCH("march_rays(lane form)");
+        return FOC_OK;
+    }
     int32_t *wl_count = scratch, *worklist = scratch + 4;
     hipLaunchKernelGGL(k_march_rays_first, dim3(foc_div_up(n_alive, 256)), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars,
                        xyzs, dirs, deltas, noises, worklist, wl_count);
@@ -1058,8 +1180,7 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, FOC_E_INVALID,
                 "composite_rays: null pointer");
-    hipLaunchKernelGGL(k_composite_rays<false>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, (int32_t *)nullptr);
+    rm_launch_composite<false>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, nullptr, (hipStream_t)stream);
     FOC_CHECK_LAUNCH("composite_rays");
     return FOC_OK;
 }
@@ -1073,8 +1194,7 @@ int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int
     FOC_REQUIRE(n_alive > 0 && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && out && n_out && block_counts, FOC_E_INVALID,
                 "composite_compact: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_composite_rays<true>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
-                       weights_sum, depth, image, block_counts);
+    rm_launch_composite<true>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, st);
     FOC_CHECK_LAUNCH("composite_compact(composite)");
     const uint32_t nb = foc_div_up(n_alive, 1024);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, n_out);

@@ -131,20 +131,26 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  * foc_nerf_field_inference (per-sample directions) -> composite_rays (in place; finished rays marked -1 in rays_alive) -> ordered
  * compaction into rays_alive_out, whose entries behind the count are -1. M = n_alive * n_step.
  * n_alive may be an UPPER BOUND of the live count: entries of rays_alive that are -1 are skipped by every stage, so a caller may read
- * `count` (device int) late. samples: fp32 [M * 8] = positions [M,3] (in the encoder's [0,1] coordinates) | dirs [M,3] | deltas [M,2]; planes fp16 [L,M,2];
+ * `count` (device int) late. samples: fp32 [M * 8] = positions [M,3] (in the encoder's [0,1] coordinates) | dirs [M,3] | deltas [M,2]; planes fp16
+ * [L, min(M, piece), 2]: the field is evaluated in pieces of FOC_OCC_FIELD_PIECE samples (default 2^23), whose planes stay in the Infinity Cache;
  * sigma [M], rgb [M,3] fp32; scratch: foc_occ_render_step_scratch_bytes(n_alive of the FIRST iteration) bytes. Hash grid D = 3, C = 2,
  * fp16 table (embeddings), linear interpolation; networks as foc_nerf_field_inference (hidden 64; obj_feat may be NULL). density_scale 1. */
 /* The two building blocks of the step that have no reference counterpart, usable on their own:
  * foc_march_rays_two_phase — foc_march_rays with the same arguments and results (bit for bit), as two launches: first visits per lane, then
  *   the rays that met an empty cell ("walkers") compacted on a worklist and marched 16 lanes per ray (one ray per lane when the list is
  *   long). scratch: int32[n_alive + 4] whose first word the caller has zeroed on this stream. normalised != 0: xyzs receives
- *   (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x.
+ *   (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x. Bursts of more than two samples (most rays meet an
+ *   empty cell inside them and would be marched twice) take one launch of the 16-lanes-per-ray kernel instead, which collects a ray's
+ *   samples in LDS and writes ALL n_step slots of every list entry (zeros where the ray ended early or the entry is -1):
+ *   foc_march_rays_two_phase_fills(n_step) != 0 says so, and the caller may then skip zeroing xyzs / dirs / deltas.
+ *   FOC_OCC_MARCH_FORM = two | row | lane overrides the choice (A/B runs, tests).
  * foc_composite_compact — foc_composite_rays followed by the ordered compaction of the surviving list entries into `out` (count in n_out),
  *   the compaction's counting pass done by the composite kernel. block_counts: int32[n_alive / 1024 + 2], zeroed by the caller. */
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                              const float *noises, int32_t *scratch, int normalised, void *stream);
+int foc_march_rays_two_phase_fills(uint32_t n_step);
 int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                           float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream);

@@ -481,13 +481,20 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
     assert out["dense"][3].max() > 0
 
 
-@pytest.mark.parametrize("n_step", [1, 4, 8])
-@pytest.mark.parametrize("row_max", ["1000000000", "0"])          # walkers 16 lanes per ray / one ray per lane
-def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, monkeypatch):
-    """foc_march_rays_two_phase (first visits per lane, walkers compacted and marched again) == foc_march_rays bit for bit, its normalised
-    form == (x + bound) * (1 / (2 bound)); foc_composite_compact == composite_rays + compact_alive (list, count, every accumulator)."""
+@pytest.mark.parametrize("n_step", [1, 4, 8, 16])
+@pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "")])
+def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, form, monkeypatch):
+    """foc_march_rays_two_phase == foc_march_rays bit for bit in each of its forms — the two phases (first visits per lane, walkers compacted
+    and marched again, 16 lanes per ray / one ray per lane), the 16-lanes-per-ray kernel that stages a ray's samples in LDS and writes every
+    slot itself (buffers handed over full of NaN), one ray per lane, and the form it picks by burst length; its normalised output ==
+    (x + bound) * (1 / (2 bound)); foc_composite_compact (register-resident bursts of 4, 8, 16) == composite_rays + compact_alive (list, count,
+    every accumulator)."""
     from focnerf_amd._lib import lib, ptr, stream_of, check
     monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
+    if form:
+        monkeypatch.setenv("FOC_OCC_MARCH_FORM", form)
+    else:
+        monkeypatch.delenv("FOC_OCC_MARCH_FORM", raising=False)
     N = 3000
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
     C, H = s["cascade"], 128
@@ -503,13 +510,16 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
     st = stream_of(o)
     for normalised in (0, 1):
-        x1, d1, l1 = torch.zeros(M, 3, device="cuda"), torch.zeros(M, 3, device="cuda"), torch.zeros(M, 2, device="cuda")
+        fills = bool(lib.foc_march_rays_two_phase_fills(n_step))
+        assert fills == (form == "row" or (form == "" and n_step > 2))
+        x1, d1, l1 = (torch.full((M, k), float("nan") if fills else 0.0, device="cuda") for k in (3, 3, 2))
         scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
         check(lib.foc_march_rays_two_phase(N, n_step, ptr(lst), ptr(t_now), ptr(o), ptr(d), float(s["bound"]), 1 / 128, 1024, C, H, ptr(bits), ptr(nears), ptr(fars),
                                            ptr(x1), ptr(d1), ptr(l1), ptr(noises), ptr(scratch), normalised, st), "two_phase")
         want = x0 if not normalised else torch.where(l0[:, :1] != 0, (x0 + s["bound"]) * (1.0 / (2.0 * s["bound"])), torch.zeros_like(x0))
         assert torch.equal(x1, want) and torch.equal(d1, d0) and torch.equal(l1, l0)
-        assert int(scratch[0]) > 0, "some rays must have been walkers"
+        if form == "two" or (form == "" and n_step <= 2):
+            assert int(scratch[0]) > 0, "some rays must have been walkers"
     # composite + compaction in one call vs the two calls
     sig, rgb = _analytic_field(to_np(x0), to_np(d0))
     sig, rgb = torch.from_numpy(sig).cuda(), torch.from_numpy(rgb).cuda()
