@@ -537,6 +537,64 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
     (void)rm_lane_walk<false>(n, index, n_step, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
 }
 
+// ---------------------------------------------------------------- R9, one ray per lane, the wave's samples staged in LDS
+// k_march_rays writes a ray's samples as single dwords at a 32 n_step-byte lane stride (a burst of 8: 64 stores per lane, each touching 64
+// cache lines) and relies on the caller for the zeros of the slots a ray does not fill. Here a lane collects its ray's burst in LDS
+// ([3 n_step] positions | [2 n_step] deltas | samples filled, direction) and the wave then writes the three arrays of its 64 list entries as
+// runs of consecutive floats, zeros included: every slot of every entry is written, whole cache lines at a time. Same loop, same bits.
+__global__ void __launch_bounds__(64) k_march_rays_staged(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
+                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
+                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                             const float *__restrict__ noises) {
+    extern __shared__ float rm_stage[];                    // [64][5 n_step + 4]
+    const uint32_t lane = threadIdx.x, n0 = blockIdx.x * 64u, n = n0 + lane;
+    const uint32_t stride = 5u * n_step + 4u;
+    float *mine = rm_stage + lane * stride;
+    const int index = n < n_alive ? rays_alive[n] : -1;
+    uint32_t step = 0;
+    float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+    if (index >= 0) {
+        const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
+        dx = rays_d[index * 3]; dy = rays_d[index * 3 + 1]; dz = rays_d[index * 3 + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        float t = rays_t[index];
+        const float far = fars[index];
+        t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+        float last_t = t;
+        float *px = mine, *pl = mine + 3u * n_step;
+        RmCell c;
+        while (t < far && step < n_step) {
+            if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
+                px[0] = rm_out(p, c.x); px[1] = rm_out(p, c.y); px[2] = rm_out(p, c.z);
+                t += c.dt;
+                pl[0] = c.dt; pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pl += 2; step++;
+            } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
+        }
+    }
+    float *tail = mine + 5u * n_step;
+    tail[0] = __builtin_bit_cast(float, step); tail[1] = dx; tail[2] = dy; tail[3] = dz;
+    __syncthreads();                                       // one wave per workgroup: orders the LDS traffic, costs nothing
+    const uint32_t cnt = min(64u, n_alive - n0);           // list entries of this wave (n0 < n_alive by the launch)
+    const uint32_t lx = 3u * n_step, ll = 2u * n_step;
+    const float inv_lx = 1.0f / (float)lx, inv_ll = 1.0f / (float)ll;
+    float *gx = xyzs + (uint64_t)n0 * lx, *gd = dirs + (uint64_t)n0 * lx, *gl = deltas + (uint64_t)n0 * ll;
+    for (uint32_t i = lane; i < cnt * lx; i += 64u) {
+        const uint32_t r = (uint32_t)(((float)i + 0.5f) * inv_lx), j = i - r * lx, slot = j / 3u, cc = j - slot * 3u;
+        const float *rec = rm_stage + r * stride;
+        const bool on = slot < __builtin_bit_cast(uint32_t, rec[5u * n_step]);
+        gx[i] = on ? rec[j] : 0.0f;
+        gd[i] = on ? rec[5u * n_step + 1u + cc] : 0.0f;
+    }
+    for (uint32_t i = lane; i < cnt * ll; i += 64u) {
+        const uint32_t r = (uint32_t)(((float)i + 0.5f) * inv_ll), j = i - r * ll;
+        const float *rec = rm_stage + r * stride;
+        gl[i] = (j >> 1) < __builtin_bit_cast(uint32_t, rec[5u * n_step]) ? rec[3u * n_step + j] : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------- R9, one ray per lane, K lattice points per round
 // With hundreds of thousands of rays alive an iteration asks every ray for ONE sample: a ray inside the object evaluates one cell and is
 // done, but every iteration also has rays that have just left the object and walk ~100 empty cells to the far side of the box — a chain
@@ -1118,13 +1176,20 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
     return FOC_OK;
 }
 
-// which kernels foc_march_rays_two_phase takes for a burst of n_step samples: 0 = the two phases, 1 = 16 lanes per ray, 2 = one ray per lane
-static int rm_burst_form(uint32_t n_step) {
+// which kernels foc_march_rays_two_phase takes for a burst of n_step samples of n_alive rays: 0 = the two phases, 1 = 16 lanes per ray (samples
+// staged in LDS), 2 = one ray per lane, 3 = one ray per lane with the wave's samples staged in LDS. Measured on the 800 x 800 occupancy view
+// (tools/time_occ_burst.py; 640 000 rays alive for most of it, bursts of 8): form 3 15.8 ms per view, form 1 17.4, form 2 18.2, form 0 18.8
+// — with ten waves per SIMD the lanes' lookup chains hide each other and what counts is instructions and how the samples reach memory;
+// 16 lanes per ray pay when few rays are left (FOC_MARCH_RAYS_ROW_MAX, as in foc_march_rays).
+static int rm_burst_form(uint32_t n_step, uint32_t n_alive) {
     const char *form_env = getenv("FOC_OCC_MARCH_FORM");
-    return form_env ? (form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : 0) : (n_step <= 2u ? 0 : 1);
+    if (form_env && form_env[0]) return form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : form_env[0] == 's' ? 3 : 0;
+    if (n_step <= 2u) return 0;
+    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");
+    return (long)n_alive <= (row_env ? atol(row_env) : 131072) ? 1 : 3;
 }
 /* 1 when foc_march_rays_two_phase writes every slot of every list entry for this burst length (the caller need not zero them) */
-int foc_march_rays_two_phase_fills(uint32_t n_step) { return rm_burst_form(n_step) == 1 ? 1 : 0; }
+int foc_march_rays_two_phase_fills(uint32_t n_step) { const int f = rm_burst_form(n_step, 1u << 30); return (f == 1 || f == 3) ? 1 : 0; }
 
 /* R9 in two phases (k_march_rays_first + k_march_walkers): `scratch` = int32[n_alive + 4], its first word the worklist length, which the
  * caller has zeroed on this stream. Same arguments and results as foc_march_rays. */
@@ -1144,13 +1209,19 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
     if (normalised) p.norm_inv = 1.0f / (2.0f * bound);    // `xyzs` receives (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
     hipStream_t st = (hipStream_t)stream;
     // A burst of several samples per ray meets an empty cell on most rays (every one of them would be marched twice): the two phases are
-    // for bursts of one or two samples. Longer bursts take the 16-lanes-per-ray form ("row") or one ray per lane ("lane");
-    // FOC_OCC_MARCH_FORM = two | row | lane overrides the choice (A/B runs, tests).
-    const int form = rm_burst_form(n_step);
+    // for bursts of one or two samples. Longer bursts take one launch — one ray per lane with the wave's samples staged in LDS ("staged"),
+    // 16 lanes per ray when few rays are left ("row"); FOC_OCC_MARCH_FORM = two | row | lane | staged overrides the choice (A/B runs, tests).
+    const int form = rm_burst_form(n_step, n_alive);
     if (form == 1) {
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0, st,
                            n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
         FOC_CHECK_LAUNCH("march_rays(row form)");
+        return FOC_OK;
+    }
+    if (form == 3) {
+        hipLaunchKernelGGL(k_march_rays_staged, dim3(foc_div_up(n_alive, 64)), dim3(64), 64u * (5u * n_step + 4u) * sizeof(float), st, n_alive, n_step, rays_alive, rays_t,
+                           rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+        FOC_CHECK_LAUNCH("march_rays(staged lane form)");
         return FOC_OK;
     }
     if (form == 2) {

@@ -140,10 +140,11 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  *   the rays that met an empty cell ("walkers") compacted on a worklist and marched 16 lanes per ray (one ray per lane when the list is
  *   long). scratch: int32[n_alive + 4] whose first word the caller has zeroed on this stream. normalised != 0: xyzs receives
  *   (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x. Bursts of more than two samples (most rays meet an
- *   empty cell inside them and would be marched twice) take one launch of the 16-lanes-per-ray kernel instead, which collects a ray's
- *   samples in LDS and writes ALL n_step slots of every list entry (zeros where the ray ended early or the entry is -1):
- *   foc_march_rays_two_phase_fills(n_step) != 0 says so, and the caller may then skip zeroing xyzs / dirs / deltas.
- *   FOC_OCC_MARCH_FORM = two | row | lane overrides the choice (A/B runs, tests).
+ *   empty cell inside them and would be marched twice) take ONE launch instead — one ray per lane (16 lanes per ray when at most
+ *   FOC_MARCH_RAYS_ROW_MAX rays are listed) — of a kernel that collects the samples in LDS and writes ALL n_step slots of every list entry
+ *   as runs of consecutive floats (zeros where the ray ended early or the entry is -1): foc_march_rays_two_phase_fills(n_step) != 0 says
+ *   so, and the caller may then skip zeroing xyzs / dirs / deltas. FOC_OCC_MARCH_FORM = two | row | lane | staged overrides the choice
+ *   (A/B runs, tests; "lane" = foc_march_rays' serial kernel, which needs the zeros).
  * foc_composite_compact — foc_composite_rays followed by the ordered compaction of the surviving list entries into `out` (count in n_out),
  *   the compaction's counting pass done by the composite kernel. block_counts: int32[n_alive / 1024 + 2], zeroed by the caller. */
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,

@@ -482,7 +482,7 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
 
 
 @pytest.mark.parametrize("n_step", [1, 4, 8, 16])
-@pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "")])
+@pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "staged"), ("0", ""), ("1000000000", "")])
 def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, form, monkeypatch):
     """foc_march_rays_two_phase == foc_march_rays bit for bit in each of its forms — the two phases (first visits per lane, walkers compacted
     and marched again, 16 lanes per ray / one ray per lane), the 16-lanes-per-ray kernel that stages a ray's samples in LDS and writes every
@@ -511,7 +511,7 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     st = stream_of(o)
     for normalised in (0, 1):
         fills = bool(lib.foc_march_rays_two_phase_fills(n_step))
-        assert fills == (form == "row" or (form == "" and n_step > 2))
+        assert fills == (form in ("row", "staged") or (form == "" and n_step > 2))
         x1, d1, l1 = (torch.full((M, k), float("nan") if fills else 0.0, device="cuda") for k in (3, 3, 2))
         scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
         check(lib.foc_march_rays_two_phase(N, n_step, ptr(lst), ptr(t_now), ptr(o), ptr(d), float(s["bound"]), 1 / 128, 1024, C, H, ptr(bits), ptr(nears), ptr(fars),

@@ -29,7 +29,8 @@ def run(env, reps=4):
 
 t_ref, ref = run({"FOC_RENDER_BURST": "1"})
 print(f"burst 1 (reference schedule): {t_ref * 1e3:.2f} ms/view", flush=True)
-for env in ({"FOC_RENDER_BURST": "8"}, {"FOC_RENDER_BURST": "8", "FOC_OCC_MARCH_FORM": "lane"}, {"FOC_RENDER_BURST": "8", "FOC_OCC_MARCH_FORM": "two"},
+for env in ({"FOC_RENDER_BURST": "8"}, {"FOC_RENDER_BURST": "8", "FOC_OCC_MARCH_FORM": "staged"}, {"FOC_RENDER_BURST": "16", "FOC_OCC_MARCH_FORM": "staged"},
+            {"FOC_RENDER_BURST": "4", "FOC_OCC_MARCH_FORM": "staged"}, {"FOC_RENDER_BURST": "8", "FOC_OCC_MARCH_FORM": "lane"}, {"FOC_RENDER_BURST": "8", "FOC_OCC_MARCH_FORM": "two"},
             {"FOC_RENDER_BURST": "4"}, {"FOC_RENDER_BURST": "16"}, {"FOC_RENDER_BURST": "16", "FOC_OCC_MARCH_FORM": "lane"},
             {"FOC_RENDER_BURST": "8", "FOC_OCC_FIELD_PIECE": str(1 << 20)}, {"FOC_RENDER_BURST": "8", "FOC_OCC_FIELD_PIECE": str(1 << 23)}):
     t, out = run(env)
