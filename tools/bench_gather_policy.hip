@@ -1,62 +1,75 @@
-// Does a cache-policy modifier change the divergent-gather rate on gfx950?  (companion of bench_gather.hip)
-// Every lane of a wave reads a different 128-byte line of an L2-resident table (2 MiB) or of one that only fits the Infinity Cache (48 MiB);
-// the load carries no modifier, sc0, sc1, nt, or combinations. Build: hipcc -O3 --offload-arch=gfx950 tools/bench_gather_policy.hip -o tools/bench_gather_policy
+// tools/bench_gather_policy.hip — rate of random 8-byte gathers from an L2-resident table (2 MiB: one fp16 level of the hash grid) under
+// the cache-policy bits of global_load (sc0 / sc1 / nt): does any of them lift the ~0.44 lane-loads per clock and CU the encoder's
+// fine levels run at?  hipcc --offload-arch=gfx950 -O3 -o tools/bench_gather_policy tools/bench_gather_policy.hip
 #include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+#include <cstdio>
+#include <cstdint>
+#include <vector>
 
-template <int POL> __device__ __forceinline__ uint32_t ld(const char *p) {
-    uint32_t v;
-    if (POL == 0) asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 1) asm volatile("global_load_dword %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 2) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 3) asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 4) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 5) asm volatile("global_load_dword %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
-    else if (POL == 6) asm volatile("global_load_dword %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
-    else asm volatile("global_load_dword %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+template <int POLICY>
+__device__ __forceinline__ uint2 ld8(const void *p) {
+    uint2 v;
+    if constexpr (POLICY == 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 1) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 2) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 3) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 5) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 6) asm volatile("global_load_dwordx2 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (POLICY == 7) asm volatile("global_load_dwordx2 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-template <int POL>
-__global__ void __launch_bounds__(256) k_gather(const uint4 *__restrict__ table, uint32_t mask16, uint32_t iters, uint32_t *__restrict__ out) {
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+
+template <int POLICY, int BYTES>
+__global__ void __launch_bounds__(256) k_gather(const char *__restrict__ table, uint32_t mask, uint32_t rounds, uint32_t *__restrict__ out) {
+    uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
     uint32_t acc = 0;
-    const uint32_t key = tid * 0x9e3779b9u;
-    for (uint32_t it = 0; it < iters; it += 8) {
-        uint32_t v[8];
+    for (uint32_t r = 0; r < rounds; r++) {
+        uint2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = ld<POL>(reinterpret_cast<const char *>(table + (mix(key + (it + u) * 0x85ebca6bu) & mask16)));
+        for (int j = 0; j < 8; j++) {
+            x = x * 1664525u + 1013904223u;
+            const uint32_t row = (x >> 8) & mask;
+            v[j] = ld8<POLICY>(table + (uint64_t)row * BYTES);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc += v[u];
+        for (int j = 0; j < 8; j++) acc += v[j].x ^ v[j].y;
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
-template <int POL> static void run(const uint4 *table, uint32_t mask16, uint32_t *out, const char *what, const char *pol) {
-    const uint32_t blocks = 256 * 32, iters = 256;
-    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_gather<POL>), dim3(blocks), dim3(256), 0, 0, table, mask16, iters, out);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(a));
-    for (int r = 0; r < 5; r++) hipLaunchKernelGGL((k_gather<POL>), dim3(blocks), dim3(256), 0, 0, table, mask16, iters, out);
-    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
-    float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
-    const double loads = 5.0 * blocks * 256.0 * iters;
-    printf("%-14s %-12s : %8.1f G lane-loads/s\n", what, pol, loads / ms / 1e6);
+
+template <int POLICY>
+static void run(const char *name, const char *table, uint32_t rows, uint32_t *out) {
+    const uint32_t blocks = 256 * 16, rounds = 64;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k_gather<POLICY, 8>), dim3(blocks), dim3(256), 0, 0, table, rows - 1, rounds, out);
+    hipEventRecord(a);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL((k_gather<POLICY, 8>), dim3(blocks), dim3(256), 0, 0, table, rows - 1, rounds, out);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double loads = 5.0 * blocks * 256.0 * rounds * 8;
+    printf("%-14s rows %8u (%6.1f MiB): %7.1f G lane-loads/s  = %.3f per clock and CU (2.4 GHz, 256 CUs)\n", name, rows, rows * 8.0 / 1048576, loads / ms * 1e-6,
+           loads / (ms * 1e-3) / (2.4e9 * 256));
 }
+
 int main() {
-    for (int mb : {2, 48}) {
-        const size_t bytes = (size_t)mb << 20;
-        uint4 *table; uint32_t *out;
-        CHECK(hipMalloc(&table, bytes)); CHECK(hipMalloc(&out, 4)); CHECK(hipMemset(table, 1, bytes));
-        const uint32_t mask16 = (uint32_t)(bytes / 16 - 1);
-        char what[64]; snprintf(what, sizeof(what), "table %d MiB", mb);
-        run<0>(table, mask16, out, what, "(none)"); run<1>(table, mask16, out, what, "sc0"); run<2>(table, mask16, out, what, "sc1"); run<3>(table, mask16, out, what, "nt");
-        run<4>(table, mask16, out, what, "sc0 sc1"); run<5>(table, mask16, out, what, "sc0 nt"); run<6>(table, mask16, out, what, "sc1 nt"); run<7>(table, mask16, out, what, "sc0 sc1 nt");
-        CHECK(hipFree(table)); CHECK(hipFree(out));
+    for (uint32_t rows : {1u << 18, 1u << 21, 1u << 24}) {       // 2 MiB (one level, L2-resident), 16 MiB (all levels), 128 MiB (Infinity Cache)
+        char *table; uint32_t *out;
+        hipMalloc(&table, (size_t)rows * 8); hipMalloc(&out, 64);
+        hipMemset(table, 1, (size_t)rows * 8);
+        run<0>("plain", table, rows, out);
+        run<1>("nt", table, rows, out);
+        run<2>("sc0", table, rows, out);
+        run<3>("sc1", table, rows, out);
+        run<4>("sc0 sc1", table, rows, out);
+        run<5>("sc0 sc1 nt", table, rows, out);
+        run<6>("sc0 nt", table, rows, out);
+        run<7>("sc1 nt", table, rows, out);
+        hipFree(table); hipFree(out);
     }
     return 0;
 }
