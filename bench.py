@@ -850,7 +850,8 @@ def main():
                 barrier()
             rel2 = max_over_ranks(time.perf_counter() - t0)
             result["render_occupancy"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW * args.render_views / rel2, "unit": "rays/s",
-                                          "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2"}
+                                          "s_per_view": rel2 / args.render_views, "path": "configs[2]: march_rays + composite_rays loop (occupancy grid), bound 2; one native call per iteration, "
+                                                  + os.environ.get("FOC_RENDER_BURST", "8") + " samples per ray and iteration (image identical to the reference's schedule, FOC_RENDER_BURST=1)"}
             # ---- density-grid maintenance (update_extra_state, every 16 steps in the reference trainer, utils.py:850-852), timed on its own:
             # running it inside the loop above would replace the analytic occupancy grid by the untrained network's density
             m2.train()
