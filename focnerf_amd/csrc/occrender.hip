@@ -45,7 +45,8 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
                         void *planes /* fp16 [L, n_alive*n_step, 2] */, float *sigma, float *rgb,
                         const void *embeddings, const int32_t *offsets, const int32_t *offsets_host, uint32_t L, float S, uint32_t base_res,
                         const void *sigma_weights, uint32_t sigma_layers, const void *color_weights, uint32_t color_layers, uint32_t activation,
-                        const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, void *stream) {
+                        const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, uint32_t flags, int32_t *deaths, uint32_t deaths_base,
+                        uint32_t deaths_len, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(count, FOC_E_INVALID, "occ_render_step: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -59,12 +60,13 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     int32_t *worklist = reinterpret_cast<int32_t *>(scratch);
     int32_t *compact_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scratch) + ((((uint64_t)n_alive + 4) * 4 + 255) & ~(uint64_t)255));
     // the sample slots are zeroed here (the reference's torch.zeros) unless the march kernel of this burst length writes every one of them itself
-    const uint64_t to_zero = foc_march_rays_two_phase_fills(n_step) ? 0 : M * 8;
+    const int march_flags = 1 | ((flags & 1u) ? 2 : 0);    // normalised positions; flags bit 0: t re-derived after every sample (focnerf.h)
+    const uint64_t to_zero = foc_march_rays_two_phase_fills(n_step, march_flags) ? 0 : M * 8;
     hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d((to_zero > n_alive ? to_zero : n_alive) + 1, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), to_zero,
                        rays_alive_out, n_alive, worklist, compact_scratch, n_alive / 1024 + 2);
     FOC_CHECK_LAUNCH("occ_render_step(prepare)");
     int rc = foc_march_rays_two_phase(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas,
-                                      noises, worklist, 1, stream);
+                                      noises, worklist, march_flags, stream);
     if (rc) return rc;
     // the field in pieces of at most `piece` samples: the [L, piece, 2] planes between the encoder and the whole-field kernel (64 B per sample)
     // are bounded whatever the burst length (FOC_OCC_FIELD_PIECE, samples; default 2^23. Measured on the 800 x 800 view, 5.1 M samples per iteration:
@@ -83,7 +85,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     }
     // composite marks finished rays in the INPUT list; the compaction then writes the survivors to the output list
     return foc_composite_compact(n_alive, n_step, T_thresh, const_cast<int32_t *>(rays_alive), rays_t, sigma, rgb, deltas, weights_sum, depth, image, rays_alive_out,
-                                 count, compact_scratch, stream);
+                                 count, compact_scratch, deaths, deaths_base, deaths_len, stream);
 }
 
 } // extern "C"

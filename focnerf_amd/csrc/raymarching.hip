@@ -147,6 +147,8 @@ struct RmParams {
     float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Cf, Hm1;
     uint32_t H;
     float norm_inv;                    // 0: sample positions leave as they are; else they leave as (x + bound) * norm_inv, the encoder's [0,1] coordinates
+    int rederive;                      // != 0: after every emitted sample t continues from last_t + (t - last_t), the value composite_rays hands to the NEXT call
+                                       // (raymarching.cu:871, 899) — a burst of k samples then marches what k calls of one sample would (see foc_march_rays_two_phase)
 };
 // position of an emitted sample as it is stored (the native render step asks for the normalised form: csrc/occrender.hip)
 __device__ __forceinline__ float rm_out(const RmParams &p, float x) { return p.norm_inv != 0.0f ? (x + p.bound) * p.norm_inv : x; }
@@ -201,6 +203,7 @@ static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, 
     p.Hf = (float)H; p.Cf = (float)C; p.Hm1 = (float)(H - 1);
     p.H = H;
     p.norm_inv = 0.0f;
+    p.rederive = 0;
     return p;
 }
 
@@ -514,7 +517,9 @@ __device__ __forceinline__ bool rm_lane_walk(uint32_t n, int index, uint32_t n_s
             px[0] = rm_out(p, c.x); px[1] = rm_out(p, c.y); px[2] = rm_out(p, c.z);
             pd[0] = dx; pd[1] = dy; pd[2] = dz;
             t += c.dt;
-            pl[0] = c.dt; pl[1] = t - last_t;
+            const float span = t - last_t;
+            pl[0] = c.dt; pl[1] = span;
+            if (p.rederive) t = last_t + span;
             last_t = t;
             px += 3; pd += 3; pl += 2; step++;
         } else {
@@ -568,7 +573,9 @@ __global__ void __launch_bounds__(64) k_march_rays_staged(uint32_t n_alive, uint
             if (rm_cell(grid, p, ox, oy, oz, dx, dy, dz, t, c)) {
                 px[0] = rm_out(p, c.x); px[1] = rm_out(p, c.y); px[2] = rm_out(p, c.z);
                 t += c.dt;
-                pl[0] = c.dt; pl[1] = t - last_t;
+                const float span = t - last_t;
+                pl[0] = c.dt; pl[1] = span;
+                if (p.rederive) t = last_t + span;
                 last_t = t;
                 px += 3; pl += 2; step++;
             } else t = rm_skip(p, c, t, dx, dy, dz, rdx, rdy, rdz);
@@ -856,6 +863,24 @@ __global__ void __launch_bounds__(256) k_march_walkers(uint32_t n_alive, uint32_
     }
 }
 
+// Where rays die, for a caller that deals the samples over iterations differently from the reference and must know what the reference's
+// own loop would have done (focnerf_amd/renderer.py): hist[min(base + j, len - 1)][slice] += 1 for a ray that ends at slot j of this call
+// (no sample there, or the transmittance test after it). hist == nullptr: nothing recorded. A view's rays die in a few iterations, tens of
+// thousands per launch into n_step bins: the wave adds its rays per bin with one atomic, and the bins come in RM_DEATH_SLICES copies
+// (slice = wave index mod RM_DEATH_SLICES; the reader sums them) — one add per ray on 8 addresses cost 5 ms per view.
+#define RM_DEATH_SLICES 64u
+struct RmDeaths { int32_t *hist; uint32_t base, len; };
+__device__ __forceinline__ void rm_record_deaths(const RmDeaths &dh, bool died, uint32_t at, uint32_t n_step, uint32_t n) {
+    if (!dh.hist) return;
+    if (__ballot(died) == 0ull) return;
+    const uint32_t slice = (n >> 6) & (RM_DEATH_SLICES - 1u);
+    for (uint32_t j = 0; j < n_step; j++) {
+        const uint64_t m = __ballot(died && at == j);
+        if (m != 0ull && (threadIdx.x & 63u) == 0u)
+            atomicAdd(&dh.hist[(uint64_t)min(dh.base + j, dh.len - 1u) * RM_DEATH_SLICES + slice], (int)__builtin_popcountll(m));
+    }
+}
+
 // ---------------------------------------------------------------- R10 (raymarching.cu:818-905)
 // COUNT: the wave also adds its number of surviving entries to block_counts[n / 1024] (zeroed by the caller) — the first pass of the ordered
 // compaction that follows in the native render step (k_compact_count otherwise)
@@ -863,10 +888,12 @@ template <bool COUNT>
 __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
                                  int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
                                  const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                                 float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts) {
+                                 float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts,
+                                 RmDeaths dh) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const int index = n < n_alive ? rays_alive[n] : -1;
-    bool survives = false;
+    bool survives = false, died = false;
+    uint32_t died_at = 0;
     if (index >= 0) {                  // beyond the list or already marked dead (stays dead, nothing to accumulate)
     const float *s = sigmas + (uint64_t)n * n_step, *c = rgbs + (uint64_t)n * n_step * 3, *dl = deltas + (uint64_t)n * n_step * 2;
     float t = rays_t[index];
@@ -885,13 +912,14 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
         if (T < T_thresh) break;
         s++; c += 3; dl += 2; step++;
     }
-    if (step < n_step) rays_alive[n] = -1; else { rays_t[index] = t; survives = true; }
+    if (step < n_step) { rays_alive[n] = -1; died = true; died_at = step; } else { rays_t[index] = t; survives = true; }
     weights_sum[index] = weight_sum; depth[index] = d;
     image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
     }
     if (COUNT) {
         const uint64_t alive = __ballot(survives);
         if ((threadIdx.x & 63u) == 0u && alive != 0ull) atomicAdd(&block_counts[n >> 10], (int)__builtin_popcountll(alive));
+        rm_record_deaths(dh, died, died_at, n_step, n);
     }
 }
 
@@ -902,11 +930,13 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
 template <int NS, bool COUNT>
 __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, float T_thresh, int32_t *__restrict__ rays_alive, float *__restrict__ rays_t,
                                      const float *__restrict__ sigmas, const float *__restrict__ rgbs, const float *__restrict__ deltas,
-                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts) {
+                                     float *__restrict__ weights_sum, float *__restrict__ depth, float *__restrict__ image, int32_t *__restrict__ block_counts,
+                                     RmDeaths dh) {
     static_assert(NS % 4 == 0, "whole float4 loads");
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     const int index = n < n_alive ? rays_alive[n] : -1;
-    bool survives = false;
+    bool survives = false, died = false;
+    uint32_t died_at = 0;
     if (index >= 0) {
         float sg[NS], cl[3 * NS], dl[2 * NS];
         const float4 *ps = reinterpret_cast<const float4 *>(sigmas + (uint64_t)n * NS);
@@ -922,9 +952,11 @@ __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, flo
         float weight_sum = weights_sum[index], d = depth[index];
         float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
         bool ended = false;
+        uint32_t ended_at = 0;
 #pragma unroll
         for (int step = 0; step < NS; step++) {
             if (!ended) {
+                ended_at = (uint32_t)step;
                 if (dl[2 * step] == 0) ended = true;
                 else {
                     const float alpha = 1.0f - __expf(-sg[step] * dl[2 * step]);
@@ -938,30 +970,32 @@ __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, flo
                 }
             }
         }
-        if (ended) rays_alive[n] = -1; else { rays_t[index] = t; survives = true; }
+        if (ended) { rays_alive[n] = -1; died = true; died_at = ended_at; } else { rays_t[index] = t; survives = true; }
         weights_sum[index] = weight_sum; depth[index] = d;
         image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
     }
     if (COUNT) {
         const uint64_t alive = __ballot(survives);
         if ((threadIdx.x & 63u) == 0u && alive != 0ull) atomicAdd(&block_counts[n >> 10], (int)__builtin_popcountll(alive));
+        rm_record_deaths(dh, died, died_at, (uint32_t)NS, n);
     }
 }
 
 template <bool COUNT>
 static void rm_launch_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas, const float *rgbs,
-                                const float *deltas, float *weights_sum, float *depth, float *image, int32_t *block_counts, hipStream_t st) {
+                                const float *deltas, float *weights_sum, float *depth, float *image, int32_t *block_counts, hipStream_t st,
+                                RmDeaths dh = RmDeaths{nullptr, 0u, 1u}) {
     const dim3 grid(foc_div_up(n_alive, 64)), block(64);
     const bool aligned = ((reinterpret_cast<uintptr_t>(sigmas) | reinterpret_cast<uintptr_t>(rgbs) | reinterpret_cast<uintptr_t>(deltas)) & 15u) == 0;
     if (aligned && n_step == 4u)
-        hipLaunchKernelGGL((k_composite_rays_pre<4, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+        hipLaunchKernelGGL((k_composite_rays_pre<4, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, dh);
     else if (aligned && n_step == 8u)
-        hipLaunchKernelGGL((k_composite_rays_pre<8, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+        hipLaunchKernelGGL((k_composite_rays_pre<8, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, dh);
     else if (aligned && n_step == 16u)
-        hipLaunchKernelGGL((k_composite_rays_pre<16, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts);
+        hipLaunchKernelGGL((k_composite_rays_pre<16, COUNT>), grid, block, 0, st, n_alive, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, dh);
     else
         hipLaunchKernelGGL(k_composite_rays<COUNT>, grid, block, 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                           block_counts);
+                           block_counts, dh);
 }
 
 // ---------------------------------------------------------------- ordered compaction of rays_alive >= 0
@@ -1181,15 +1215,19 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 // (tools/time_occ_burst.py; 640 000 rays alive for most of it, bursts of 8): form 3 15.8 ms per view, form 1 17.4, form 2 18.2, form 0 18.8
 // — with ten waves per SIMD the lanes' lookup chains hide each other and what counts is instructions and how the samples reach memory;
 // 16 lanes per ray pay when few rays are left (FOC_MARCH_RAYS_ROW_MAX, as in foc_march_rays).
-static int rm_burst_form(uint32_t n_step, uint32_t n_alive) {
+static int rm_burst_form(uint32_t n_step, uint32_t n_alive, bool rederive = false) {
     const char *form_env = getenv("FOC_OCC_MARCH_FORM");
-    if (form_env && form_env[0]) return form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : form_env[0] == 's' ? 3 : 0;
+    int forced = -1;
+    if (form_env && form_env[0]) forced = form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : form_env[0] == 's' ? 3 : 0;
+    // the forms that generate a ray's lattice 16 points ahead (row, the walkers of the two phases) cannot re-derive t sample by sample
+    if (rederive && n_step > 1u) return forced == 2 ? 2 : 3;
+    if (forced >= 0) return forced;
     if (n_step <= 2u) return 0;
     const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");
     return (long)n_alive <= (row_env ? atol(row_env) : 131072) ? 1 : 3;
 }
 /* 1 when foc_march_rays_two_phase writes every slot of every list entry for this burst length (the caller need not zero them) */
-int foc_march_rays_two_phase_fills(uint32_t n_step) { const int f = rm_burst_form(n_step, 1u << 30); return (f == 1 || f == 3) ? 1 : 0; }
+int foc_march_rays_two_phase_fills(uint32_t n_step, int flags) { const int f = rm_burst_form(n_step, 1u << 30, (flags & 2) != 0); return (f == 1 || f == 3) ? 1 : 0; }
 
 /* R9 in two phases (k_march_rays_first + k_march_walkers): `scratch` = int32[n_alive + 4], its first word the worklist length, which the
  * caller has zeroed on this stream. Same arguments and results as foc_march_rays. */
@@ -1206,12 +1244,13 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
                 "march_rays_two_phase: unsupported C=%u H=%u max_steps=%u n_step=%u", C, H, max_steps, n_step);
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_two_phase: C*H^3 exceeds 2^24");
     RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
-    if (normalised) p.norm_inv = 1.0f / (2.0f * bound);    // `xyzs` receives (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
+    if (normalised & 1) p.norm_inv = 1.0f / (2.0f * bound);    // `xyzs` receives (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
+    p.rederive = (normalised & 2) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // A burst of several samples per ray meets an empty cell on most rays (every one of them would be marched twice): the two phases are
     // for bursts of one or two samples. Longer bursts take one launch — one ray per lane with the wave's samples staged in LDS ("staged"),
     // 16 lanes per ray when few rays are left ("row"); FOC_OCC_MARCH_FORM = two | row | lane | staged overrides the choice (A/B runs, tests).
-    const int form = rm_burst_form(n_step, n_alive);
+    const int form = rm_burst_form(n_step, n_alive, p.rederive != 0);
     if (form == 1) {
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0, st,
                            n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
@@ -1260,12 +1299,15 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
  * composite kernel itself: block_counts = int32[n_alive / 1024 + 2], ZEROED by the caller on this stream. (csrc/occrender.hip) */
 int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
-                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream) {
+                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, int32_t *deaths, uint32_t deaths_base, uint32_t deaths_len,
+                          void *stream) {
     FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n_alive > 0 && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && out && n_out && block_counts, FOC_E_INVALID,
                 "composite_compact: null pointer");
+    FOC_REQUIRE(!deaths || deaths_len >= 1, FOC_E_INVALID, "composite_compact: empty death histogram");
     hipStream_t st = (hipStream_t)stream;
-    rm_launch_composite<true>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, st);
+    rm_launch_composite<true>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, st,
+                              RmDeaths{deaths, deaths_base, deaths ? deaths_len : 1u});
     FOC_CHECK_LAUNCH("composite_compact(composite)");
     const uint32_t nb = foc_div_up(n_alive, 1024);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, n_out);

@@ -294,13 +294,17 @@ class NeRFRenderer(nn.Module):
         L = enc.offsets.shape[0] - 1
         lag = max(1, int(os.environ.get("FOC_RENDER_COUNT_LAG", "2")))
         # Samples per ray and iteration. The reference sizes a burst so that live x burst stays within the view's ray count (max(min(n // live,
-        # 8), 1), renderer.py:337: one sample per ray for the ~130 iterations in which most rays are alive) — a memory bound of its time. What
-        # a ray receives does not depend on how its samples are dealt over iterations: the march continues from rays_t, which composite_rays
-        # advances by the exact differences t_k - t_(k-1), and composite_rays accumulates sample by sample. So every iteration here marches
-        # at least FOC_RENDER_BURST samples per ray (default 8, at most 16; 1 = the reference's schedule): 8x fewer iterations, the rays' state
-        # read and written once per 8 samples, a march kernel that looks up 16 lattice points per round. A ray that dies inside a burst wastes
-        # the rest of it, as it does in the reference's own bursts of 8. Like the reference's loop, this one ends once `marched` reaches
-        # max_steps, a multiple of the burst later at most (the reference: 1024..1031 samples for a ray still alive, depending on the others).
+        # 8), 1), renderer.py:337: ONE sample per ray for the ~130 iterations in which most rays are alive) — a memory bound of its time. What
+        # a ray receives does not depend on how its samples are dealt over iterations, provided the march continues after each sample from
+        # the t composite_rays would hand to the next iteration (rays_t + deltas[:,1]: `flags` below) — composite_rays accumulates sample by
+        # sample anyway. So an iteration here marches at least FOC_RENDER_BURST samples per ray (default 8, at most 16; 1 = the reference's
+        # schedule): 8x fewer iterations, the rays' state read and written once per 8 samples. A ray that dies inside a burst wastes the rest
+        # of it, as it does in the reference's own bursts of 8.
+        # What DOES depend on the schedule is where the reference's loop stops for rays that are still alive after max_steps samples: `step +=
+        # n_step` overshoots max_steps by up to 7, depending on how many rays were alive at each of its iterations. The wide bursts therefore
+        # end 8 samples short of max_steps; if rays are still alive there, the reference's own schedule is replayed from the histogram of the
+        # sample index at which every ray died (`deaths`, filled by the composite kernel) and the last iterations run exactly as the reference
+        # would run them (its burst rule on the exact live count, one host round trip each) — same image, bit for bit, cap included.
         wide = min(max(int(os.environ.get("FOC_RENDER_BURST", "8")), 1), 16)
         cap = n * wide                                         # most samples of one iteration (the reference's own bursts keep live x burst <= n)
         piece = min(cap, max(1024, int(os.environ.get("FOC_OCC_FIELD_PIECE", str(1 << 23)))))
@@ -313,20 +317,42 @@ class NeRFRenderer(nn.Module):
         still = torch.zeros(n, dtype=torch.float32, device=dev)
         jitter = torch.rand(n, dtype=torch.float32, device=dev) if perturb else still
         ring = torch.empty(lag + 1, dtype=torch.int32).pin_memory()
-        waiting, live, marched, it = [], n, 0, 0
+        n_deaths = int(max_steps) + 32
+        deaths = torch.zeros(n_deaths, 64, dtype=torch.int32, device=dev)       # [sample index][slice]: see RM_DEATH_SLICES
+        trace = bool(os.environ.get("FOC_RENDER_TRACE"))
         S = float(np.log2(enc.per_level_scale))
+
+        def rule(n_alive):                                      # renderer.py:337
+            return max(min(n // n_alive, 8), 1)
+
         with half_cache_scope():
             emb, ws, wc = _half_of(enc.embeddings), _half_of(sn.weights), _half_of(cn.weights)
             st = stream_of(o)
-            while marched < max_steps and live > 0:
-                burst = max(min(n // live, 8), min(wide, max_steps - marched), 1)
+            state = {"it": 0, "marched": 0}
+
+            def step(live, burst, flags):
+                it, marched = state["it"], state["marched"]
+                if trace:
+                    print(f"[occ loop] it {it} live<= {live} burst {burst} flags {flags} marched {marched}", flush=True)
                 src, dst = lists[it & 1], lists[(it & 1) ^ 1]
                 check(lib.foc_occ_render_step(live, burst, ptr(src), ptr(dst), ptr(count), ptr(t_now), ptr(o), ptr(d), float(self.bound), float(dt_gamma),
                                               int(max_steps), self.cascade, self.grid_size, ptr(self.density_bitfield), ptr(near), ptr(far),
                                               ptr(jitter if marched == 0 else still), ptr(samples), ptr(planes), ptr(sigma), ptr(rgb), ptr(emb),
                                               ptr(enc.offsets), None, L, S, enc.base_resolution, ptr(ws), sn.num_layers, ptr(wc), cn.num_layers, sn.activation,
-                                              None, float(T_thresh), ptr(opacity), ptr(depth), ptr(image), ptr(scratch), st), "occ_render_step")
-                slot = it % (lag + 1)
+                                              None, float(T_thresh), ptr(opacity), ptr(depth), ptr(image), ptr(scratch), flags, ptr(deaths), marched, n_deaths,
+                                              st), "occ_render_step")
+                state["it"], state["marched"] = it + 1, marched + burst
+
+            # ---- the wide bursts, the live count read `lag` iterations late (an upper bound: rays only die)
+            wide_end = max(int(max_steps) - 8, 0) if wide > 1 else 0
+            waiting, live = [], n
+            while state["marched"] < wide_end and live > 0:
+                ref_burst = rule(live)
+                burst = max(ref_burst, min(wide, wide_end - state["marched"]))
+                # several of the reference's one-sample iterations in one: every sample starts from the t the reference's NEXT iteration would
+                # start from, last_t + (t - last_t) as composite_rays re-derives it (an ulp off the march's own t when the subtraction rounds)
+                step(live, burst, 1 if (ref_burst == 1 and burst > 1) else 0)
+                slot = (state["it"] - 1) % (lag + 1)
                 ring[slot:slot + 1].copy_(count, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -335,8 +361,31 @@ class NeRFRenderer(nn.Module):
                     ev0, s0 = waiting.pop(0)
                     ev0.synchronize()
                     live = min(live, int(ring[s0]))
-                marched += burst
-                it += 1
+            if live <= 0:
+                return
+            # ---- up to max_steps (and the reference's overshoot): the reference's own iterations
+            if state["it"] > 0:
+                live = int(count.item())                        # exact from here on
+            if live <= 0:
+                return
+            done = state["marched"]
+            virt = 0                                            # the reference's `step` at its last iteration boundary <= done
+            if done > 0:
+                died = torch.cumsum(deaths.sum(1), 0).cpu().tolist()   # died[i] = rays whose last sample index is <= i
+                while True:
+                    b = rule(n - (died[virt - 1] if virt > 0 else 0))
+                    if virt + b > done:
+                        break
+                    virt += b
+                nxt = virt + b
+            else:
+                nxt = rule(live)
+            while True:
+                step(live, nxt - state["marched"], 0)
+                live = int(count.item())
+                if state["marched"] >= max_steps or live <= 0:
+                    break
+                nxt = state["marched"] + rule(live)
 
     # ------------------------------------------------------------------ occupancy-grid maintenance (device side)
     def _require_grid(self, what):

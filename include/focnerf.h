@@ -134,27 +134,39 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  * `count` (device int) late. samples: fp32 [M * 8] = positions [M,3] (in the encoder's [0,1] coordinates) | dirs [M,3] | deltas [M,2]; planes fp16
  * [L, min(M, piece), 2]: the field is evaluated in pieces of FOC_OCC_FIELD_PIECE samples (default 2^23), whose planes stay in the Infinity Cache;
  * sigma [M], rgb [M,3] fp32; scratch: foc_occ_render_step_scratch_bytes(n_alive of the FIRST iteration) bytes. Hash grid D = 3, C = 2,
- * fp16 table (embeddings), linear interpolation; networks as foc_nerf_field_inference (hidden 64; obj_feat may be NULL). density_scale 1. */
+ * fp16 table (embeddings), linear interpolation; networks as foc_nerf_field_inference (hidden 64; obj_feat may be NULL). density_scale 1.
+ * flags bit 0: the march re-derives t after every sample (foc_march_rays_two_phase, flag bit 1): a caller that marches n_step samples where
+ * the reference's loop would march one per iteration sets it and receives the reference's samples. deaths / deaths_base / deaths_len: as
+ * foc_composite_compact. */
 /* The two building blocks of the step that have no reference counterpart, usable on their own:
  * foc_march_rays_two_phase — foc_march_rays with the same arguments and results (bit for bit), as two launches: first visits per lane, then
  *   the rays that met an empty cell ("walkers") compacted on a worklist and marched 16 lanes per ray (one ray per lane when the list is
- *   long). scratch: int32[n_alive + 4] whose first word the caller has zeroed on this stream. normalised != 0: xyzs receives
- *   (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x. Bursts of more than two samples (most rays meet an
+ *   long). scratch: int32[n_alive + 4] whose first word the caller has zeroed on this stream. `normalised` is a flag word. Bit 0: xyzs
+ *   receives (x + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates, instead of x. Bit 1 ("re-derive"): after every emitted sample
+ *   the march continues from last_t + (t - last_t) instead of t — the value composite_rays reconstructs from deltas[:,1] and stores in
+ *   rays_t for the NEXT call (raymarching.cu:871, 899). The two differ by an ulp when t - last_t is not exact in fp32 (a skip over empty
+ *   space that more than doubles t), so the reference's samples depend on where its bursts end; with bit 1 a burst of k samples marches
+ *   exactly what k consecutive calls with n_step = 1 would, whatever k. Bursts of more than two samples (most rays meet an
  *   empty cell inside them and would be marched twice) take ONE launch instead — one ray per lane (16 lanes per ray when at most
  *   FOC_MARCH_RAYS_ROW_MAX rays are listed) — of a kernel that collects the samples in LDS and writes ALL n_step slots of every list entry
  *   as runs of consecutive floats (zeros where the ray ended early or the entry is -1): foc_march_rays_two_phase_fills(n_step) != 0 says
  *   so, and the caller may then skip zeroing xyzs / dirs / deltas. FOC_OCC_MARCH_FORM = two | row | lane | staged overrides the choice
  *   (A/B runs, tests; "lane" = foc_march_rays' serial kernel, which needs the zeros).
  * foc_composite_compact — foc_composite_rays followed by the ordered compaction of the surviving list entries into `out` (count in n_out),
- *   the compaction's counting pass done by the composite kernel. block_counts: int32[n_alive / 1024 + 2], zeroed by the caller. */
+ *   the compaction's counting pass done by the composite kernel. block_counts: int32[n_alive / 1024 + 2], zeroed by the caller.
+ *   deaths (may be NULL): int32[deaths_len][64] histogram in 64 slices (sum them): deaths[min(deaths_base + j, deaths_len - 1)][slice] += 1
+ *   for every ray that ends at slot j of this call (no sample there, or the transmittance test after it). With deaths_base = the samples marched per ray so far, the histogram
+ *   over a view tells how many rays were alive after any number of samples — what the reference's burst rule (renderer.py:337) looks at —
+ *   to a caller that deals the samples over iterations differently. */
 int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, const float *rays_t, const float *rays_o,
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                              const float *noises, int32_t *scratch, int normalised, void *stream);
-int foc_march_rays_two_phase_fills(uint32_t n_step);
+int foc_march_rays_two_phase_fills(uint32_t n_step, int flags);
 int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
-                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, void *stream);
+                          float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, int32_t *deaths, uint32_t deaths_base,
+                          uint32_t deaths_len, void *stream);
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays);
 int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, int32_t *rays_alive_out, int32_t *count,
                         float *rays_t, const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,
@@ -162,7 +174,8 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
                         float *samples, void *planes, float *sigma, float *rgb,
                         const void *embeddings, const int32_t *offsets, const int32_t *offsets_host, uint32_t L, float S, uint32_t base_res,
                         const void *sigma_weights, uint32_t sigma_layers, const void *color_weights, uint32_t color_layers, uint32_t activation,
-                        const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, void *stream);
+                        const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, uint32_t flags,
+                        int32_t *deaths, uint32_t deaths_base, uint32_t deaths_len, void *stream);
 
 int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out,
                       int32_t *scratch, void *stream);

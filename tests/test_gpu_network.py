@@ -342,9 +342,29 @@ def test_native_inference_loop_edge_cases():
         assert (p["image"] - q["image"]).abs().mean() < 2e-2
 
 
+@pytest.mark.parametrize("burst", ["1", "3", "8", "16"])
+def test_native_inference_loop_burst_lengths_and_the_step_cap(burst, monkeypatch):
+    """The native loop deals a ray's samples over iterations in bursts of FOC_RENDER_BURST (default 8) where the reference's rule gives one sample
+    per ray while most rays are alive: same image and depth, bit for bit, as the Python loop on the reference's schedule — also when the loop
+    ends on `max_steps` (100, 37: not multiples of the burst; every ray is still alive then) and with a transmittance threshold that ends rays
+    inside a burst (T_thresh 0.3), an opaque field (density_scale-free: a bias on the density) included."""
+    from focnerf_amd import synthetic
+    monkeypatch.setenv("FOC_RENDER_BURST", burst)
+    bound = 2
+    m = _model(bound, True, seed=5).eval()
+    o, d = synthetic.make_view_rays(48, 48, bound, 1, seed=8, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        for max_steps, thresh in ((1024, 1e-4), (100, 1e-4), (37, 1e-4), (1024, 0.3)):
+            kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=max_steps, bg_color=1.0, T_thresh=thresh)
+            a = m.render(o, d, **kw)
+            b = m.render(o, d, device_compaction=True, **kw)
+            assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"]), (max_steps, thresh)
+        assert (a["image"] < 0.99).any()
+
+
 def test_native_inference_loop_at_baseline_view_size():
-    """BASELINE configs[2] render size: one 800 x 800 view (640 000 rays) through the native loop (one C call per iteration, two-phase march, late
-    count) and through the Python loop with the reference's boolean-mask compaction: the same image and depth, bit for bit."""
+    """BASELINE configs[2] render size: one 800 x 800 view (640 000 rays) through the native loop (one C call per iteration, bursts of 8 samples
+    per ray, late count) and through the Python loop with the reference's boolean-mask compaction and schedule: the same image and depth, bit for bit."""
     from focnerf_amd import synthetic
     import bench
     bound = 2

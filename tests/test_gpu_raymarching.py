@@ -510,7 +510,7 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
     st = stream_of(o)
     for normalised in (0, 1):
-        fills = bool(lib.foc_march_rays_two_phase_fills(n_step))
+        fills = bool(lib.foc_march_rays_two_phase_fills(n_step, normalised))
         assert fills == (form in ("row", "staged") or (form == "" and n_step > 2))
         x1, d1, l1 = (torch.full((M, k), float("nan") if fills else 0.0, device="cuda") for k in (3, 3, 2))
         scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
@@ -533,7 +533,58 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
     blocks = torch.zeros(N // 1024 + 2, dtype=torch.int32, device="cuda")
     check(lib.foc_composite_compact(N, n_step, 1e-4, ptr(b_list), ptr(b_t), ptr(sig), ptr(rgb), ptr(l0), ptr(b_ws), ptr(b_dp), ptr(b_im), ptr(out), ptr(n_out),
-                                    ptr(blocks), st), "composite_compact")
+                                    ptr(blocks), None, 0, 1, st), "composite_compact")
     assert int(n_out) == int(count) and torch.equal(out, kept) and torch.equal(b_list, a_list)
     for a, b in ((a_t, b_t), (a_ws, b_ws), (a_dp, b_dp), (a_im, b_im)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("form", ["staged", "lane", ""])
+@pytest.mark.parametrize("max_steps", [37, 1024])
+def test_rederived_burst_equals_single_sample_calls(rm, form, max_steps, monkeypatch):
+    """foc_march_rays_two_phase with flag bit 1: a burst of k samples == k calls of the reference kernel with n_step = 1, each continued from
+    rays_t + deltas[:,1] the way composite_rays hands t to the next call (raymarching.cu:871, 899) — bit for bit, also where a skip over
+    empty space more than doubles t and t - last_t is rounded (max_steps 37: steps of dt_max; rays starting inside the box at t = 0.2)."""
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    if form:
+        monkeypatch.setenv("FOC_OCC_MARCH_FORM", form)
+    else:
+        monkeypatch.delenv("FOC_OCC_MARCH_FORM", raising=False)
+    N, k = 4000, 8
+    s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=11, max_steps=max_steps)
+    C, H = s["cascade"], 128
+    # half of the rays start INSIDE the box (near = min_near = 0.2): the first occupied cell is then several times t away
+    o = s["rays_o"].clone()
+    o[::2] *= 0.15
+    o = o.contiguous()
+    n_ref, f_ref = oracle.near_far_from_aabb(o.numpy(), s["rays_d"].numpy(), s["aabb"].numpy(), 0.2)
+    o, d, bits = o.cuda(), s["rays_d"].cuda(), s["bits"].cuda()
+    nears, fars = torch.from_numpy(n_ref).cuda(), torch.from_numpy(f_ref).cuda()
+    lst = torch.arange(N, dtype=torch.int32, device="cuda")
+    # reference: k single-sample calls, t handed on as composite_rays does (fp32 add of deltas[:,1]); a ray that returned no sample is finished
+    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "0")
+    t_now = nears.clone()
+    alive = torch.ones(N, dtype=torch.bool, device="cuda")
+    want_x, want_l = torch.zeros(N, k, 3, device="cuda"), torch.zeros(N, k, 2, device="cuda")
+    for j in range(k):
+        x, _, dl = rm.march_rays(N, 1, lst, t_now, o, d, s["bound"], bits, C, H, nears, fars, -1, False, 1 / 128, max_steps)
+        got = (dl[:N, 0] > 0) & alive
+        want_x[:, j][got] = x[:N][got]
+        want_l[:, j][got] = dl[:N][got]
+        t_now = torch.where(got, t_now + dl[:N, 1], t_now)
+        alive = got
+    assert alive.float().mean() > 0.3, "most rays should still be marching after k samples"
+    st = stream_of(o)
+    noises = torch.zeros(N, device="cuda")
+    outs = {}
+    for flags in (2, 0):
+        x1, d1, l1 = (torch.zeros(N * k, c, device="cuda") for c in (3, 3, 2))
+        scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
+        check(lib.foc_march_rays_two_phase(N, k, ptr(lst), ptr(nears), ptr(o), ptr(d), float(s["bound"]), 1 / 128, max_steps, C, H, ptr(bits), ptr(nears), ptr(fars),
+                                           ptr(x1), ptr(d1), ptr(l1), ptr(noises), ptr(scratch), flags, st), "two_phase")
+        outs[flags] = (x1.view(N, k, 3), l1.view(N, k, 2))
+    assert torch.equal(outs[2][0], want_x) and torch.equal(outs[2][1], want_l)
+    # without the bit the burst keeps the march's own t: last_t + fl(t - last_t) rounds back to t except in tie cases, so on ordinary scenes the
+    # two forms agree (they do here) — the bit turns "practically always" into "always"
+    same = torch.equal(outs[0][1], want_l)
+    print("burst without re-derivation equals the single-sample calls:", same)
