@@ -544,6 +544,7 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="headline step through the torch glue of NeRFRenderer.run instead of csrc/fixedstep.hip")
     ap.add_argument("--dry-run-cpu", action="store_true", help="no GPU: gloo ranks, combined-render leg on injected CPU ops (launch / collective logic only)")
     ap.add_argument("--combined-views", type=int, default=2)
+    ap.add_argument("--exchange-timeout", type=float, default=150.0, help="N > 1: seconds the combined-render leg may take before every rank abandons it")
     ap.add_argument("--combined-no-overlap", action="store_true", help="combined-render leg: wait for each chunk's all-to-all before evaluating the next chunk")
     args = ap.parse_args()
 
@@ -872,6 +873,22 @@ def main():
         # ---- configs[3]/[4]: K = N objects, one per rank, a full 800x800 view end to end (field evaluation + exchange + composite + gather)
         progress("combined-render leg")
         model.eval()
+        # The N-rank exchange is the one part of this file in which a rank can wait for another one. If it makes no progress (a rank that
+        # failed and left the others inside a collective), every rank leaves on its own timer — before the process group's 240 s timeout
+        # would abort the job — and rank 0 still prints the line with the headline and what has been measured so far.
+        abandoned = {"leg": False}
+        guard = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                result["combined_render"] = {"error": f"no progress for {args.exchange_timeout} s in the {world}-rank exchange: leg abandoned", "world_size": world}
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+            guard = threading.Timer(args.exchange_timeout, give_up)
+            guard.daemon = True
+            guard.start()
         try:
             from focnerf_amd import raymarching as rm
             from focnerf_amd.field import half_cache_scope
@@ -918,6 +935,13 @@ def main():
         except Exception as e:   # an extra must never take the headline number down with it
             import traceback
             result["combined_render"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
+            abandoned["leg"] = world > 1                     # the other ranks may be inside a collective: no orderly shutdown of the group
+        if guard is not None:
+            guard.cancel()
+        if abandoned["leg"]:
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         progress("cpu baseline: C oracle port")
