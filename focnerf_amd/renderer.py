@@ -9,7 +9,11 @@ reference's own renderer also works unchanged on the same ops.
 What differs from the reference caller:
   * the density-grid maintenance runs on the device (csrc/densitygrid.hip) instead of Python loops over 128^3 cells
     with host round trips; the torch restatements used to check it live with the tests (tests/torch_baselines.py);
-  * `run_cuda(..., device_compaction=True)` compacts the list of live rays on the device (order preserving);
+  * the inference loop of `run_cuda` runs as one native call per iteration wherever that call serves the network (hash grid + the two
+    FFMLPs under autocast): the list of live rays compacted on the device, 8 samples per ray and iteration, the reference's stopping
+    point reproduced — same image and depth as the reference's loop, bit for bit (tests/test_gpu_network.py). `device_compaction=False`
+    runs the reference's loop as it is (boolean mask, one host round trip per iteration), `=True` also takes the device-side
+    compaction for networks the native call does not serve;
   * `run(..., weight_thresh=...)` names the threshold below which a sample's colour is not queried (1e-10 in FOC, 1e-4 in the legacy
     renderer), and `return_fields` controls whether the per-sample fields COMBINED.py merges are returned.
 """
@@ -203,7 +207,7 @@ class NeRFRenderer(nn.Module):
         return sigmas if self.density_scale == 1 else self.density_scale * sigmas      # x * 1 == x: no launch for the default scale
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4,
-                 device_compaction=False, **kwargs):
+                 device_compaction=None, **kwargs):
         """Samples only where the occupancy bitfield is set (legacy/nerf/renderer.py:256-376). Training: one marching pass, one
         evaluation of the field, one compositing node. Inference: rays advance a few samples at a time and leave the list once they are
         opaque or out of the box."""
@@ -227,9 +231,13 @@ class NeRFRenderer(nn.Module):
             alive = torch.arange(n, dtype=torch.int32, device=dev)
             t_now = near.clone()
             marched = 0
-            if device_compaction and self._native_loop_ok(o):
+            # device_compaction: None (default) = the native loop where it serves the network (same image and depth as the reference's loop,
+            # bit for bit: tests/test_gpu_network.py), else the reference's loop as it is; True = the native loop, else the Python loop with the
+            # list compacted on the device and its length read late; False = the reference's loop (boolean mask, a host round trip per iteration)
+            if (device_compaction is None or device_compaction) and self._native_loop_ok(o):
                 self._native_inference_loop(o, d, near, far, alive, t_now, opacity, depth, image, perturb, dt_gamma, max_steps, T_thresh)
                 marched = max_steps                                   # the Python loop below has nothing left to do
+            device_compaction = bool(device_compaction)
             import contextlib
             from .field import half_cache_scope
             # the loop evaluates the same parameters once per burst: one fp16 conversion per view when nothing can write them in between

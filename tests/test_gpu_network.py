@@ -104,15 +104,16 @@ def test_inference_loop_matches_training_composite(monkeypatch):
         m.train()
         a = m.render(o, d, staged=False, perturb=False, force_all_rays=True, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0)
         m.eval()
-        b = m.render(o, d, **kw)
+        b = m.render(o, d, device_compaction=False, **kw)                 # the reference's loop
         assert m._native_loop_ok(o.view(-1, 3))
+        dflt = m.render(o, d, **kw)                                       # default: the native loop where it serves the network
         c = m.render(o, d, device_compaction=True, **kw)                  # native loop
         monkeypatch.setenv("FOC_RENDER_NATIVE", "0")
         e = m.render(o, d, device_compaction=True, **kw)                  # Python loop, late count
         monkeypatch.setenv("FOC_RENDER_COUNT_LAG", "0")
         f = m.render(o, d, device_compaction=True, **kw)                  # Python loop, count read every iteration
     assert torch.allclose(a["image"], b["image"], atol=2e-3)
-    for other in (c, e, f):
+    for other in (c, e, f, dflt):
         assert torch.equal(b["image"], other["image"]) and torch.equal(b["depth"], other["depth"])
     assert (a["image"] < 0.99).any(), "the view should hit the object"
 
@@ -325,13 +326,13 @@ def test_native_inference_loop_edge_cases():
     kw = dict(staged=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         for n in (1, 7, 1599):
-            a = m.render(o[:, :n], d[:, :n], perturb=False, **kw)
+            a = m.render(o[:, :n], d[:, :n], perturb=False, device_compaction=False, **kw)
             b = m.render(o[:, :n], d[:, :n], perturb=False, device_compaction=True, **kw)
             assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"]), n
         # rays pointing away from the box: nothing to march, the background comes back
         away = -d[:, :500]
         far_o = o[:, :500] * 4.0
-        a = m.render(far_o, away, perturb=False, **kw)
+        a = m.render(far_o, away, perturb=False, device_compaction=False, **kw)
         b = m.render(far_o, away, perturb=False, device_compaction=True, **kw)
         assert torch.equal(a["image"], b["image"]) and bool((b["image"] == 1.0).all())
         # jitter: another draw of the same distribution per loop form — close to each other and to the unjittered image, not equal
@@ -356,7 +357,7 @@ def test_native_inference_loop_burst_lengths_and_the_step_cap(burst, monkeypatch
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         for max_steps, thresh in ((1024, 1e-4), (100, 1e-4), (37, 1e-4), (1024, 0.3)):
             kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=max_steps, bg_color=1.0, T_thresh=thresh)
-            a = m.render(o, d, **kw)
+            a = m.render(o, d, device_compaction=False, **kw)
             b = m.render(o, d, device_compaction=True, **kw)
             assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"]), (max_steps, thresh)
         assert (a["image"] < 0.99).any()
@@ -373,7 +374,7 @@ def test_native_inference_loop_at_baseline_view_size():
     o, d = synthetic.get_rays(poses[:1], intr, 800, 800)
     kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, bg_color=1.0, T_thresh=1e-4)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        a = m.render(o, d, **kw)
+        a = m.render(o, d, device_compaction=False, **kw)
         b = m.render(o, d, device_compaction=True, **kw)
     assert a["image"].shape == (1, 640000, 3)
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])

@@ -161,7 +161,7 @@ def test_run_cuda_matches_reference_renderer():
     tr1 = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=0.25, perturb=False, force_all_rays=False, max_steps=256, T_thresh=1e-4)
     m.eval()
     with torch.no_grad():
-        ev = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4)
+        ev = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4, device_compaction=False)
         ev2 = m.run_cuda(o[None], d[None], dt_gamma=1 / 128, bg_color=None, perturb=False, max_steps=256, T_thresh=1e-4, device_compaction=True)
     assert np.array_equal(to_np(m.step_counter), g["rc_step_counter"])
     for got, img, dep in ((tr0, "rc_train0_image", "rc_train0_depth"), (tr1, "rc_train1_image", "rc_train1_depth"), (ev, "rc_eval_image", "rc_eval_depth"),

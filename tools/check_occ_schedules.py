@@ -16,7 +16,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             os.environ["FOC_OCC_MARCH_FORM"] = form
             for max_steps, thresh in ((1024, 1e-4), (100, 1e-4), (37, 1e-4), (1024, 0.3)):
                 kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=max_steps, bg_color=1.0, T_thresh=thresh)
-                a = m.render(o, d, **kw)
+                a = m.render(o, d, device_compaction=False, **kw)
                 b = m.render(o, d, device_compaction=True, **kw)
                 bad = (a["image"] != b["image"]).any(-1).sum().item()
                 badd = (a["depth"] != b["depth"]).sum().item()
