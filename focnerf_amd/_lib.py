@@ -45,8 +45,9 @@ SIGNATURES = {
     "foc_composite_rays": (i32, [u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_compact_alive": (i32, [c_vp, u32, c_vp, c_vp, c_vp, c_vp]),
     "foc_march_rays_two_phase": (i32, [u32, u32, c_vp, c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, c_vp]),
-    "foc_composite_compact": (i32, [u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, c_vp]),
+    "foc_composite_compact": (i32, [u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, i32, c_vp]),
     "foc_march_rays_two_phase_fills": (i32, [u32, i32]),
+    "foc_march_rays_two_phase_sample_major": (i32, [u32, u32, i32]),
     "foc_occ_render_step_scratch_bytes": (u64, [u32]),
     "foc_occ_render_step": (i32, [u32, u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp, u32, f32, u32, c_vp, u32, c_vp, u32, u32, c_vp, f32, c_vp, c_vp, c_vp, c_vp, u32, c_vp, u32, u32, c_vp]),

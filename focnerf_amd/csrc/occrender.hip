@@ -60,7 +60,11 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     int32_t *worklist = reinterpret_cast<int32_t *>(scratch);
     int32_t *compact_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scratch) + ((((uint64_t)n_alive + 4) * 4 + 255) & ~(uint64_t)255));
     // the sample slots are zeroed here (the reference's torch.zeros) unless the march kernel of this burst length writes every one of them itself
-    const int march_flags = 1 | ((flags & 1u) ? 2 : 0);    // normalised positions; flags bit 0: t re-derived after every sample (focnerf.h)
+    int march_flags = 1 | ((flags & 1u) ? 2 : 0);          // normalised positions; flags bit 0: t re-derived after every sample (focnerf.h)
+    // sample-major sample arrays ([n_step][n_alive]) where the march kernel of this call can write them (FOC_OCC_SAMPLE_MAJOR=0: ray-major)
+    const char *sm_env = getenv("FOC_OCC_SAMPLE_MAJOR");
+    const int sample_major = (n_step > 1 && !(sm_env && sm_env[0] == '0') && foc_march_rays_two_phase_sample_major(n_alive, n_step, march_flags)) ? 1 : 0;
+    if (sample_major) march_flags |= 4;
     const uint64_t to_zero = foc_march_rays_two_phase_fills(n_step, march_flags) ? 0 : M * 8;
     hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d((to_zero > n_alive ? to_zero : n_alive) + 1, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), to_zero,
                        rays_alive_out, n_alive, worklist, compact_scratch, n_alive / 1024 + 2);
@@ -85,7 +89,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     }
     // composite marks finished rays in the INPUT list; the compaction then writes the survivors to the output list
     return foc_composite_compact(n_alive, n_step, T_thresh, const_cast<int32_t *>(rays_alive), rays_t, sigma, rgb, deltas, weights_sum, depth, image, rays_alive_out,
-                                 count, compact_scratch, deaths, deaths_base, deaths_len, stream);
+                                 count, compact_scratch, deaths, deaths_base, deaths_len, sample_major, stream);
 }
 
 } // extern "C"

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(64) k_march_rays_staged(uint32_t n_alive, uint
                              const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                              const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
                              float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                             const float *__restrict__ noises) {
+                             const float *__restrict__ noises, int sample_major) {
     extern __shared__ float rm_stage[];                    // [64][5 n_step + 4]
     const uint32_t lane = threadIdx.x, n0 = blockIdx.x * 64u, n = n0 + lane;
     const uint32_t stride = 5u * n_step + 4u;
@@ -585,6 +585,27 @@ __global__ void __launch_bounds__(64) k_march_rays_staged(uint32_t n_alive, uint
     tail[0] = __builtin_bit_cast(float, step); tail[1] = dx; tail[2] = dy; tail[3] = dz;
     __syncthreads();                                       // one wave per workgroup: orders the LDS traffic, costs nothing
     const uint32_t cnt = min(64u, n_alive - n0);           // list entries of this wave (n0 < n_alive by the launch)
+    if (sample_major) {
+        // [n_step][n_alive] arrays: slot s of the wave's entries is one run of 3 cnt (2 cnt) consecutive floats. The 64 rows of an encoder /
+        // network wave are then 64 NEIGHBOURING rays at the same burst slot — closer to each other than 8 consecutive samples of 8 rays
+        // (a pixel apart against a step apart) — and the composite kernel's loads are contiguous across lanes.
+        for (uint32_t sl = 0; sl < n_step; sl++) {
+            float *gx = xyzs + ((uint64_t)sl * n_alive + n0) * 3u, *gd = dirs + ((uint64_t)sl * n_alive + n0) * 3u, *gl = deltas + ((uint64_t)sl * n_alive + n0) * 2u;
+            for (uint32_t k = lane; k < cnt * 3u; k += 64u) {
+                const uint32_t r = k / 3u, cc = k - r * 3u;
+                const float *rec = rm_stage + r * stride;
+                const bool on = sl < __builtin_bit_cast(uint32_t, rec[5u * n_step]);
+                gx[k] = on ? rec[sl * 3u + cc] : 0.0f;
+                gd[k] = on ? rec[5u * n_step + 1u + cc] : 0.0f;
+            }
+            for (uint32_t k = lane; k < cnt * 2u; k += 64u) {
+                const uint32_t r = k >> 1;
+                const float *rec = rm_stage + r * stride;
+                gl[k] = sl < __builtin_bit_cast(uint32_t, rec[5u * n_step]) ? rec[3u * n_step + sl * 2u + (k & 1u)] : 0.0f;
+            }
+        }
+        return;
+    }
     const uint32_t lx = 3u * n_step, ll = 2u * n_step;
     const float inv_lx = 1.0f / (float)lx, inv_ll = 1.0f / (float)ll;
     float *gx = xyzs + (uint64_t)n0 * lx, *gd = dirs + (uint64_t)n0 * lx, *gl = deltas + (uint64_t)n0 * ll;
@@ -869,7 +890,7 @@ __global__ void __launch_bounds__(256) k_march_walkers(uint32_t n_alive, uint32_
 // thousands per launch into n_step bins: the wave adds its rays per bin with one atomic, and the bins come in RM_DEATH_SLICES copies
 // (slice = wave index mod RM_DEATH_SLICES; the reader sums them) — one add per ray on 8 addresses cost 5 ms per view.
 #define RM_DEATH_SLICES 64u
-struct RmDeaths { int32_t *hist; uint32_t base, len; };
+struct RmDeaths { int32_t *hist; uint32_t base, len; int sample_major; };      // (sample_major: the layout of the sample arrays rides along)
 __device__ __forceinline__ void rm_record_deaths(const RmDeaths &dh, bool died, uint32_t at, uint32_t n_step, uint32_t n) {
     if (!dh.hist) return;
     if (__ballot(died) == 0ull) return;
@@ -895,7 +916,9 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
     bool survives = false, died = false;
     uint32_t died_at = 0;
     if (index >= 0) {                  // beyond the list or already marked dead (stays dead, nothing to accumulate)
-    const float *s = sigmas + (uint64_t)n * n_step, *c = rgbs + (uint64_t)n * n_step * 3, *dl = deltas + (uint64_t)n * n_step * 2;
+    // ray-major [n_alive][n_step] (the reference's layout) or sample-major [n_step][n_alive] (dh.sample_major: the native render step)
+    const uint64_t first = dh.sample_major ? (uint64_t)n : (uint64_t)n * n_step, hop = dh.sample_major ? (uint64_t)n_alive : 1ull;
+    const float *s = sigmas + first, *c = rgbs + first * 3, *dl = deltas + first * 2;
     float t = rays_t[index];
     float weight_sum = weights_sum[index], d = depth[index];
     float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
@@ -910,7 +933,7 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
         d = fmaf(weight, t, d);
         r = fmaf(weight, c[0], r); g = fmaf(weight, c[1], g); b = fmaf(weight, c[2], b);
         if (T < T_thresh) break;
-        s++; c += 3; dl += 2; step++;
+        s += hop; c += 3 * hop; dl += 2 * hop; step++;
     }
     if (step < n_step) { rays_alive[n] = -1; died = true; died_at = step; } else { rays_t[index] = t; survives = true; }
     weights_sum[index] = weight_sum; depth[index] = d;
@@ -939,6 +962,16 @@ __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, flo
     uint32_t died_at = 0;
     if (index >= 0) {
         float sg[NS], cl[3 * NS], dl[2 * NS];
+        if (dh.sample_major) {             // [NS][n_alive]: consecutive lanes read consecutive rays of one slot
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const uint64_t m = (uint64_t)i * n_alive + n;
+                sg[i] = sigmas[m];
+                cl[3 * i] = rgbs[m * 3]; cl[3 * i + 1] = rgbs[m * 3 + 1]; cl[3 * i + 2] = rgbs[m * 3 + 2];
+                const float2 v = *reinterpret_cast<const float2 *>(deltas + m * 2);
+                dl[2 * i] = v.x; dl[2 * i + 1] = v.y;
+            }
+        } else {
         const float4 *ps = reinterpret_cast<const float4 *>(sigmas + (uint64_t)n * NS);
         const float4 *pc = reinterpret_cast<const float4 *>(rgbs + (uint64_t)n * NS * 3);
         const float4 *pd = reinterpret_cast<const float4 *>(deltas + (uint64_t)n * NS * 2);
@@ -948,6 +981,7 @@ __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, flo
         for (int i = 0; i < 3 * NS / 4; i++) { const float4 v = pc[i]; cl[4 * i] = v.x; cl[4 * i + 1] = v.y; cl[4 * i + 2] = v.z; cl[4 * i + 3] = v.w; }
 #pragma unroll
         for (int i = 0; i < 2 * NS / 4; i++) { const float4 v = pd[i]; dl[4 * i] = v.x; dl[4 * i + 1] = v.y; dl[4 * i + 2] = v.z; dl[4 * i + 3] = v.w; }
+        }
         float t = rays_t[index];
         float weight_sum = weights_sum[index], d = depth[index];
         float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
@@ -984,7 +1018,7 @@ __global__ void __launch_bounds__(64) k_composite_rays_pre(uint32_t n_alive, flo
 template <bool COUNT>
 static void rm_launch_composite(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t, const float *sigmas, const float *rgbs,
                                 const float *deltas, float *weights_sum, float *depth, float *image, int32_t *block_counts, hipStream_t st,
-                                RmDeaths dh = RmDeaths{nullptr, 0u, 1u}) {
+                                RmDeaths dh = RmDeaths{nullptr, 0u, 1u, 0}) {
     const dim3 grid(foc_div_up(n_alive, 64)), block(64);
     const bool aligned = ((reinterpret_cast<uintptr_t>(sigmas) | reinterpret_cast<uintptr_t>(rgbs) | reinterpret_cast<uintptr_t>(deltas)) & 15u) == 0;
     if (aligned && n_step == 4u)
@@ -1213,8 +1247,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 // which kernels foc_march_rays_two_phase takes for a burst of n_step samples of n_alive rays: 0 = the two phases, 1 = 16 lanes per ray (samples
 // staged in LDS), 2 = one ray per lane, 3 = one ray per lane with the wave's samples staged in LDS. Measured on the 800 x 800 occupancy view
 // (tools/time_occ_burst.py; 640 000 rays alive for most of it, bursts of 8): form 3 15.8 ms per view, form 1 17.4, form 2 18.2, form 0 18.8
-// — with ten waves per SIMD the lanes' lookup chains hide each other and what counts is instructions and how the samples reach memory;
-// 16 lanes per ray pay when few rays are left (FOC_MARCH_RAYS_ROW_MAX, as in foc_march_rays).
+// — with ten waves per SIMD the lanes' lookup chains hide each other and what counts is instructions and how the samples reach memory.
 static int rm_burst_form(uint32_t n_step, uint32_t n_alive, bool rederive = false) {
     const char *form_env = getenv("FOC_OCC_MARCH_FORM");
     int forced = -1;
@@ -1222,12 +1255,13 @@ static int rm_burst_form(uint32_t n_step, uint32_t n_alive, bool rederive = fals
     // the forms that generate a ray's lattice 16 points ahead (row, the walkers of the two phases) cannot re-derive t sample by sample
     if (rederive && n_step > 1u) return forced == 2 ? 2 : 3;
     if (forced >= 0) return forced;
-    if (n_step <= 2u) return 0;
-    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");
-    return (long)n_alive <= (row_env ? atol(row_env) : 131072) ? 1 : 3;
+    (void)n_alive;
+    return n_step <= 2u ? 0 : 3;       // (16 lanes per ray for short lists, as foc_march_rays does: 14.7 against 14.0 ms per view — its samples stay ray-major)
 }
 /* 1 when foc_march_rays_two_phase writes every slot of every list entry for this burst length (the caller need not zero them) */
 int foc_march_rays_two_phase_fills(uint32_t n_step, int flags) { const int f = rm_burst_form(n_step, 1u << 30, (flags & 2) != 0); return (f == 1 || f == 3) ? 1 : 0; }
+/* 1 when foc_march_rays_two_phase honours flag bit 2 (sample-major output) for this call: the staged one-ray-per-lane kernel does */
+int foc_march_rays_two_phase_sample_major(uint32_t n_alive, uint32_t n_step, int flags) { return rm_burst_form(n_step, n_alive, (flags & 2) != 0) == 3 ? 1 : 0; }
 
 /* R9 in two phases (k_march_rays_first + k_march_walkers): `scratch` = int32[n_alive + 4], its first word the worklist length, which the
  * caller has zeroed on this stream. Same arguments and results as foc_march_rays. */
@@ -1259,7 +1293,7 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
     }
     if (form == 3) {
         hipLaunchKernelGGL(k_march_rays_staged, dim3(foc_div_up(n_alive, 64)), dim3(64), 64u * (5u * n_step + 4u) * sizeof(float), st, n_alive, n_step, rays_alive, rays_t,
-                           rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
+                           rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises, (normalised & 4) ? 1 : 0);
         FOC_CHECK_LAUNCH("march_rays(staged lane form)");
         return FOC_OK;
     }
@@ -1300,14 +1334,14 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
 int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                           float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, int32_t *deaths, uint32_t deaths_base, uint32_t deaths_len,
-                          void *stream) {
+                          int sample_major, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     FOC_REQUIRE(n_alive > 0 && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && out && n_out && block_counts, FOC_E_INVALID,
                 "composite_compact: null pointer");
     FOC_REQUIRE(!deaths || deaths_len >= 1, FOC_E_INVALID, "composite_compact: empty death histogram");
     hipStream_t st = (hipStream_t)stream;
     rm_launch_composite<true>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, block_counts, st,
-                              RmDeaths{deaths, deaths_base, deaths ? deaths_len : 1u});
+                              RmDeaths{deaths, deaths_base, deaths ? deaths_len : 1u, sample_major ? 1 : 0});
     FOC_CHECK_LAUNCH("composite_compact(composite)");
     const uint32_t nb = foc_div_up(n_alive, 1024);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, n_out);

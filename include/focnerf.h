@@ -146,9 +146,12 @@ int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
  *   the march continues from last_t + (t - last_t) instead of t — the value composite_rays reconstructs from deltas[:,1] and stores in
  *   rays_t for the NEXT call (raymarching.cu:871, 899). The two differ by an ulp when t - last_t is not exact in fp32 (a skip over empty
  *   space that more than doubles t), so the reference's samples depend on where its bursts end; with bit 1 a burst of k samples marches
- *   exactly what k consecutive calls with n_step = 1 would, whatever k. Bursts of more than two samples (most rays meet an
- *   empty cell inside them and would be marched twice) take ONE launch instead — one ray per lane (16 lanes per ray when at most
- *   FOC_MARCH_RAYS_ROW_MAX rays are listed) — of a kernel that collects the samples in LDS and writes ALL n_step slots of every list entry
+ *   exactly what k consecutive calls with n_step = 1 would, whatever k. Bit 2 ("sample-major"): xyzs / dirs / deltas are written as
+ *   [n_step][n_alive] arrays instead of [n_alive][n_step] — honoured by the staged one-ray-per-lane kernel only
+ *   (foc_march_rays_two_phase_sample_major(n_alive, n_step, flags) != 0 says whether this call would); foc_composite_compact reads that
+ *   layout with sample_major != 0. The 64 rows an encoder / network wave works on are then 64 neighbouring rays at one burst slot. Bursts of more than two samples (most rays meet an
+ *   empty cell inside them and would be marched twice) take ONE launch instead — one ray per lane — of a kernel that collects the
+ *   samples in LDS and writes ALL n_step slots of every list entry
  *   as runs of consecutive floats (zeros where the ray ended early or the entry is -1): foc_march_rays_two_phase_fills(n_step) != 0 says
  *   so, and the caller may then skip zeroing xyzs / dirs / deltas. FOC_OCC_MARCH_FORM = two | row | lane | staged overrides the choice
  *   (A/B runs, tests; "lane" = foc_march_rays' serial kernel, which needs the zeros).
@@ -163,10 +166,11 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                              const float *noises, int32_t *scratch, int normalised, void *stream);
 int foc_march_rays_two_phase_fills(uint32_t n_step, int flags);
+int foc_march_rays_two_phase_sample_major(uint32_t n_alive, uint32_t n_step, int flags);
 int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                           float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, int32_t *deaths, uint32_t deaths_base,
-                          uint32_t deaths_len, void *stream);
+                          uint32_t deaths_len, int sample_major, void *stream);
 uint64_t foc_occ_render_step_scratch_bytes(uint32_t n_rays);
 int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive, int32_t *rays_alive_out, int32_t *count,
                         float *rays_t, const float *rays_o, const float *rays_d, float bound, float dt_gamma, uint32_t max_steps,

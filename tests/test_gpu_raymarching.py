@@ -482,7 +482,7 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
 
 
 @pytest.mark.parametrize("n_step", [1, 4, 8, 16])
-@pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "staged"), ("0", ""), ("1000000000", "")])
+@pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "staged"), ("0", "")])
 def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, form, monkeypatch):
     """foc_march_rays_two_phase == foc_march_rays bit for bit in each of its forms — the two phases (first visits per lane, walkers compacted
     and marched again, 16 lanes per ray / one ray per lane), the 16-lanes-per-ray kernel that stages a ray's samples in LDS and writes every
@@ -533,10 +533,31 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     n_out = torch.zeros(1, dtype=torch.int32, device="cuda")
     blocks = torch.zeros(N // 1024 + 2, dtype=torch.int32, device="cuda")
     check(lib.foc_composite_compact(N, n_step, 1e-4, ptr(b_list), ptr(b_t), ptr(sig), ptr(rgb), ptr(l0), ptr(b_ws), ptr(b_dp), ptr(b_im), ptr(out), ptr(n_out),
-                                    ptr(blocks), None, 0, 1, st), "composite_compact")
+                                    ptr(blocks), None, 0, 1, 0, st), "composite_compact")
     assert int(n_out) == int(count) and torch.equal(out, kept) and torch.equal(b_list, a_list)
     for a, b in ((a_t, b_t), (a_ws, b_ws), (a_dp, b_dp), (a_im, b_im)):
         assert torch.equal(a, b)
+    # sample-major arrays ([n_step][N] instead of [N][n_step]): the staged kernel writes them (flag bit 2), foc_composite_compact reads them
+    if lib.foc_march_rays_two_phase_sample_major(N, n_step, 4):
+        xs, ds_, ls = (torch.full((M, k), float("nan"), device="cuda") for k in (3, 3, 2))
+        scratch = torch.zeros(N + 4, dtype=torch.int32, device="cuda")
+        check(lib.foc_march_rays_two_phase(N, n_step, ptr(lst), ptr(t_now), ptr(o), ptr(d), float(s["bound"]), 1 / 128, 1024, C, H, ptr(bits), ptr(nears), ptr(fars),
+                                           ptr(xs), ptr(ds_), ptr(ls), ptr(noises), ptr(scratch), 4, st), "two_phase (sample-major)")
+        for got, want in ((xs, x0), (ds_, d0), (ls, l0)):
+            assert torch.equal(got.view(n_step, N, -1).transpose(0, 1), want[:M].view(N, n_step, -1))
+        sig_sm = sig[:M].view(N, n_step).t().contiguous()
+        rgb_sm = rgb[:M].view(N, n_step, 3).transpose(0, 1).contiguous()
+        c_list, c_t = lst.clone(), t_now.clone()
+        c_ws, c_dp, c_im = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, 3, device="cuda")
+        out.fill_(-1); n_out.zero_(); blocks.zero_()
+        deaths = torch.zeros(n_step + 1, 64, dtype=torch.int32, device="cuda")
+        check(lib.foc_composite_compact(N, n_step, 1e-4, ptr(c_list), ptr(c_t), ptr(sig_sm), ptr(rgb_sm), ptr(ls), ptr(c_ws), ptr(c_dp), ptr(c_im), ptr(out), ptr(n_out),
+                                        ptr(blocks), ptr(deaths), 0, n_step + 1, 1, st), "composite_compact (sample-major)")
+        assert int(n_out) == int(count) and torch.equal(out, kept) and torch.equal(c_list, a_list)
+        for a, b in ((a_t, c_t), (a_ws, c_ws), (a_dp, c_dp), (a_im, c_im)):
+            assert torch.equal(a, b)
+        # the death histogram: every listed ray that did not survive, at the slot where it ended
+        assert int(deaths.sum()) == int((lst >= 0).sum()) - int(count)
 
 
 @pytest.mark.parametrize("form", ["staged", "lane", ""])
