@@ -10,6 +10,8 @@ constant (csrc/ffmlp.hip, MlpHead). Checked here against
   (c) network.NeRFNetwork when the object feature is zero.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -412,3 +414,68 @@ def test_foc_fused_step_at_baseline_size_rows_are_those_of_the_materialised_path
     for x, y, z, name in ((a[0], b[0], c[0], "dW0[:, 31:47]"), (a[1], b[1], c[1], "object-feature encoder")):
         s = z.abs().max().item()
         assert s > 0 and (x + y - z).abs().max().item() <= 1e-2 * s, name
+
+
+def test_occ_render_step_with_object_feature():
+    """foc_occ_render_step's obj_feat argument (FOC's object-conditioned colour network inside the native occupancy-render iteration): the
+    iteration's sigma / rgb equal the whole-field call with the object feature on the samples the step marched, and the composite is that of
+    composite_rays on them — one iteration on a half-full occupancy grid, ray-major and sample-major sample arrays."""
+    from focnerf_amd import raymarching as rm, synthetic
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    from focnerf_amd.field import field_infer, _half_of, half_cache_scope
+    m = _foc(9).eval()
+    m.color_net.weights.data.mul_(1.5)
+    obj = (torch.randn(16, device="cuda") * 0.8).half()
+    o, d = synthetic.make_view_rays(40, 40, 1, 1, seed=4, device="cuda", radius=2.5)
+    o, d = o.view(-1, 3).contiguous(), d.view(-1, 3).contiguous()
+    n, burst, C, H = o.shape[0], 8, 1, 128
+    gen = torch.Generator().manual_seed(0)
+    grid = (torch.rand(C, H ** 3, generator=gen) < 0.5).float().cuda()
+    bits = rm.packbits(grid, 0.5)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device="cuda")
+    near, far = rm.near_far_from_aabb(o, d, aabb, 0.2)
+    enc, sn, cn = m.encoder, m.sigma_net, m.color_net
+    L = enc.offsets.shape[0] - 1
+    M = n * burst
+    S = float(np.log2(enc.per_level_scale))
+    results = {}
+    for sm in ("1", "0"):
+        os.environ["FOC_OCC_SAMPLE_MAJOR"] = sm
+        try:
+            samples = torch.full((M * 8,), float("nan"), device="cuda")
+            planes = torch.empty(L * M * 2, dtype=torch.float16, device="cuda")
+            sigma, rgb = torch.empty(M, device="cuda"), torch.empty(M * 3, device="cuda")
+            alive, out = torch.arange(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda")
+            count = torch.empty(1, dtype=torch.int32, device="cuda")
+            scratch = torch.empty(lib.foc_occ_render_step_scratch_bytes(n), dtype=torch.uint8, device="cuda")
+            t_now = near.clone()
+            ws, dp, im = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, 3, device="cuda")
+            still = torch.zeros(n, device="cuda")
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16), half_cache_scope():
+                emb, wsn, wcn = _half_of(enc.embeddings), _half_of(sn.weights), _half_of(cn.weights)
+                check(lib.foc_occ_render_step(n, burst, ptr(alive), ptr(out), ptr(count), ptr(t_now), ptr(o), ptr(d), 1.0, 1 / 128, 1024, C, H, ptr(bits), ptr(near),
+                                              ptr(far), ptr(still), ptr(samples), ptr(planes), ptr(sigma), ptr(rgb), ptr(emb), ptr(enc.offsets), None, L, S,
+                                              enc.base_resolution, ptr(wsn), sn.num_layers, ptr(wcn), cn.num_layers, sn.activation, ptr(obj), 1e-4, ptr(ws), ptr(dp),
+                                              ptr(im), ptr(scratch), 0, None, 0, 1, stream_of(o)), "occ_render_step")
+                xn, dirs, dl = samples[: 3 * M].view(M, 3), samples[3 * M: 6 * M].view(M, 3), samples[6 * M:].view(M, 2)
+                assert torch.isfinite(samples).all(), "every slot of every entry is written"
+                real = dl[:, 0] > 0
+                assert 0.2 < real.float().mean() < 1.0
+                want_s, want_c = field_infer(m, xn.contiguous(), dirs.contiguous(), obj_feat=obj)
+            assert torch.equal(sigma[real], want_s[real]) and torch.equal(rgb.view(M, 3)[real], want_c[real])
+            # composite_rays on the step's own samples (ray-major copies of them)
+            if sm == "1":
+                to_rm = lambda a, k: a.view(burst, n, k).transpose(0, 1).reshape(M, k).contiguous()
+            else:
+                to_rm = lambda a, k: a.view(M, k)
+            alive2, t2 = torch.arange(n, dtype=torch.int32, device="cuda"), near.clone()
+            ws2, dp2, im2 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, 3, device="cuda")
+            rm.composite_rays(n, burst, alive2, t2, to_rm(sigma, 1).view(M), to_rm(rgb, 3), to_rm(dl, 2), ws2, dp2, im2, 1e-4)
+            for a, b in ((ws, ws2), (dp, dp2), (im, im2), (t_now, t2)):
+                assert torch.equal(a, b)
+            assert int(count) == int((alive2 >= 0).sum()) and ws.max() > 0.05
+            results[sm] = (ws, dp, im)
+        finally:
+            os.environ.pop("FOC_OCC_SAMPLE_MAJOR", None)
+    for a, b in zip(results["1"], results["0"]):
+        assert torch.equal(a, b)
