@@ -487,6 +487,21 @@ class NeRFRenderer(nn.Module):
             densities, rgbs = torch.empty(B, N, T, device=dev), torch.empty(B, N, T, 3, device=dev)
         import contextlib
         from .field import half_cache_scope
+        # Inference of whole views without per-sample outputs: the rays are walked in 8 x 8 pixel tiles (rayorder.py) and the image rows put
+        # back where the caller's rays were — a ray's result does not depend on its neighbours in a chunk (no jitter: perturb must be off)
+        perms = None
+        per_ray_bg = torch.is_tensor(kwargs.get("bg_color")) and kwargs["bg_color"].numel() > 3
+        if (densities is None and not torch.is_grad_enabled() and not self.training and not kwargs.get("perturb", False) and not per_ray_bg
+                and dev.type == "cuda"):
+            from .rayorder import view_tiling
+            perms = [view_tiling(rays_d[b]) for b in range(B)]
+            if any(p is None for p in perms):
+                perms = None
+        if perms is not None:
+            caller_depth, caller_image = depth, image
+            rays_o = torch.stack([rays_o[b].index_select(0, perms[b]) for b in range(B)]) if B > 1 else rays_o[0].index_select(0, perms[0]).unsqueeze(0)
+            rays_d = torch.stack([rays_d[b].index_select(0, perms[b]) for b in range(B)]) if B > 1 else rays_d[0].index_select(0, perms[0]).unsqueeze(0)
+            depth, image = torch.empty_like(depth), torch.empty_like(image)
         # one fp16 conversion of the table / weight blobs per VIEW instead of per chunk — only where nothing can write the parameters
         # between two chunks (no autograd, hence no optimizer step inside the loop); the copies are dropped when the view is done
         # Chunks are independent of each other while the kernels of one chunk form a chain: under no_grad the chunks alternate between
@@ -519,6 +534,11 @@ class NeRFRenderer(nn.Module):
             finally:
                 for st in sides:                                              # also when a chunk raised: the caller's stream must not run ahead of
                     main.wait_stream(st)                                      # side-stream kernels that still write the view's buffers
+        if perms is not None:
+            for b in range(B):
+                caller_depth[b].index_copy_(0, perms[b], depth[b])
+                caller_image[b].index_copy_(0, perms[b], image[b])
+            depth, image = caller_depth, caller_image
         out = {'depth': depth, 'image': image, 'timing': part.get('timing')}
         if densities is not None and 'densities' in part:
             out['densities'], out['rgbs'] = densities, rgbs

@@ -11,6 +11,13 @@ dev = torch.device("cuda", 0)
 m = bench.build_model(1, dev, seed=0).eval()
 poses, intr = bench.make_training_rays(dev, 1, 8, seed=0)
 rays = [synthetic.get_rays(poses[v:v + 1], intr, 800, 800) for v in range(8)]
+tile = os.environ.get("TILE")                       # "8x8", "4x16", "16x4": every 64 consecutive rays = one pixel tile (experiment: locality of a 64-ray block)
+if tile:
+    th, tw = (int(v) for v in tile.split("x"))
+    yy, xx = torch.meshgrid(torch.arange(800), torch.arange(800), indexing="ij")
+    key = ((yy // th) * (800 // tw) + (xx // tw)) * (th * tw) + (yy % th) * tw + (xx % tw)
+    perm = torch.argsort(key.reshape(-1)).to(dev)
+    rays = [(o[:, perm].contiguous(), d[:, perm].contiguous()) for o, d in rays]
 ro, rd = rays[0]
 views = int(os.environ.get("VIEWS", "8"))
 kw = dict(staged=True, max_ray_batch=int(os.environ.get("CHUNK", "4096")), num_steps=512, upsample_steps=0, perturb=False, fused=True)
