@@ -401,7 +401,12 @@ def cpu_baseline(budget_s=10.0, one_core_s=4.0):
 
 
 def progress(msg):
-    """Progress marker on stderr (rank 0): the one JSON line comes last, and a long silent run looks hung to whoever is watching."""
+    """Progress marker on stderr (rank 0): the one JSON line comes last, and a long silent run looks hung to whoever is watching.
+    Also where Python's cycle collector runs: it is switched off for the measurements (main(), timeit's convention) and called here, between
+    the legs — a generation-2 pass over this process's heap inside a timed loop is a 50-100 ms pause of the ENQUEUEING thread (measured: the
+    eight timed views of the render leg 42 ms each with the collector off or after three warm-up views, 51-62 with it on and one)."""
+    import gc
+    gc.collect()
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -423,7 +428,8 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True):
+def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True,
+                        ray_order=None):
     """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (4096-ray chunks, packed
     per-sample fields), the chunks are exchanged by ray (all-to-all over xGMI), every rank selects + composites its ray slices for both
     backgrounds, one all-gather per view assembles the images. Timed against the same view with the field evaluation alone.
@@ -435,7 +441,11 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
     nears, fars = model["nears"], model["fars"]
 
     def one_view(ov=overlap):
-        return comb.render_view([fused_fn], n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk, overlap=ov)
+        img, dep = comb.render_view([fused_fn], n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk, overlap=ov)
+        if ray_order is not None:          # the view was walked in pixel tiles (focnerf_amd/rayorder.py): rows back to the caller's ray order, inside the timed region
+            img = torch.empty_like(img).index_copy_(1, ray_order, img)
+            dep = torch.empty_like(dep).index_copy_(0, ray_order, dep)
+        return img, dep
 
     def eval_only():
         buf = torch.empty(chunk, T, 4, dtype=torch.float32, device=device)
@@ -599,6 +609,9 @@ def main():
 
     timer = KernelTimer()
     timer.install()
+    import gc
+    gc.collect()
+    gc.disable()                      # see progress(): collections happen between the legs, not inside a timed loop
 
     fused = not args.no_fused
     # Initialisation, before the W warm-up steps: the first steps create the persistent scratch buffers (2 GB of records), size the
@@ -723,6 +736,7 @@ def main():
                 result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
                                              "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
             # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
+            progress("render leg (fixed-step, 800x800 views)")
             model.eval()
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 # one untimed full view first: the caching allocator sizes its blocks for the view's chunk shapes
@@ -798,6 +812,7 @@ def main():
                 result["foc_network"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
 
             # ---- configs[2]: occupancy-grid path (march_rays_train -> encode -> MLPs -> composite_rays_train -> backward -> Adam)
+            progress("occupancy-grid path (configs[2]): training step, render loop")
             m2 = build_model(2, device, cuda_ray=True, seed=rank).train()
             opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
             sc2 = torch.amp.GradScaler("cuda")
@@ -894,6 +909,12 @@ def main():
             from focnerf_amd.field import half_cache_scope
             from focnerf_amd.fixedstep import render_field4
             vo, vd = rays_o[0].contiguous(), rays_d[0].contiguous()
+            # the view's rays in 8 x 8 pixel tiles, as the staged render walks them (rayorder.py): every rank permutes the same way, the exchange and
+            # the composite are per ray, the image rows go back to the caller's order at the end of each view
+            from focnerf_amd.rayorder import view_tiling
+            tile_order = view_tiling(vd)
+            if tile_order is not None:
+                vo, vd = vo.index_select(0, tile_order), vd.index_select(0, tile_order)
             vn, vf = rm.near_far_from_aabb(vo, vd, model.aabb_infer, model.min_near)
             # the objects COMBINED.py loads are network_tcnn networks (COMBINED.py:84): one FOC object-conditioned network per rank, each
             # with its own object feature (gather_obj_feats, utils.py:177-187)
@@ -904,7 +925,8 @@ def main():
                 return render_field4(obj_model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=obj_yolo, out=out)
             with torch.no_grad(), half_cache_scope():
                 result["combined_render"] = combined_render_leg(rank, world, device, {"nears": vn, "fars": vf}, args.combined_views, my_object, barrier,
-                                                                max_over_ranks, overlap=not args.combined_no_overlap)
+                                                                max_over_ranks, overlap=not args.combined_no_overlap, ray_order=tile_order)
+            result["combined_render"]["ray_order"] = "8x8 pixel tiles" if tile_order is not None else "as given"
             cr = result["combined_render"]
             # the N-rank half of BASELINE's metric inside `roofline` (the driver's record keeps `roofline` and `config` whole)
             result.setdefault("roofline", {})["combined"] = {

@@ -522,6 +522,8 @@ class NeRFRenderer(nn.Module):
                         if buf is not None:
                             buf.record_stream(st)
             chunk = 0
+            # (gating the encoder launches of the two streams behind each other — so that an encoder only ever runs next to a whole-field kernel,
+            # never next to another encoder — measured 42.6 against 41.6 ms per view: the free interleaving is the better one)
             try:
                 for b in range(B):
                     for lo in range(0, N, max_ray_batch):

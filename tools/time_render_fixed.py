@@ -36,4 +36,11 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         enq.append(t1 - t0); tot.append(t2 - t0)
         del out
 print(f"enqueue min {min(enq):.4f} med {np.median(enq):.4f}  s/view min {min(tot):.4f} mean {np.mean(tot):.4f} max {max(tot):.4f} (views cycle through 8 poses)")
+with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(views):
+        out = m.render(*rays[i % 8], **kw)
+    torch.cuda.synchronize()
+print(f"back to back (no synchronisation between views): s/view {(time.perf_counter() - t0) / views:.4f}")
 print("s/view", float(np.mean(tot)))
