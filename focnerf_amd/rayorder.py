@@ -62,5 +62,10 @@ def view_tiling(rays_d):
     w = detect_image_width(rays_d)
     if w is None:
         return None
-    th, tw = (int(v) for v in shape.split("x"))
+    try:
+        th, tw = (int(v) for v in shape.lower().split("x"))
+    except ValueError:
+        raise ValueError(f"FOC_RAY_TILES must be 0 or <rows>x<columns> (got {shape!r})") from None
+    if th < 1 or tw < 1:
+        return None
     return tile_permutation(rays_d.shape[0], w, rays_d.device, th, tw)
