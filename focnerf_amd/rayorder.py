@@ -57,7 +57,7 @@ def tile_permutation(n, w, device, th=8, tw=8):
 def view_tiling(rays_d):
     """Permutation (int64 [N]) that lists the rays of a row-major view in 8 x 8 pixel tiles, or None (not a pixel grid; FOC_RAY_TILES=0)."""
     shape = os.environ.get("FOC_RAY_TILES", "8x8")
-    if shape in ("0", "", "off") or not rays_d.is_cuda:
+    if shape in ("0", "", "off") or not rays_d.is_cuda or torch.cuda.is_current_stream_capturing():      # (the recognition reads back from the device)
         return None
     w = detect_image_width(rays_d)
     if w is None:
