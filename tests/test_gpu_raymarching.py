@@ -609,3 +609,45 @@ def test_rederived_burst_equals_single_sample_calls(rm, form, max_steps, monkeyp
     # two forms agree (they do here) — the bit turns "practically always" into "always"
     same = torch.equal(outs[0][1], want_l)
     print("burst without re-derivation equals the single-sample calls:", same)
+
+
+@pytest.mark.parametrize("n_step", [1, 3, 4, 8, 16])
+def test_composite_rays_every_burst_length(rm, n_step):
+    """R10 on synthetic bursts: the register-resident kernels (bursts of 4, 8, 16 on 16-byte aligned arrays) and the pointer-walking one (any
+    other burst, or unaligned arrays) give the same bits, and both are the oracle's result up to __expf against expf (1e-5; a ray whose
+    transmittance sits on the threshold may end one sample apart) — rays that end on an empty slot, rays that end on the transmittance test
+    (opaque samples), rays that survive, accumulators that start non-zero."""
+    g = torch.Generator().manual_seed(100 + n_step)
+    N = 3001
+    M = N * n_step
+    sig = (torch.rand(M, generator=g) * 3.0)
+    sig[torch.rand(M, generator=g) < 0.02] = 400.0                                  # opaque: the transmittance test fires
+    rgb = torch.rand(M, 3, generator=g)
+    dl = torch.rand(M, 2, generator=g) * 0.05 + 0.005
+    filled = torch.randint(0, n_step + 1, (N,), generator=g)
+    filled[torch.rand(N, generator=g) < 0.5] = n_step                                # half of the rays fill their burst
+    dl.view(N, n_step, 2)[torch.arange(n_step)[None, :] >= filled[:, None]] = 0.0
+    alive = torch.randperm(N, generator=g).to(torch.int32)            # (no dead entries: the reference kernel, and so the oracle, does not expect any)
+    rt = torch.rand(N, generator=g) + 0.2
+    ws0, dp0, im0 = torch.rand(N, generator=g) * 0.3, torch.rand(N, generator=g), torch.rand(N, 3, generator=g) * 0.3
+    want = oracle.composite_rays(N, n_step, 1e-4, alive.numpy(), rt.numpy(), sig.numpy(), rgb.numpy(), dl.numpy(), ws0.numpy(), dp0.numpy(), im0.numpy())
+
+    def dev(t, pad):                       # pad = 1: the array starts 4 bytes into a 16-byte aligned allocation (the pointer-walking kernel)
+        buf = torch.empty(t.numel() + 4, dtype=t.dtype, device="cuda")
+        view = buf[pad: pad + t.numel()].view(t.shape)
+        view.copy_(t)
+        return view
+    got = {}
+    for pad in (0, 1):
+        ga, gt = alive.cuda(), rt.cuda()
+        gws, gdp, gim = ws0.cuda(), dp0.cuda(), im0.cuda()
+        rm.composite_rays(N, n_step, ga, gt, dev(sig, pad), dev(rgb, pad), dev(dl, 2 * pad), gws, gdp, gim, 1e-4)
+        got[pad] = (ga, gt, gws, gdp, gim)
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+    ga, gt, gws, gdp, gim = got[0]
+    same = (to_np(ga) >= 0) == (want[0] >= 0)
+    assert same.mean() > 1 - 2e-3, "ray termination decisions diverge"
+    for g_, w_, name in ((gt, want[1], "rays_t"), (gws, want[2], "weights_sum"), (gdp, want[3], "depth"), (gim, want[4], "image")):
+        np.testing.assert_allclose(to_np(g_)[same], w_[same], atol=1e-5, rtol=1e-5, err_msg=name)
+    assert (want[0] >= 0).sum() > 0 and (want[0] < 0).sum() > N // 10
