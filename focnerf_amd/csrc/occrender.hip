@@ -5,15 +5,19 @@
 // each, and ~20 Python-level operations per iteration cost more than that to enqueue. foc_occ_render_step enqueues the whole iteration —
 // nine launches — from C, on buffers the caller allocated once per view:
 //
-//   prepare   zero the iteration's sample slots (the reference's torch.zeros, raymarching.py:334-336), fill the output list with -1,
-//             reset the walkers' worklist and the compaction's block counts
-//   march     foc_march_rays_two_phase (raymarching.hip): first visits per lane, walkers densely packed; the positions leave already
-//             normalised, x -> (x + bound) * (1 / (2 bound))  (gridencoder/grid.py:149 as torch evaluates it: division by a scalar =
-//             multiplication by its reciprocal) — nobody but the encoder reads them here
+//   prepare   fill the output list with -1, reset the walkers' worklist and the compaction's block counts; zero the iteration's sample slots
+//             (the reference's torch.zeros, raymarching.py:334-336) where the march kernel of this burst length does not write them all itself
+//   march     foc_march_rays_two_phase (raymarching.hip). One sample per ray: first visits per lane, then the walkers densely packed. A burst
+//             of several samples (focnerf_amd/renderer.py marches 8 per ray and iteration): one ray per lane, the wave's samples staged in
+//             LDS and written as whole runs, SAMPLE-MAJOR ([n_step][n_alive]: the 64 rows of an encoder / network wave are 64 neighbouring
+//             rays at one burst slot), t re-derived after every sample so that the samples are those of one-sample iterations. The
+//             positions leave already normalised, x -> (x + bound) * (1 / (2 bound))  (gridencoder/grid.py:149 as torch evaluates it:
+//             division by a scalar = multiplication by its reciprocal) — nobody but the encoder reads them here
 //   encode    foc_grid_encode_forward ([L, M, 2] planes)
 //   field     foc_nerf_field_inference (sigma net -> head -> colour net, per-sample directions)
-//   composite foc_composite_compact: composite_rays in place (weights_sum, depth, image, rays_t; finished rays marked -1), its waves counting
-//             their survivors, then scan + ordered scatter into the output list, whose tail stays -1 (march / composite skip such entries)
+//   composite foc_composite_compact: composite_rays in place (weights_sum, depth, image, rays_t; finished rays marked -1; a burst's samples
+//             loaded at once), its waves counting their survivors and recording where rays died, then scan + ordered scatter into the output
+//             list, whose tail stays -1 (march / composite skip such entries)
 //
 // The live count stays on the device (`count`, one int); the caller reads it late (focnerf_amd/renderer.py) and passes an upper bound.
 #include "common.h"

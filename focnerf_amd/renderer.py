@@ -295,9 +295,10 @@ class NeRFRenderer(nn.Module):
                 and self.encoder.interp_id == 0 and os.environ.get("FOC_RENDER_NATIVE", "1") != "0")
 
     def _native_inference_loop(self, o, d, near, far, alive, t_now, opacity, depth, image, perturb, dt_gamma, max_steps, T_thresh):
-        """The loop of legacy/nerf/renderer.py:323-372 with every iteration ONE call into the library (csrc/occrender.hip: march in two
-        phases, encode, whole-field kernel, composite, compaction) on buffers allocated once per view; the live count is read
-        `FOC_RENDER_COUNT_LAG` iterations late, as in the Python form of the loop. Same samples, same per-ray accumulation order."""
+        """The loop of legacy/nerf/renderer.py:323-372 with every iteration ONE call into the library (csrc/occrender.hip: march, encode,
+        whole-field kernel, composite, compaction) on buffers allocated once per view; bursts of FOC_RENDER_BURST samples per ray, the live
+        count read `FOC_RENDER_COUNT_LAG` iterations late, the reference's stopping point reproduced. Same samples, same per-ray
+        accumulation order, same image and depth bit for bit."""
         import numpy as np
         from ._lib import lib, ptr, stream_of, check
         from .field import _half_of, half_cache_scope
