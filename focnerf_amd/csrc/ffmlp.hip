@@ -36,6 +36,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define MLP_BLOCK 256
 #define MLP_WAVES 4
+// k_mlp_bwd_fused hands its weight-gradient tiles over in per-workgroup slots: [stage][wave][16 registers][64 lanes] fp32
+#define MLP_DW_SLOT_STAGE 4096u        // floats per stage and slot (4 wave tiles of 32 x 32)
+#define MLP_DW_MAX_SLOTS 1024u         // cap on the workgroups of a launch (2 per CU)
 #ifndef FOC_MLP_SETPRIO
 #define FOC_MLP_SETPRIO 1              // issue priority of the MFMA sections of k_mlp_bwd_fused (0 = none: A/B builds, tools/build_variant.sh)
 #endif
@@ -730,7 +733,6 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     const int c = lane & 31, h = lane >> 5;
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
-    const uint64_t first = (uint64_t)HIDDEN * ld0, lsz = (uint64_t)HIDDEN * HIDDEN;
     _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
 
     f16v dwacc[NL + 1];
@@ -1129,25 +1131,61 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             foc_lds_barrier();     // every wave is done reading sD / sA of this stage
         }
     }
-    // ---- flush the weight-gradient tiles
+    // ---- flush the weight-gradient tiles: every workgroup writes ITS partial tiles to a slot of its own with plain coalesced stores
+    // (slot layout [stage][wave][reg][lane]: a wave instruction stores 256 contiguous bytes); k_mlp_dw_reduce adds the slots up in a
+    // fixed order. As fp32 atomics into ONE blob-shaped workspace the flush was 512 workgroups x 7-11 K adds on the same 28-45 KB:
+    // 35-50 us of serialised same-address atomics at the end of every launch whatever the batch (the whole kernel takes 67 / 89 us on
+    // the 0.5 M-sample batches of the occupancy sampler), and sums that depended on arrival order.
+    float *slot = ws + (uint64_t)blockIdx.x * ((NL + 1) * MLP_DW_SLOT_STAGE);
 #pragma unroll
     for (int s = 0; s <= NL; s++) {
         const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN;
         const uint32_t IN = s < NL ? (uint32_t)HIDDEN : in_dim;
-        const uint32_t fl = NL - s;                                               // forward layer whose matrix this is (s = 0: output matrix)
-        const uint64_t ws_off = s == 0 ? first + (uint64_t)(NL - 1) * lsz : (fl == 0 ? 0 : first + (uint64_t)(fl - 1) * lsz);
-        const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi;
-        const uint32_t ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+        const uint32_t ntile = ((OUT + 31) / 32) * ((IN + 31) / 32), ksplit = (ntile * 2 <= 4) ? 2u : 1u;
         if (wave < ntile * ksplit) {
-            const uint32_t tile = wave % ntile;
-            const uint32_t mt = tile / NTi, nt = tile % NTi;
-            const uint32_t i = 32 * nt + (lane & 31);
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const uint32_t o = 32 * mt + acc_row(reg, h);
-                if (o < OUT && i < IN) (void)__hip_atomic_fetch_add(ws + ws_off + (uint64_t)o * (s == NL ? ld0 : IN) + i, dwacc[s][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int reg = 0; reg < 16; reg++) slot[(s * 4 + wave) * 1024 + reg * 64 + lane] = dwacc[s][reg];
         }
+    }
+}
+
+// Sum of the per-workgroup weight-gradient slots of k_mlp_bwd_fused -> the gradient blob (fp16, `gw`) or, for the object-conditioned
+// colour head, the fp32 blob image k_mlp_dw_finalize_obj expands (`wsb`). One workgroup per 64 consecutive slot positions (same stage,
+// wave tile and register: 256 contiguous bytes in every slot); its 16 waves split the slots (wave k takes slots k, k + 16, ...), the
+// partial sums meet in LDS and are added in wave order: the result does not depend on timing (the atomic flush's did).
+template <int HIDDEN>
+__global__ void __launch_bounds__(1024) k_mlp_dw_reduce(const float *__restrict__ slots, uint32_t n_slots, uint32_t NL, uint32_t in_dim, uint32_t ld0,
+                                                        _Float16 *__restrict__ gw, float *__restrict__ wsb) {
+    __shared__ float part[16][64];
+    const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x / 64, w = (blockIdx.x / 16) % 4, reg = blockIdx.x % 16;       // stage, wave tile, accumulator register
+    const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN, IN = s < NL ? (uint32_t)HIDDEN : in_dim;
+    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+    if (w >= ntile) return;                               // the second batch half of a tile (w >= ntile) is added by the tile's workgroup
+    const uint32_t mt = w / NTi, nt = w % NTi, h = lane >> 5;
+    const uint32_t o = 32 * mt + (uint32_t)acc_row((int)reg, (int)h), i = 32 * nt + (lane & 31);
+    if (!(o < OUT) && !(32 * mt + (uint32_t)acc_row((int)reg, 1 - (int)h) < OUT)) return;      // rows past OUT in both lane halves (16-wide output stage)
+    const uint64_t stride = (uint64_t)(NL + 1) * MLP_DW_SLOT_STAGE;
+    const float *p = slots + (uint64_t)(s * 4 + w) * 1024 + reg * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (uint32_t k = 0; k < ksplit; k++) {
+        const float *q = p + (uint64_t)k * ntile * 1024;
+        uint32_t g = slice;
+        for (; g + 48 < n_slots; g += 64) {
+            a0 += q[(uint64_t)g * stride]; a1 += q[(uint64_t)(g + 16) * stride]; a2 += q[(uint64_t)(g + 32) * stride]; a3 += q[(uint64_t)(g + 48) * stride];
+        }
+        for (; g < n_slots; g += 16) a0 += q[(uint64_t)g * stride];
+    }
+    part[slice][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (slice == 0 && o < OUT && i < IN) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v += part[k][lane];
+        const uint64_t first = (uint64_t)HIDDEN * ld0, lsz = (uint64_t)HIDDEN * HIDDEN;
+        const uint32_t fl = NL - s;                       // forward layer whose matrix this is (s = 0: output matrix)
+        const uint64_t off = (s == 0 ? first + (uint64_t)(NL - 1) * lsz : (fl == 0 ? 0 : first + (uint64_t)(fl - 1) * lsz)) + (uint64_t)o * (s == NL ? ld0 : IN) + i;
+        if (wsb) wsb[off] = v; else gw[off] = (_Float16)v;
     }
 }
 
@@ -1420,6 +1458,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_nerf_infer(const _Float16 *__r
 // Per-device caches (the entry points make the stream's device current, common.h FocDeviceGuard): CU count and, per kernel, the number
 // of workgroups one CU holds.
 #define MLP_MAX_DEVICES 16
+// floats of the fp32 blob image at the head of the backward workspace (rounded up to 256 bytes: the slots behind it stay aligned)
+static inline uint64_t mlp_dw_blob_floats(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    const uint64_t n = (uint64_t)hidden_dim * (input_dim + (uint64_t)hidden_dim * (num_layers - 1) + 16);
+    return (n + 63) & ~(uint64_t)63;
+}
 static int mlp_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MLP_MAX_DEVICES) dev = 0;
@@ -1556,18 +1599,23 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const uint32_t n_w = HIDDEN * ((has_obj ? HEAD_OBJ_LD : in_dim) + HIDDEN * (NL - 1) + 16);
-    if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t grid = foc_div_up(B, 4 * RW);
-    const uint32_t cap = mlp_num_cus() * 2;
+    const uint32_t cap = min(mlp_num_cus() * 2, MLP_DW_MAX_SLOTS);
     if (grid > cap) grid = cap;
+    // workspace: [fp32 blob image (object-conditioned head only)] [one slot of (NL + 1) x 4096 floats per workgroup] — no zero fill, no atomics
+    float *slots = ws + mlp_dw_blob_floats(has_obj ? HEAD_OBJ_LD : in_dim, HIDDEN, NL);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, ws, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, slots, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
                        head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
     FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
-    if (has_obj) hipLaunchKernelGGL(k_mlp_dw_finalize_obj, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w, (uint32_t)HIDDEN,
-                                    (const _Float16 *)weights, head->obj, grad_obj);
-    else hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);
-    FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
+    hipLaunchKernelGGL((k_mlp_dw_reduce<HIDDEN>), dim3((NL + 1) * 64), dim3(1024), 0, st, (const float *)slots, grid, (uint32_t)NL, in_dim,
+                       has_obj ? (uint32_t)HEAD_OBJ_LD : in_dim, (_Float16 *)grad_weights, has_obj ? ws : (float *)nullptr);
+    FOC_CHECK_LAUNCH("ffmlp_backward(reduce)");
+    if (has_obj) {
+        hipLaunchKernelGGL(k_mlp_dw_finalize_obj, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w, (uint32_t)HIDDEN,
+                           (const _Float16 *)weights, head->obj, grad_obj);
+        FOC_CHECK_LAUNCH("ffmlp_backward(finalize)");
+    }
     return FOC_OK;
 }
 
@@ -1668,7 +1716,11 @@ int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uin
 }
 
 uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
-    return (uint64_t)hidden_dim * (input_dim + (uint64_t)hidden_dim * (num_layers - 1) + 16) * sizeof(float);
+    // the fp32 image of the weight blob (split-K sums of k_mlp_dw; the object-conditioned head's finalize) and, for the shapes
+    // k_mlp_bwd_fused serves, one slot of partial tiles per workgroup of its launch
+    uint64_t floats = mlp_dw_blob_floats(input_dim, hidden_dim, num_layers);
+    if (hidden_dim <= 64 && input_dim <= 64 && num_layers >= 2 && num_layers <= 4) floats += (uint64_t)MLP_DW_MAX_SLOTS * (num_layers + 1) * MLP_DW_SLOT_STAGE;
+    return floats * sizeof(float);
 }
 
 static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,

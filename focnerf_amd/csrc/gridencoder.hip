@@ -511,7 +511,6 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const T *__restrict__ grad, co
 #define GB_SEG (1u << GB_SEG_SHIFT)            // rows per segment
 #define GB_MAX_SEGS 64u                        // per level: covers 2^19-row levels
 #define GB_CHUNK 32768u                        // records (two corners each) per reduce workgroup
-#define GB_WG 256u
 
 struct GbHeader {                              // lives at the start of the workspace
     uint32_t counts[GE_MAX_LEVELS * GB_MAX_SEGS];
@@ -721,16 +720,17 @@ __global__ void __launch_bounds__(256) k_gbin_scans(GbHeader *__restrict__ hdr, 
 template <uint32_t THREADS>
 __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uint32_t n_wg, const float *__restrict__ inputs, const int32_t *__restrict__ offsets,
                                               GbHeader *__restrict__ hdr, uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, const GeLevels &lv,
-                                              uint32_t gridtype, bool align_corners, uint32_t interp) {
+                                              uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t l_begin, uint32_t l_end) {
+    // levels [l_begin, l_end) of the tile: the slots of different levels are disjoint, so a tile's levels may be counted by different workgroups
     static_assert(GB_PM_TILE % THREADS == 0 && THREADS % 64 == 0, "whole waves, whole tile");
-    const uint32_t nslots = L * GB_MAX_SEGS;
-    for (uint32_t i = threadIdx.x; i < nslots; i += THREADS) hist[i] = 0;
+    const uint32_t slot_lo = l_begin * GB_MAX_SEGS, slot_hi = l_end * GB_MAX_SEGS;
+    for (uint32_t i = slot_lo + threadIdx.x; i < slot_hi; i += THREADS) hist[i] = 0;
     __syncthreads();
     for (uint32_t it = 0; it < GB_PM_TILE / THREADS; it++) {
         const uint32_t b = tile * GB_PM_TILE + it * THREADS + threadIdx.x;
         float x[3] = {0.f, 0.f, 0.f};
         const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
-        for (uint32_t level = 0; level < L; level++) {
+        for (uint32_t level = l_begin; level < l_end; level++) {
             const uint32_t resolution = lv.resolution[level];
             uint32_t pg[3]; float pf[3];
             gb_cell<3>(x, lv.scale[level], align_corners, interp, pg, pf);
@@ -758,7 +758,7 @@ __device__ __forceinline__ void gb_count_tile(uint32_t *hist, uint32_t tile, uin
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nslots; i += THREADS) {
+    for (uint32_t i = slot_lo + threadIdx.x; i < slot_hi; i += THREADS) {
         const uint32_t hcount = hist[i];
         if (hcount) (void)__hip_atomic_fetch_add(&hdr->counts[i], hcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wg_hist[(uint64_t)i * n_wg + tile] = hcount;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(GB_PMS_WG) k_gbin_count_pt(const float *__rest
                                                              uint32_t *__restrict__ wg_hist, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
                                                              bool align_corners, uint32_t interp) {
     __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
-    gb_count_tile<GB_PMS_WG>(hist, blockIdx.x, gridDim.x, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp);
+    gb_count_tile<GB_PMS_WG>(hist, blockIdx.x, gridDim.x, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp, 0u, L);
 }
 
 // The level-major forward (k_grid_fwd_lbc, plain walk, fp16 C = 2 D = 3, no dy_dx) with the backward's count pass riding along: every
@@ -781,19 +781,23 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_grid_fwd_counted(const float *__restrict__ inputs, const T *__restrict__ grid, const int32_t *__restrict__ offsets,
                                                           T *__restrict__ outputs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype, bool align_corners,
                                                           uint32_t interp, uint32_t chunks, uint32_t pairs, GbHeader *__restrict__ hdr,
-                                                          uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0, uint32_t lc) {
+                                                          uint32_t *__restrict__ wg_hist, uint32_t n_tiles, uint32_t period, uint32_t w0, uint32_t lc, uint32_t csplit) {
     __shared__ uint32_t hist[GE_MAX_LEVELS * GB_MAX_SEGS];
     // the counting workgroups sit among the encoding workgroups of the FINE levels (from block w0 on, one in `period`): those are the
     // request-bound ones; the coarse levels are instruction-bound themselves, and the last level is left alone so that no long-running
-    // counting workgroup starts at the very end of the launch
+    // counting workgroup starts at the very end of the launch. A tile is counted by `csplit` workgroups, L / csplit levels each: one
+    // workgroup walking all 16 levels of its 4 x 256 points is ~20 us of dependent VALU work on one wave per SIMD — longer than the
+    // encoding workgroups behind it in a launch of 0.5 M points, whose end it then sets (forward 100 us, forward + count 120 us).
+    const uint32_t n_count = n_tiles * csplit;
     uint32_t f = blockIdx.x;                                // index among the encoding workgroups
     if (blockIdx.x >= w0) {
         const uint32_t g = blockIdx.x - w0, q = g / period, r = g - q * period;
-        if (r == period - 1u && q < n_tiles) {
-            gb_count_tile<256>(hist, q, n_tiles, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp);
+        if (r == period - 1u && q < n_count) {
+            const uint32_t part = q % csplit;
+            gb_count_tile<256>(hist, q / csplit, n_tiles, inputs, offsets, hdr, wg_hist, B, L, lv, gridtype, align_corners, interp, (part * L) / csplit, ((part + 1u) * L) / csplit);
             return;
         }
-        f = blockIdx.x - min(q, n_tiles);
+        f = blockIdx.x - min(q, n_count);
     }
     uint32_t chunk, l0, l1;
     ge_walk(f, chunks, lc, chunk, l0, l1);
@@ -824,8 +828,17 @@ template <typename T>
 __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_scatter_pms(
     const T *__restrict__ grad, const float *__restrict__ inputs, const int32_t *__restrict__ offsets, const GbHeader *__restrict__ hdr,
     const uint32_t *__restrict__ wg_base, void *__restrict__ recs, uint64_t max_recs, uint32_t B, uint32_t L, GeLevels lv, uint32_t gridtype,
-    bool align_corners, uint32_t interp, bool grad_bl, uint32_t fact_mask, GbSizes sz, uint32_t l_begin, uint32_t l_end) {
-    // [l_begin, l_end): the levels this launch scatters (all of them, or one level group of gb_run's pipelined form)
+    bool align_corners, uint32_t interp, bool grad_bl, uint32_t fact_mask, GbSizes sz, uint32_t n_tiles, uint32_t n_whole, uint32_t split) {
+    // Workgroups 0 .. n_whole-1 take one tile each through all levels. The tiles behind them — the launch's last, partial round of
+    // workgroups (gb_run) — are dealt out `split` workgroups per tile, each walking L / split of the levels: a tile's (level, segment)
+    // record ranges are fixed by the count pass, so the levels of a tile are independent of each other. 517 tiles on a chip that holds
+    // 512 of these workgroups used to be two rounds, the second one five workgroups wide and a full tile long (105 us where 512 tiles take 60).
+    uint32_t tile = blockIdx.x, l_begin = 0u, l_end = L;
+    if (blockIdx.x >= n_whole) {
+        const uint32_t r = blockIdx.x - n_whole, part = r % split;
+        tile = n_whole + r / split;
+        l_begin = (part * L) / split; l_end = ((part + 1u) * L) / split;
+    }
     static_assert(GB_PM_TILE == GB_PMS_WG, "one point per thread");
     // a record carries the two corners along x of one (y, z) corner pair: 4 per point, 5 when one pair straddles a segment boundary
     // (two pairs of a point cannot: their rows differ by less than 8192 and not by a multiple of it on a dense level, and a hashed
@@ -837,8 +850,8 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     __shared__ uint32_t gb[2][GB_MAX_SEGS];                // this workgroup's first global record per segment MINUS its first staging position
     __shared__ uint32_t s_rows[NREC];                      // local row of corner 0 | local row of corner 1 << 13 | segment << 26
     __shared__ uint32_t s_val[2 * VW][NREC];               // corner 0 value words, corner 1 value words
-    const uint32_t n_wg = gridDim.x;
-    const uint32_t b = blockIdx.x * GB_PM_TILE + threadIdx.x;
+    const uint32_t n_wg = n_tiles;
+    const uint32_t b = tile * GB_PM_TILE + threadIdx.x;
     float x[3] = {0.f, 0.f, 0.f};
     const bool inside = b < B && !ge_load_point<3>(inputs, b, x);
     // Gradient of the tile, one level at a time (fp16 -> one dword per point, fp32 -> two), through LDS: WAVE 0 requests the 1024 points'
@@ -852,16 +865,11 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
     constexpr uint32_t GW = sizeof(T) == 2 ? 1 : 2;
     __shared__ uint32_t s_grad[2][GW][GB_PM_TILE];
     auto fetch_grad = [&](uint32_t level) {                 // wave 0 only
-#ifdef FOC_TIMING_NO_GRAD_PLANES
-        // TIMING BUILD (tools/ab_no_grad_planes.sh; results wrong): the scatter reads no gradient planes — the upper bound of what feeding it
-        // from the sigma network's backward (no [L,B,C] planes in memory) could gain, with the fusion itself taken as free
-        return;
-#endif
         if (level < l_end) {
             const uint32_t *gbase = reinterpret_cast<const uint32_t *>(grad);
 #pragma unroll 4
             for (uint32_t k = 0; k < GB_PM_TILE / 64u; k++) {
-                const uint32_t pt = blockIdx.x * GB_PM_TILE + k * 64u + threadIdx.x;
+                const uint32_t pt = tile * GB_PM_TILE + k * 64u + threadIdx.x;
                 const uint32_t pq = pt < B ? pt : 0u;
                 const uint32_t *src = grad_bl ? gbase + ((uint64_t)pq * L + level) * GW : gbase + ((uint64_t)level * B + pq) * GW;
                 // as inline asm: with the builtin, hipcc 7.2 puts `s_waitcnt vmcnt(0)` in front of EVERY later LDS access of every wave (it cannot
@@ -883,12 +891,12 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         if (threadIdx.x < GB_MAX_SEGS && level < l_end) {
             const uint32_t slot = level * GB_MAX_SEGS + threadIdx.x;
             const uint32_t sb = hdr->base[slot];           // wg_base holds the prefix inside the slot
-            const uint32_t wi = slot * n_wg + blockIdx.x;      // < 2^26 (gb_check: B * 8 * L < 2^32); a 32-bit offset from the scalar base keeps one register live
+            const uint32_t wi = slot * n_wg + tile;      // < 2^26 (gb_check: B * 8 * L < 2^32); a 32-bit offset from the scalar base keeps one register live
             // loaded values only, no arithmetic: the sums are taken where the next level consumes them, so wave 0 does not wait for these
             // loads in front of the barrier the other fifteen waves are parked at
             nsb = sb;
             nw0 = wg_base[wi];
-            nw1 = *(blockIdx.x + 1 < n_wg ? &wg_base[wi + 1u] : &hdr->counts[slot]);
+            nw1 = *(tile + 1 < n_wg ? &wg_base[wi + 1u] : &hdr->counts[slot]);
         }
     };
     // Wave 0 prepares the segment tables of level l + 1 (cur / pre / gb of the other parity) right AFTER the first barrier of level l,
@@ -924,9 +932,6 @@ __global__ void __launch_bounds__(GB_PMS_WG, (sizeof(T) == 2 ? 8 : 4)) k_gbin_sc
         } else {
             g[0] = __uint_as_float(s_grad[pb][0][threadIdx.x]); g[1] = __uint_as_float(s_grad[pb][GW - 1][threadIdx.x]);
         }
-#ifdef FOC_TIMING_NO_GRAD_PLANES
-        g[0] = 0.25f * (float)((threadIdx.x & 7u) + 1u); g[1] = -0.125f;     // finite stand-ins (the LDS words were never loaded)
-#endif
         if (!inside) { g[0] = 0.0f; g[1] = 0.0f; }
         const bool fact = sizeof(T) == 2 && ((fact_mask >> level) & 1u) != 0u;      // kernel-uniform per level (gb_fact_mask)
         if (fact) {
@@ -1049,9 +1054,7 @@ __device__ __forceinline__ unsigned long long gb_half_to_fixed(uint32_t h) {
 #define GB_RTHREADS 1024u
 template <typename T>
 __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__restrict__ hdr, const void *__restrict__ recs, uint64_t max_recs,
-                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L, uint32_t fact_mask,
-                                                             uint32_t l_begin, uint32_t l_end) {
-    // [l_begin, l_end): the levels whose chunks this launch reduces (all of them, or one level group of gb_run's pipelined form)
+                                                             const int32_t *__restrict__ offsets, T *__restrict__ grad_grid, uint32_t L, uint32_t fact_mask) {
     // 128 KiB (fp32 tables: f64 sums; fp16 tables: the same bytes as 2^24-scaled int64), one PLANE per channel: with the two channels
     // of a row side by side a wave instruction (one channel of 64 random rows) could only ever touch every other pair of banks —
     // half of the LDS's banks idle, twice the conflict cycles; planes spread a channel's 64 addends over all 64 banks
@@ -1059,11 +1062,11 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     unsigned long long *acci = reinterpret_cast<unsigned long long *>(acc);
     __shared__ uint32_t s_bad[GB_SEG / 32];        // fp16 tables: rows that received an inf/NaN addend (an overflowed AMP step) -> NaN out
     __shared__ uint32_t s_slot, s_lo, s_hi;
-    const uint32_t n_lo = l_begin * GB_MAX_SEGS, n = l_end * GB_MAX_SEGS;
+    const uint32_t n = L * GB_MAX_SEGS;
     const uint32_t total_chunks = hdr->chunk_prefix[n];
     // (one workgroup per chunk; a persistent form — one workgroup per CU walking the chunks with the grid's stride — measured 263 vs
     // 256 us, and with larger chunks worse: the dynamic dispatch balances the uneven chunks better than a stride does)
-    const uint32_t chunk_id = blockIdx.x + hdr->chunk_prefix[n_lo];
+    const uint32_t chunk_id = blockIdx.x;
     if (chunk_id >= total_chunks) return;
     {
     // Which (level, segment) slot and which chunk of it this workgroup owns: the slot with chunk_prefix[slot] <= blockIdx.x < chunk_prefix[slot + 1]
@@ -1071,7 +1074,7 @@ __global__ void __launch_bounds__(GB_RTHREADS) k_gbin_reduce(const GbHeader *__r
     // thread 0's eleven dependent loads of a binary search (no measurable difference: the header sits in L2; kept for the shorter chain).
     if (threadIdx.x == 0) { s_slot = 0u; s_lo = 0u; s_hi = 0u; }      // a header that matches nothing (not this launch's) reduces nothing
     __syncthreads();
-    for (uint32_t i = n_lo + threadIdx.x; i < n; i += GB_RTHREADS) {
+    for (uint32_t i = threadIdx.x; i < n; i += GB_RTHREADS) {
         const uint32_t p0 = hdr->chunk_prefix[i], p1 = hdr->chunk_prefix[i + 1];
         const uint32_t cnt = hdr->counts[i];
         const uint64_t b0 = hdr->base[i];
@@ -1577,10 +1580,11 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
     const uint32_t lo = groups >= 4 ? groups / 2 : 0, hi = groups >= 4 ? groups - 1 : groups;   // groups whose workgroups the counting ones are spread over
     // an ODD period: workgroups go to the 8 XCDs round-robin, so an even one puts every counting workgroup on the same 1, 2 or 4 XCDs
     // (period 16, which any B that is not a multiple of 1024 gave for 4 host groups, made this launch 3-4x slower than for B = k * 1024)
-    const uint32_t w0 = lo * chunks, fit = ((hi - lo) * chunks) / n_tiles + 1u, period = (fit & 1u) ? fit : fit - 1u;
+    const uint32_t csplit = L >= 4u ? 4u : 1u, n_count = n_tiles * csplit;
+    const uint32_t w0 = lo * chunks, fit = ((hi - lo) * chunks) / n_count + 1u, period = (fit & 1u) ? fit : fit - 1u;
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
-    hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_tiles), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
-                       interp, chunks, sizeof(T) == 2 ? ge_pairs_mode(emb, nullptr, sizeof(T), 3, 2, gridtype, ac, interp) : 0u, hdr, wg_hist, n_tiles, period, w0, lc);
+    hipLaunchKernelGGL((k_grid_fwd_counted<T>), dim3(fwd_blocks + n_count), dim3(256), 0, st, inputs, (const T *)emb, offsets, (T *)outputs, B, L, lv, gridtype, ac,
+                       interp, chunks, sizeof(T) == 2 ? ge_pairs_mode(emb, nullptr, sizeof(T), 3, 2, gridtype, ac, interp) : 0u, hdr, wg_hist, n_tiles, period, w0, lc, csplit);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted");
     hipLaunchKernelGGL(k_gbin_scans, dim3(L * GB_MAX_SEGS + 1), dim3(256), 0, st, hdr, wg_hist, n_tiles, L);
     FOC_CHECK_LAUNCH("grid_encode_forward_counted(scans)");
@@ -1606,40 +1610,17 @@ static uint32_t gb_fact_mask(uint32_t L, const GeLevels &lv, const int32_t *offs
     return m;
 }
 
-// level groups of the pipelined form: cuts[0] = 0 < ... < cuts[n] = L from FOC_GB_LEVEL_SPLITS (comma-separated first levels of groups 1..n-1)
-static uint32_t gb_level_groups(uint32_t L, uint32_t *cuts) {
-    uint32_t n = 0;
-    cuts[n++] = 0;
-    const char *e = getenv("FOC_GB_LEVEL_SPLITS");         // read per call: tests and A/B runs switch it inside one process
-    if (e) {
-        const char *p = e;
-        while (*p && n < GE_MAX_LEVELS) {
-            char *end = nullptr;
-            const long v = strtol(p, &end, 10);
-            if (end == p) break;
-            if (v > (long)cuts[n - 1] && v < (long)L) cuts[n++] = (uint32_t)v;
-            p = *end ? end + 1 : end;
-        }
-    }
-    cuts[n] = L;
-    return n;
-}
-static int gb_group_streams() { const char *e = getenv("FOC_GB_GROUP_STREAMS"); return e ? atoi(e) : 1; }
-// one side stream + events per device for the two-stream form (created on first use, kept for the life of the process)
-struct GbSide { hipStream_t stream; hipEvent_t ev[GE_MAX_LEVELS]; hipEvent_t join; };
-static GbSide *gb_side(hipStream_t st) {
-    static GbSide sides[16];
-    static bool made[16];
+// workgroups of k_gbin_scatter_pms one CU holds (fp16 tables: two 1024-thread workgroups, fp32 tables: one)
+static uint32_t gb_scatter_resident(size_t elem) {
+    static uint32_t cus[16];
     int dev = 0;
-    (void)st;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!made[dev]) {
-        if (hipStreamCreateWithFlags(&sides[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (uint32_t i = 0; i < GE_MAX_LEVELS; i++) if (hipEventCreateWithFlags(&sides[dev].ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&sides[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        made[dev] = true;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = (uint32_t)n;
     }
-    return &sides[dev];
+    return cus[dev] * (elem == 2 ? 2u : 1u);
 }
 
 template <typename T>
@@ -1648,42 +1629,24 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     GbHeader *hdr = reinterpret_cast<GbHeader *>(workspace);
     void *recs = reinterpret_cast<char *>(workspace) + ((sizeof(GbHeader) + 255) & ~(uint64_t)255);
     const uint64_t max_recs = gb_max_recs(B, L);
-    const uint32_t n_wg = foc_div_up(B, GB_PM_TILE);
-    const dim3 grid(n_wg);
+    const uint32_t n_tiles = foc_div_up(B, GB_PM_TILE);
     uint32_t *wg_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(recs) + gb_recs_bytes(B, L, sizeof(T) == 2 ? FOC_F16 : FOC_F32));
     if (!counted) {
         const int rc = gb_count(inputs, offsets, B, L, lv, gridtype, ac, interp, sizeof(T) == 2 ? FOC_F16 : FOC_F32, workspace, st);
         if (rc) return rc;
     }
-    // Level groups (FOC_GB_LEVEL_SPLITS="9,11,14": groups [0,9) [9,11) [11,14) [14,L)): scatter and reduce one group of levels at a time, so
-    // that a group's records (<= ~200 MB) are still in the 256 MiB Infinity Cache when the reduce reads them — the reduce of the whole
-    // batch streams 0.72 GB that fell out of it at 3.1 TB/s. FOC_GB_GROUP_STREAMS=2 runs the reduces on a side stream of
-    // the library, next to the following group's scatter. Default: one group (the measured A/B is in DESIGN.md).
-    uint32_t cuts[GE_MAX_LEVELS + 2];
-    uint32_t n_groups = gb_level_groups(L, cuts);
-    const int two_streams = n_groups > 1 && gb_group_streams() == 2;
-    GbSide *side = two_streams ? gb_side(st) : nullptr;
-    for (uint32_t g = 0; g < n_groups; g++) {
-        const uint32_t l0 = cuts[g], l1 = cuts[g + 1];
-        hipLaunchKernelGGL((k_gbin_scatter_pms<T>), grid, dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv, gridtype, ac,
-                           interp, bl, fact_mask, sz, l0, l1);
-        FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
-        const uint32_t ub = (uint32_t)(((uint64_t)B * 5u * (l1 - l0) + GB_CHUNK - 1) / GB_CHUNK) + (l1 - l0) * GB_MAX_SEGS;      // chunks in the worst case
-        hipStream_t rs = st;
-        if (side) {
-            if (hipEventRecord(side->ev[g], st) != hipSuccess || hipStreamWaitEvent(side->stream, side->ev[g], 0) != hipSuccess) {
-                foc_set_error("grid_encode_backward: event fork failed"); return FOC_E_LAUNCH;
-            }
-            rs = side->stream;
-        }
-        hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, rs, hdr, recs, max_recs, offsets, (T *)grad_emb, L, fact_mask, l0, l1);
-        FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
-    }
-    if (side) {
-        if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
-            foc_set_error("grid_encode_backward: event join failed"); return FOC_E_LAUNCH;
-        }
-    }
+    // The last, partial round of scatter workgroups is cut into shorter ones (see the kernel): `split` workgroups per tile, as many as
+    // still fit one round, so that the launch ends a fraction of a tile's time after its last full round instead of a whole one.
+    const uint32_t resident = gb_scatter_resident(sizeof(T));
+    const uint32_t n_tail = n_tiles % resident, n_whole = n_tiles - n_tail;
+    uint32_t split = 1u;
+    while (n_tail && split * 2u <= L && n_tail * split * 2u <= resident && split < 16u) split *= 2u;
+    hipLaunchKernelGGL((k_gbin_scatter_pms<T>), dim3(n_whole + n_tail * split), dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv,
+                       gridtype, ac, interp, bl, fact_mask, sz, n_tiles, n_whole, split);
+    FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");
+    const uint32_t ub = (uint32_t)(((uint64_t)B * 5u * L + GB_CHUNK - 1) / GB_CHUNK) + L * GB_MAX_SEGS;      // chunks in the worst case
+    hipLaunchKernelGGL((k_gbin_reduce<T>), dim3(ub), dim3(GB_RTHREADS), 0, st, hdr, recs, max_recs, offsets, (T *)grad_emb, L, fact_mask);
+    FOC_CHECK_LAUNCH("grid_encode_backward(reduce)");
     return FOC_OK;
 }
 

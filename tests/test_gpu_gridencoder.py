@@ -617,33 +617,3 @@ def test_factored_records_agree_with_the_two_corner_records(monkeypatch):
     for l in range(L):
         want = grad[l][inb].astype(np.float64).sum(0)
         np.testing.assert_allclose(b[off[l]:off[l + 1]].astype(np.float64).sum(0), want, atol=0.5)
-
-
-@pytest.mark.parametrize("streams", ["1", "2"])
-@pytest.mark.parametrize("splits", ["9,11,14", "1", "5,6,7,8,9,10,11,12,13,14,15", "16,3,3,99"])
-def test_level_group_form_of_the_binned_backward_is_bitwise_the_single_pass(splits, streams, monkeypatch):
-    """FOC_GB_LEVEL_SPLITS scatters and reduces one group of levels at a time (so that a group's records are read back out of the Infinity
-    Cache), FOC_GB_GROUP_STREAMS=2 with the reduces on the library's side stream next to the following group's scatter: the same record
-    ranges, the same chunks, the same fixed-point sums — bit for bit the single-pass result, also for degenerate split lists."""
-    D, C, L, H, lh, desired, gridtype, ac, interp = CASES[0]
-    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, np.float16)
-    B = 6000                                          # one reduce chunk per (level, segment): every row is rounded to half exactly once
-    x = _points(B, D, 21)
-    x[::7] = x[::7] * 0.02 + 0.4                       # clustered points: uneven segments
-    grad = (np.random.default_rng(6).standard_normal((L, B, C)) * 0.25).astype(np.float16)
-    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
-    g = torch.from_numpy(grad).cuda()
-
-    def run():
-        ge = torch.zeros(int(off[-1]), C, dtype=torch.float16, device="cuda")
-        _be().grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=False)
-        torch.cuda.synchronize()
-        return ge
-    monkeypatch.delenv("FOC_GB_LEVEL_SPLITS", raising=False)
-    ref = run()
-    monkeypatch.setenv("FOC_GB_LEVEL_SPLITS", splits)
-    monkeypatch.setenv("FOC_GB_GROUP_STREAMS", streams)
-    for _ in range(2):
-        got = run()
-        assert torch.equal(got, ref)
-    assert ref.abs().max() > 0
