@@ -351,36 +351,95 @@ __global__ void __launch_bounds__(1024) k_march_scan(const int32_t *__restrict__
     if (tid == 0) { counter[0] = base0 + s_total; counter[1] = ray0 + (int32_t)N; }
 }
 
+// degree-4 real spherical harmonics of a direction, the expressions of head.hip hd_sh16 (focnerf_amd/shencoder.py)
+__device__ __forceinline__ void rm_sh16(float x, float y, float z, float (&o)[16]) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
 // ---------------------------------------------------------------- R6 pass 3: emit (raymarching.cu:415-479)
 // One wave per ray, lane k = sample k: t_k from the strip; xyz = clamp(o + t d), dt = clamp(t dt_gamma) exactly as rm_cell forms them;
 // deltas = (dt_k, (t_k + dt_k) - last_t) with last_t = t_{k-1} + dt_{k-1} (the start t for k = 0), as the loop accumulates them.
 // Stores are contiguous across the wave (768 B of xyz per 64 samples).
+// FIELD: the sample list in the layout the fused training path consumes (foc_march_rays_train_field) — `xyzs` receives the encoder's
+// [0,1] coordinates (x + bound) * 1 / (2 bound) (rm_out), `dirs` is not written, and `sh` [M,16] fp16 receives each sample's degree-4
+// SH row (the first k-chunk of the colour network's input, head.hip hd_sh16 rounded like k_head_fwd rounds it): one row per sample of
+// a ray, all equal. Every row of both arrays is written — rays that do not fit the list and the rows behind the last ray get zeros
+// (spare workgroups; `counter` from k_march_scan) — so the caller needs no zero fill.
+#define RM_PAD_BLOCKS 64u
+template <bool FIELD>
 __global__ void __launch_bounds__(256) k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, RmParams p, uint32_t max_steps,
                                                     uint32_t N, uint32_t M, const float *__restrict__ nears, const float *__restrict__ noises,
                                                     const int32_t *__restrict__ rays, const float *__restrict__ tstrip,
-                                                    float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas) {
+                                                    float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
+                                                    _Float16 *__restrict__ sh, const int32_t *__restrict__ counter) {
+    typedef _Float16 rm_h8 __attribute__((ext_vector_type(8)));
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if constexpr (FIELD) {
+        if (blockIdx.x >= (N + 3u) / 4u) {
+            const uint32_t total = (uint32_t)counter[0], pb = blockIdx.x - (N + 3u) / 4u;
+            for (uint64_t s = (uint64_t)total + pb * 256u + threadIdx.x; s < M; s += (uint64_t)RM_PAD_BLOCKS * 256u) {
+                xyzs[s * 3] = 0.0f; xyzs[s * 3 + 1] = 0.0f; xyzs[s * 3 + 2] = 0.0f;
+                deltas[s * 2] = 0.0f; deltas[s * 2 + 1] = 0.0f;
+                *reinterpret_cast<uint4 *>(sh + s * 16) = make_uint4(0u, 0u, 0u, 0u); *reinterpret_cast<uint4 *>(sh + s * 16 + 8) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            return;
+        }
+    }
     if (n >= N) return;
     const uint32_t point_index = (uint32_t)rays[n * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
     if (num_steps == 0) return;
-    if (point_index + num_steps > M) return;                       // raymarching.cu:413
+    if (point_index + num_steps > M) {                             // raymarching.cu:413
+        if constexpr (FIELD) {
+            const uint64_t end = min((uint64_t)point_index + num_steps, (uint64_t)M);
+            for (uint64_t s = (uint64_t)point_index + lane; s < end; s += 64) {
+                xyzs[s * 3] = 0.0f; xyzs[s * 3 + 1] = 0.0f; xyzs[s * 3 + 2] = 0.0f;
+                deltas[s * 2] = 0.0f; deltas[s * 2 + 1] = 0.0f;
+                *reinterpret_cast<uint4 *>(sh + s * 16) = make_uint4(0u, 0u, 0u, 0u); *reinterpret_cast<uint4 *>(sh + s * 16 + 8) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        return;
+    }
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     float t0 = nears[n];
     t0 = fmaf(rm_clamp(t0 * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t0);
     const float *strip = tstrip + (uint64_t)n * max_steps;
+    rm_h8 sh0, sh1;
+    if constexpr (FIELD) {
+        float o[16];
+        rm_sh16(dx, dy, dz, o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { sh0[k] = foc_f2h(o[k]); sh1[k] = foc_f2h(o[8 + k]); }
+    }
     for (uint32_t k = lane; k < num_steps; k += 64) {
         const float t = strip[k];
         const float dt = rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max);
         float last_t = t0;
         if (k > 0) { const float tp = strip[k - 1]; last_t = tp + rm_clamp(tp * p.dt_gamma, p.dt_min, p.dt_max); }
         const uint64_t s = (uint64_t)point_index + k;
-        xyzs[s * 3] = rm_clamp(fmaf(t, dx, ox), -p.bound, p.bound);
-        xyzs[s * 3 + 1] = rm_clamp(fmaf(t, dy, oy), -p.bound, p.bound);
-        xyzs[s * 3 + 2] = rm_clamp(fmaf(t, dz, oz), -p.bound, p.bound);
-        dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz;
+        xyzs[s * 3] = rm_out(p, rm_clamp(fmaf(t, dx, ox), -p.bound, p.bound));
+        xyzs[s * 3 + 1] = rm_out(p, rm_clamp(fmaf(t, dy, oy), -p.bound, p.bound));
+        xyzs[s * 3 + 2] = rm_out(p, rm_clamp(fmaf(t, dz, oz), -p.bound, p.bound));
+        if constexpr (FIELD) { *reinterpret_cast<rm_h8 *>(sh + s * 16) = sh0; *reinterpret_cast<rm_h8 *>(sh + s * 16 + 8) = sh1; }
+        else { dirs[s * 3] = dx; dirs[s * 3 + 1] = dy; dirs[s * 3 + 2] = dz; }
         deltas[s * 2] = dt;
         deltas[s * 2 + 1] = (t + dt) - last_t;
     }
@@ -1142,20 +1201,19 @@ int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *b
 static uint64_t rm_strip_offset(uint32_t N) { return (((uint64_t)N + 64) * sizeof(int32_t) + 255) & ~(uint64_t)255; }
 uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) { return rm_strip_offset(N) + (uint64_t)N * max_steps * sizeof(float); }
 
-int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
-                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                         const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                         int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *sh_rows, bool field, void *stream) {
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
                 "march_rays_train: null pointer");
-    FOC_REQUIRE(M == 0 || (xyzs && dirs && deltas), FOC_E_INVALID, "march_rays_train: null output with M > 0");
+    FOC_REQUIRE(M == 0 || (xyzs && deltas && (field ? sh_rows != nullptr : dirs != nullptr)), FOC_E_INVALID, "march_rays_train: null output with M > 0");
     FOC_REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 512 && max_steps >= 1, FOC_E_INVALID,
                 "march_rays_train: unsupported C=%u H=%u max_steps=%u", C, H, max_steps);
     // the float index `level*H^3 + morton` of raymarching.cu:378 is exact only below 2^24
     FOC_REQUIRE((uint64_t)C * H * H * H <= (1ull << 24), FOC_E_INVALID, "march_rays_train: C*H^3 exceeds 2^24");
-    const RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
+    RmParams p = rm_make_params(bound, dt_gamma, max_steps, C, H);
     hipStream_t st = (hipStream_t)stream;
     float *tstrip = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + rm_strip_offset(N));
     // A wave per ray repeats the lattice recurrence on 64 lanes: about 4x the instructions of a ray per lane, in exchange for a chain
@@ -1175,10 +1233,34 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, st, scratch, N, rays, counter);
     FOC_CHECK_LAUNCH("march_rays_train(scan)");
-    hipLaunchKernelGGL(k_march_emit, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs, dirs,
-                       deltas);
+    if (field) {
+        p.norm_inv = 1.0f / (2.0f * bound);                // (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
+        hipLaunchKernelGGL(k_march_emit<true>, dim3(foc_div_up(N, 4) + RM_PAD_BLOCKS), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays,
+                           tstrip, xyzs, (float *)nullptr, deltas, (_Float16 *)sh_rows, counter);
+    } else {
+        hipLaunchKernelGGL(k_march_emit<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs,
+                           dirs, deltas, (_Float16 *)nullptr, (const int32_t *)nullptr);
+    }
     FOC_CHECK_LAUNCH("march_rays_train(emit)");
     return FOC_OK;
+}
+
+int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
+                         int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises, scratch, nullptr, false,
+                          stream);
+}
+
+int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
+                               uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                               const float *nears, const float *fars, float *enc_in, void *sh_rows, float *deltas,
+                               int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, enc_in, nullptr, deltas, rays, counter, noises, scratch, sh_rows, true,
+                          stream);
 }
 
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,

@@ -90,6 +90,21 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
 /* Bytes of `scratch` needed by foc_march_rays_train for N rays of at most max_steps samples. */
 uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
 
+/* Extension (no reference binding): the same march — same rays table, counter and per-ray samples — with the sample list in the
+ * layout the fused occupancy-grid training path consumes (focnerf_amd/occtrain.py; the caller-side expressions of
+ * legacy/nerf/renderer.py:288-300 and nerf/network_ff.py:51-68 folded into the emit pass):
+ *   enc_in [M,3] fp32  = (xyz + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates as torch evaluates (x + bound) / (2 bound);
+ *   sh_rows [M,16] fp16 = the degree-4 SH values of each sample's ray direction (k-chunk 0 of the colour network's input);
+ *   deltas [M,2] as above. No `dirs`. EVERY row of the three arrays is written (rays that do not fit the list and the rows behind the
+ *   last ray receive zeros): the caller does not pre-zero them. */
+int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid,
+                               float bound, float dt_gamma, uint32_t max_steps,
+                               uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                               const float *nears, const float *fars,
+                               float *enc_in, void *sh_rows, float *deltas,
+                               int32_t *rays, int32_t *counter, const float *noises,
+                               int32_t *scratch, void *stream);
+
 /* raymarching.cu:500-588  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                      weights_sum, depth, image) */
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas,
@@ -486,6 +501,23 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
                             const float *fars, const float *noise, const float *bg_ray, float bg_scalar, uint32_t N,
                             uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width,
                             const float *grad_sumsq, void *stream);
+
+/* Tail of the occupancy-grid TRAINING path on a ragged sample list (csrc/occtrain.hip; legacy/nerf/renderer.py:300-314):
+ *   sigma = density_scale * exp(h[:,0]); rgb = sigmoid(c[:,0:3]) (rounded to fp16); composite_rays_train (raymarching.cu:500-588);
+ *   image = raw + (1 - weights_sum) * bg (bg_ray [N,3] or NULL -> bg_scalar); depth = clamp(depth - nears, 0) / (fars - nears).
+ * h [M,16] fp16 (density network output), c [M,c_width] fp16 (colour network output, c_width 4 or 16), deltas [M,2], rays [N,3].
+ * Outputs [N] / [N,3] fp32: weights_sum, image_raw (the composite's own image: the backward needs it), image, depth.
+ * Backward: grad_image [N,3] (of `image`), grad_ws [N] or NULL -> grad_c [M,c_width] fp16 and grad_h0 [M] fp16 (the gradient of
+ * h[:,0], trunc_exp's factor applied) — what foc_color_head_backward consumes. EVERY row of both is written (zeros where a ray
+ * stopped early, did not fit the list, and behind the last ray: `counter` = the march's counter, counter[0] = samples marched). */
+int foc_occ_tail_forward(const void *h, const void *c, uint32_t c_width, const float *deltas, const int32_t *rays,
+                         uint32_t M, uint32_t N, float T_thresh, float density_scale, const float *bg_ray, float bg_scalar,
+                         const float *nears, const float *fars, float *weights_sum, float *image_raw, float *image,
+                         float *depth, void *stream);
+int foc_occ_tail_backward(const float *grad_image, const float *grad_ws, const void *h, const void *c, uint32_t c_width,
+                          const float *deltas, const int32_t *rays, const int32_t *counter, const float *weights_sum,
+                          const float *image_raw, uint32_t M, uint32_t N, float T_thresh, float density_scale,
+                          const float *bg_ray, float bg_scalar, void *grad_c, void *grad_h0, void *stream);
 
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL

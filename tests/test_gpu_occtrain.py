@@ -1,0 +1,198 @@
+"""GPU: the fused occupancy-grid training path (focnerf_amd/occtrain.py, csrc/occtrain.hip, foc_march_rays_train_field) against the
+chain of separate ops it replaces, and its tail kernels against the oracle's composite_rays_train (raymarching.cu:500-693)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(bound, seed=0, density_scale=1):
+    from focnerf_amd import synthetic
+    from focnerf_amd.network import NeRFNetwork
+    torch.manual_seed(seed)
+    m = NeRFNetwork(bound=bound, cuda_ray=True, density_scale=density_scale).cuda()
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    m.set_density_grid(synthetic.analytic_density_grid(bound, device="cuda"))
+    return m.train()
+
+
+def _rays(bound, n, seed):
+    from focnerf_amd import synthetic
+    o, d = synthetic.make_view_rays(64, 64, bound, 1, seed=seed, device="cuda")
+    g = torch.Generator().manual_seed(seed)
+    pick = torch.randperm(o.shape[1], generator=g)[:n].cuda()
+    return o[:, pick].contiguous(), d[:, pick].contiguous()
+
+
+def _step(m, o, d, fused, monkeypatch, seed=7, **kw):
+    monkeypatch.setenv("FOC_FUSED_OCC", "1" if fused else "0")
+    for p in m.parameters():
+        p.grad = None
+    torch.manual_seed(seed)                                      # the jitter of `perturb` comes from torch.rand(n) in both paths
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m.render(o, d, staged=False, dt_gamma=1 / 128, max_steps=1024, **kw)
+        target = 0.5 + 0.5 * torch.sin(3.0 * d)
+        loss = torch.nn.functional.mse_loss(out["image"], target) + 1e-3 * out["weights_sum"].mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    return out, [p.grad.clone() for p in (m.encoder.embeddings, m.sigma_net.weights, m.color_net.weights)]
+
+
+@pytest.mark.parametrize("case", ["all_rays", "budget", "budget_overflow", "per_ray_bg", "grey_bg_scaled"])
+def test_fused_training_path_equals_the_op_chain(case, monkeypatch):
+    """Same sample list, hence the same image, depth and opacity BIT FOR BIT (every per-sample expression is that of the separate
+    kernels, in their order); gradients agree to the order of their fp32 sums (the colour network's input gradient takes another route)."""
+    bound = 2
+    m = _model(bound, density_scale=2 if case == "grey_bg_scaled" else 1)
+    o, d = _rays(bound, 1500, 3)
+    kw = dict(perturb=True, force_all_rays=case == "all_rays", bg_color=None)
+    if case.startswith("budget"):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            m.render(o, d, staged=False, dt_gamma=1 / 128, max_steps=1024, perturb=False, force_all_rays=True)      # fills step_counter
+        total = int(m.step_counter[(m.local_step - 1) % 16, 0])
+        assert total > 1000
+        m.mean_count = total + 500 if case == "budget" else total // 2        # a list with room to spare / one that drops the last rays
+    if case == "per_ray_bg":
+        kw["bg_color"] = torch.rand(1500, 3, device="cuda")
+    if case == "grey_bg_scaled":
+        kw["bg_color"] = 0.25
+    ref, g_ref = _step(m, o, d, False, monkeypatch, **kw)
+    got, g_got = _step(m, o, d, True, monkeypatch, **kw)
+    for k in ("image", "depth", "weights_sum"):
+        a, b = to_np(ref[k]), to_np(got[k])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), \
+            f"{case}: {k} differs, max {np.nanmax(np.abs(a - b))}"
+    assert to_np(ref["weights_sum"]).max() > 0.5
+    if case == "budget_overflow":
+        assert (to_np(got["weights_sum"]) == 0).sum() > (to_np(_step(m, o, d, True, monkeypatch, perturb=True, force_all_rays=True)[0]["weights_sum"]) == 0).sum()
+    for name, a, b in zip(("embeddings", "sigma_net", "color_net"), g_ref, g_got):
+        a, b = to_np(a).astype(np.float64), to_np(b).astype(np.float64)
+        scale = np.abs(a).max()
+        assert scale > 0
+        assert np.abs(a - b).max() <= 4e-3 * scale, f"{case}: grad {name} off by {np.abs(a - b).max() / scale:.2e} of its range"
+
+
+def test_fused_training_step_is_deterministic(monkeypatch):
+    """No atomics on the way: the march hands out slots by a scan, the weight gradients are summed in a fixed order, the table gradient
+    in fixed point — two runs of the same step give the same bits."""
+    m = _model(2)
+    o, d = _rays(2, 2000, 5)
+    _, g1 = _step(m, o, d, True, monkeypatch, perturb=True, force_all_rays=True)
+    _, g2 = _step(m, o, d, True, monkeypatch, perturb=True, force_all_rays=True)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+
+
+def test_march_field_layout_equals_the_reference_layout():
+    """foc_march_rays_train_field: the rays table and counter of foc_march_rays_train, enc_in = (xyz + bound) / (2 bound) as torch
+    evaluates it, one SH row per sample = the first 16 columns of k_head_fwd's colour input, deltas; zeros in every row no ray owns."""
+    from focnerf_amd import raymarching
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    from focnerf_amd.head import sample_head
+    bound = 2
+    m = _model(bound)
+    o, d = _rays(bound, 777, 9)
+    o, d = o[0], d[0]
+    nears, fars = raymarching.near_far_from_aabb(o, d, m.aabb_train, m.min_near)
+    torch.manual_seed(1)
+    c_ref = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, float(bound), m.density_bitfield, m.cascade, 128, nears, fars, c_ref, -1, True, 128, True, 1 / 128, 1024)
+    M = xyzs.shape[0]
+    total = int(c_ref[0])
+    for cap in (M, M - 256, total // 3 // 128 * 128):                        # exact fit (padded to 128), a list that drops rays, a short one
+        torch.manual_seed(1)
+        jitter = torch.rand(o.shape[0], device="cuda")
+        enc_in = torch.full((cap, 3), float("nan"), device="cuda")
+        sh = torch.full((cap, 16), float("nan"), device="cuda", dtype=torch.float16)
+        dl = torch.full((cap, 2), float("nan"), device="cuda")
+        r2 = torch.empty_like(rays)
+        c2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+        scratch = torch.empty(lib.foc_march_rays_train_scratch_bytes(o.shape[0], 1024), dtype=torch.uint8, device="cuda")
+        check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(nears), ptr(fars),
+                                             ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), stream_of(o)), "march_field")
+        assert torch.equal(r2, rays) and torch.equal(c2, c_ref)
+        rr = to_np(rays)
+        fits = (rr[:, 2] > 0) & (rr[:, 1] + rr[:, 2] <= cap)
+        own = np.zeros(cap, bool)
+        for off, cnt in rr[fits][:, 1:]:
+            own[off:off + cnt] = True
+        assert own.sum() > 0
+        want_x = to_np((xyzs[:cap] + bound) / (2 * bound))
+        _, cin = sample_head(torch.zeros(cap, 16, dtype=torch.float16, device="cuda"), dirs[:cap])
+        got_x, got_sh, got_dl = to_np(enc_in), to_np(sh), to_np(dl)
+        assert np.array_equal(got_x[own].view(np.uint32), want_x[own].view(np.uint32))
+        assert np.array_equal(got_sh[own].view(np.uint16), to_np(cin)[own][:, :16].view(np.uint16))
+        assert np.array_equal(got_dl[own].view(np.uint32), to_np(deltas[:cap])[own].view(np.uint32))
+        assert not got_x[~own].any() and not got_sh[~own].any() and not got_dl[~own].any(), "rows outside every fitting ray must be zeros"
+
+
+@pytest.mark.parametrize("c_width", [4, 16])
+def test_tail_kernels_against_the_oracle_composite(c_width):
+    """foc_occ_tail_forward / _backward on synthetic ragged lists against oracle.composite_rays_train_* fed with the values the kernels
+    form on the lane (sigma = exp(h0), rgb = half(sigmoid(c))): forward 1e-4 (north_star), gradients 1e-4 relative; rays that stop early,
+    empty rays, rays that do not fit the list; every row of the gradient arrays written."""
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    rng = np.random.default_rng(4)
+    N = 300
+    counts = rng.integers(0, 200, N).astype(np.int32)
+    counts[::17] = 0
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+    total = int(counts.sum())
+    M = (total - 150 + 127) // 128 * 128                                  # the last rays do not fit
+    rays = np.stack([rng.permutation(N).astype(np.int32), offs, counts], 1)
+    h = (rng.standard_normal((M, 16)) * 1.5).astype(np.float16)
+    h[::50, 0] = 16.5                                                     # beyond trunc_exp's clamp
+    c = (rng.standard_normal((M, c_width)) * 2).astype(np.float16)
+    deltas = np.abs(rng.standard_normal((M, 2))).astype(np.float32) * 0.02 + 1e-3
+    nears = rng.random(N).astype(np.float32) + 0.2
+    fars = nears + 2 + rng.random(N).astype(np.float32)
+    bg = rng.random((N, 3)).astype(np.float32)
+    T_thresh = 1e-3
+    sigma = np.exp(h[:, 0].astype(np.float32))
+    rgb = (1 / (1 + np.exp(-c[:, :3].astype(np.float32)))).astype(np.float16).astype(np.float32)
+    ws_r, dp_r, im_r = oracle.composite_rays_train_forward(sigma, rgb, deltas, rays, N, T_thresh)
+    t = lambda a: torch.from_numpy(a).cuda()
+    ht, ct, dt, rt, nt, ft, bt = t(h), t(c), t(deltas), t(rays), t(nears), t(fars), t(bg)
+    ws, raw, img, dep = torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda"), torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")
+    check(lib.foc_occ_tail_forward(ptr(ht), ptr(ct), c_width, ptr(dt), ptr(rt), M, N, T_thresh, 1.0, ptr(bt), 0.0, ptr(nt), ptr(ft), ptr(ws), ptr(raw), ptr(img), ptr(dep),
+                                   stream_of(ht)), "tail_fwd")
+    np.testing.assert_allclose(to_np(ws), ws_r, atol=1e-4)
+    np.testing.assert_allclose(to_np(raw), im_r, atol=1e-4)
+    np.testing.assert_allclose(to_np(img), im_r + (1 - ws_r)[:, None] * bg, atol=1e-4)
+    np.testing.assert_allclose(to_np(dep), np.maximum(dp_r - nears, 0) / (fars - nears), atol=1e-4)
+    # backward: d(loss)/d(image) = g, d(loss)/d(ws) = gw
+    g = rng.standard_normal((N, 3)).astype(np.float32)
+    gw = rng.standard_normal(N).astype(np.float32)
+    gw_total = gw - (g * bg).sum(1)
+    gs_r, grgb_r = oracle.composite_rays_train_backward(gw_total.astype(np.float32), g, sigma, rgb, deltas, rays, ws_r, im_r, T_thresh)
+    counter = torch.tensor([total, N], dtype=torch.int32, device="cuda")
+    grad_c = torch.full((M, c_width), float("nan"), dtype=torch.float16, device="cuda")
+    grad_h0 = torch.full((M,), float("nan"), dtype=torch.float16, device="cuda")
+    gt, gwt = t(g), t(gw)                                                 # named: a temporary would be freed (and its block reused) before the kernel runs
+    check(lib.foc_occ_tail_backward(ptr(gt), ptr(gwt), ptr(ht), ptr(ct), c_width, ptr(dt), ptr(rt), ptr(counter), ptr(ws), ptr(raw), M, N, T_thresh, 1.0, ptr(bt), 0.0,
+                                    ptr(grad_c), ptr(grad_h0), stream_of(ht)), "tail_bwd")
+    gc, gh0 = to_np(grad_c).astype(np.float32), to_np(grad_h0).astype(np.float32)
+    assert np.isfinite(gc).all() and np.isfinite(gh0).all(), "every row must be written"
+    want_h0 = gs_r * np.exp(np.clip(h[:, 0].astype(np.float32), -15, 15))
+    want_c = grgb_r * (1 - rgb) * rgb
+    # tolerances of the separate composite kernel's own test (grad_sigmas: atol 2e-4, rtol 2e-3; grad_rgbs: atol 4e-4) carried through
+    # the factors the tail applies on the lane (exp(clamp(h0)) resp. (1 - y) y <= 1/4), plus the fp16 rounding of the stored values
+    e0 = np.exp(np.clip(h[:, 0].astype(np.float32), -15, 15))
+    tol_h0 = 2e-4 * e0 + 3e-3 * np.abs(want_h0) + 1e-7
+    tol_c = 1e-4 + 3e-3 * np.abs(want_c)
+    # a ray stops at the first sample whose transmittance falls below T_thresh: the wave's product scan and the oracle's running product
+    # round differently, so a ray whose transmittance lands within an ulp of the threshold may stop one sample earlier or later —
+    # that one sample then carries its whole gradient on one side and zero on the other. At most a handful of rays.
+    bad_h0 = np.abs(gh0 - want_h0) > tol_h0
+    bad_c = (np.abs(gc[:, :3] - want_c) > tol_c).any(1)
+    assert (bad_h0 | bad_c).sum() <= 3, ((bad_h0 | bad_c).sum(), np.abs(gh0 - want_h0).max(), np.abs(gc[:, :3] - want_c).max())
+    for s_ in np.nonzero(bad_h0 | bad_c)[0]:
+        assert gh0[s_] == 0 or want_h0[s_] == 0, "a sample on one side of a threshold flip only"
+    assert not gc[:, 3:].any()
+    assert np.abs(want_h0).max() > 0 and (gh0 != 0).sum() > 100
