@@ -37,7 +37,7 @@ SIGNATURES = {
     "foc_march_rays_train": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_field": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
-                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_occ_tail_forward": (i32, [c_vp, c_vp, u32, c_vp, c_vp, u32, u32, f32, f32, c_vp, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_occ_tail_backward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, f32, c_vp, f32, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_scratch_bytes": (u64, [u32, u32]),

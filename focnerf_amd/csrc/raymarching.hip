@@ -387,14 +387,16 @@ __global__ void __launch_bounds__(256) k_march_emit(const float *__restrict__ ra
                                                     uint32_t N, uint32_t M, const float *__restrict__ nears, const float *__restrict__ noises,
                                                     const int32_t *__restrict__ rays, const float *__restrict__ tstrip,
                                                     float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                                                    _Float16 *__restrict__ sh, const int32_t *__restrict__ counter) {
+                                                    _Float16 *__restrict__ sh, const int32_t *__restrict__ counter, uint32_t pad_align) {
     typedef _Float16 rm_h8 __attribute__((ext_vector_type(8)));
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if constexpr (FIELD) {
         if (blockIdx.x >= (N + 3u) / 4u) {
+            // pad_align > 0: the caller cuts the list to the samples marched, rounded up like raymarching.py:226 — nothing behind that is read
             const uint32_t total = (uint32_t)counter[0], pb = blockIdx.x - (N + 3u) / 4u;
-            for (uint64_t s = (uint64_t)total + pb * 256u + threadIdx.x; s < M; s += (uint64_t)RM_PAD_BLOCKS * 256u) {
+            const uint64_t end = pad_align ? min((uint64_t)M, (uint64_t)total + (pad_align - total % pad_align)) : (uint64_t)M;
+            for (uint64_t s = (uint64_t)total + pb * 256u + threadIdx.x; s < end; s += (uint64_t)RM_PAD_BLOCKS * 256u) {
                 xyzs[s * 3] = 0.0f; xyzs[s * 3 + 1] = 0.0f; xyzs[s * 3 + 2] = 0.0f;
                 deltas[s * 2] = 0.0f; deltas[s * 2 + 1] = 0.0f;
                 *reinterpret_cast<uint4 *>(sh + s * 16) = make_uint4(0u, 0u, 0u, 0u); *reinterpret_cast<uint4 *>(sh + s * 16 + 8) = make_uint4(0u, 0u, 0u, 0u);
@@ -1204,7 +1206,7 @@ uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) { re
 static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                           const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *sh_rows, bool field, void *stream) {
+                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *sh_rows, bool field, uint32_t pad_align, void *stream) {
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
                 "march_rays_train: null pointer");
@@ -1236,10 +1238,10 @@ static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_
     if (field) {
         p.norm_inv = 1.0f / (2.0f * bound);                // (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
         hipLaunchKernelGGL(k_march_emit<true>, dim3(foc_div_up(N, 4) + RM_PAD_BLOCKS), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays,
-                           tstrip, xyzs, (float *)nullptr, deltas, (_Float16 *)sh_rows, counter);
+                           tstrip, xyzs, (float *)nullptr, deltas, (_Float16 *)sh_rows, counter, pad_align);
     } else {
         hipLaunchKernelGGL(k_march_emit<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs,
-                           dirs, deltas, (_Float16 *)nullptr, (const int32_t *)nullptr);
+                           dirs, deltas, (_Float16 *)nullptr, (const int32_t *)nullptr, 0u);
     }
     FOC_CHECK_LAUNCH("march_rays_train(emit)");
     return FOC_OK;
@@ -1250,17 +1252,17 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
     FocDeviceGuard foc_guard_(stream);
-    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises, scratch, nullptr, false,
+    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises, scratch, nullptr, false, 0u,
                           stream);
 }
 
 int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                const float *nears, const float *fars, float *enc_in, void *sh_rows, float *deltas,
-                               int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
+                               int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, uint32_t pad_align, void *stream) {
     FocDeviceGuard foc_guard_(stream);
     return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, enc_in, nullptr, deltas, rays, counter, noises, scratch, sh_rows, true,
-                          stream);
+                          pad_align, stream);
 }
 
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,

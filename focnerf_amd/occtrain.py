@@ -68,8 +68,8 @@ class _occ_train(Function):
         jitter = torch.rand(n, dtype=torch.float32, device=dev) if perturb else _no_jitter(n, dev)
         scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(n, max_steps), dev)
         check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(bitfield), float(bound), float(dt_gamma), int(max_steps), n, int(cascade), int(grid_size), cap,
-                                             ptr(nears), ptr(fars), ptr(enc_in), ptr(sh), ptr(deltas), ptr(rays), ptr(counter), ptr(jitter), ptr(scratch), st),
-              "march_rays_train_field")
+                                             ptr(nears), ptr(fars), ptr(enc_in), ptr(sh), ptr(deltas), ptr(rays), ptr(counter), ptr(jitter), ptr(scratch),
+                                             0 if budgeted else max(int(align), 1), st), "march_rays_train_field")
         M = cap
         if not budgeted:                                        # raymarching.py:223-229: the list is cut to the samples marched (one device -> host copy)
             M = min(cap, _round_up(int(counter[0].item()), align))

@@ -96,14 +96,15 @@ uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
  *   enc_in [M,3] fp32  = (xyz + bound) * (1 / (2 bound)), the encoder's [0,1] coordinates as torch evaluates (x + bound) / (2 bound);
  *   sh_rows [M,16] fp16 = the degree-4 SH values of each sample's ray direction (k-chunk 0 of the colour network's input);
  *   deltas [M,2] as above. No `dirs`. EVERY row of the three arrays is written (rays that do not fit the list and the rows behind the
- *   last ray receive zeros): the caller does not pre-zero them. */
+ *   last ray receive zeros): the caller does not pre-zero them. pad_align > 0: the rows behind the last ray are zeroed only up to the
+ *   next multiple of pad_align above counter[0] (a caller that cuts the list there, raymarching.py:223-229, reads nothing beyond). */
 int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid,
                                float bound, float dt_gamma, uint32_t max_steps,
                                uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                const float *nears, const float *fars,
                                float *enc_in, void *sh_rows, float *deltas,
                                int32_t *rays, int32_t *counter, const float *noises,
-                               int32_t *scratch, void *stream);
+                               int32_t *scratch, uint32_t pad_align, void *stream);
 
 /* raymarching.cu:500-588  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                      weights_sum, depth, image) */

@@ -115,7 +115,7 @@ def test_march_field_layout_equals_the_reference_layout():
         c2 = torch.zeros(2, dtype=torch.int32, device="cuda")
         scratch = torch.empty(lib.foc_march_rays_train_scratch_bytes(o.shape[0], 1024), dtype=torch.uint8, device="cuda")
         check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(nears), ptr(fars),
-                                             ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), stream_of(o)), "march_field")
+                                             ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 0, stream_of(o)), "march_field")
         assert torch.equal(r2, rays) and torch.equal(c2, c_ref)
         rr = to_np(rays)
         fits = (rr[:, 2] > 0) & (rr[:, 1] + rr[:, 2] <= cap)
@@ -130,6 +130,16 @@ def test_march_field_layout_equals_the_reference_layout():
         assert np.array_equal(got_sh[own].view(np.uint16), to_np(cin)[own][:, :16].view(np.uint16))
         assert np.array_equal(got_dl[own].view(np.uint32), to_np(deltas[:cap])[own].view(np.uint32))
         assert not got_x[~own].any() and not got_sh[~own].any() and not got_dl[~own].any(), "rows outside every fitting ray must be zeros"
+    # pad_align: a caller that cuts the list at the next multiple of 128 above the samples marched gets zeros up to there and nothing behind
+    cap = M + 1024
+    enc_in = torch.full((cap, 3), float("nan"), device="cuda")
+    sh = torch.full((cap, 16), float("nan"), device="cuda", dtype=torch.float16)
+    dl = torch.full((cap, 2), float("nan"), device="cuda")
+    c2.zero_()
+    check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(nears), ptr(fars),
+                                         ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 128, stream_of(o)), "march_field")
+    cut = total + (128 - total % 128)
+    assert cut == M and not to_np(enc_in)[total:cut].any() and not to_np(sh)[total:cut].any() and np.isnan(to_np(enc_in)[cut:]).all() and np.isnan(to_np(dl)[cut:]).all()
 
 
 @pytest.mark.parametrize("c_width", [4, 16])
