@@ -764,12 +764,15 @@ def main():
                 result.setdefault("roofline", {})["render"] = {"error": repr(e)}
             # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                # the SAME views as the `render` leg, in the same order: a view costs 40 - 45 ms depending on its pose, and with one fixed view here
+                # the two legs were not comparable (round 3: 41.5 ms for pose 0 against 42.4 ms for the mean over eight poses)
                 model.render(rays_o, rays_d, return_fields=True, **rkw)
                 barrier()
                 t0 = time.perf_counter()
-                model.render(rays_o, rays_d, return_fields=True, **rkw)
+                for i in range(args.render_views):
+                    model.render(*view_rays[i % len(view_rays)], return_fields=True, **rkw)
                 barrier()
-            relf = max_over_ranks(time.perf_counter() - t0)
+            relf = max_over_ranks(time.perf_counter() - t0) / max(1, args.render_views)
             result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
                                             "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
 

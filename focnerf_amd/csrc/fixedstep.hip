@@ -557,6 +557,57 @@ __global__ void __launch_bounds__(1024) k_fs_render_infer_blk(const float *__res
 }
 
 // ================================================================= host entry points
+// ---------------------------------------------------------------- tile order of a view's rays, found and built on the device
+// focnerf_amd/rayorder.py: a caller hands a view over row by row; the staged render walks it in th x tw pixel tiles (the 64 rays of a block
+// are then a compact patch at every level of the hash grid). Whether the ray list IS a row-major H x W pixel grid is read off the
+// directions: inside a row consecutive steps point the same way, the step from a row's last pixel to the next row's first points back
+// across the image — it is anti-parallel to the step before it and to the step after it. All of it here, no host round trip (the
+// torch form — nonzero, int(), bool() — waited for the GPU three times per view, i.e. until the PREVIOUS view had drained, before the
+// first chunk of the next one could be enqueued: 1-3 ms per 800 x 800 view).
+//   pass 1: turns t_i = [ (d[i+2] - d[i+1]) . (d[i+1] - d[i]) < 0 ], i < N - 2: their number and the first one (W = first + 2)
+//   pass 2: every t_i must be where an H x W grid puts it: (i + 2) % W == 0 or (i + 1) % W == 0
+//   pass 3: perm[p] = the ray at position p of the tile order (closed form, ragged last tiles included), or p when it is no such grid
+struct VtState { uint32_t count, first_enc, bad, pad; };      // first_enc = N - (index of the first turn), 0 = none (zero-initialised)
+
+__device__ __forceinline__ bool vt_turn(const float *__restrict__ d, uint32_t i) {
+    const float ax = d[(i + 1) * 3] - d[i * 3], ay = d[(i + 1) * 3 + 1] - d[i * 3 + 1], az = d[(i + 1) * 3 + 2] - d[i * 3 + 2];
+    const float bx = d[(i + 2) * 3] - d[(i + 1) * 3], by = d[(i + 2) * 3 + 1] - d[(i + 1) * 3 + 1], bz = d[(i + 2) * 3 + 2] - d[(i + 1) * 3 + 2];
+    return (bx * ax + by * ay) + bz * az < 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_vt_find(const float *__restrict__ d, uint32_t N, VtState *__restrict__ st) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i + 2 < N; i += gridDim.x * 256)
+        if (vt_turn(d, i)) { atomicAdd(&st->count, 1u); atomicMax(&st->first_enc, N - i); }
+}
+
+__global__ void __launch_bounds__(256) k_vt_check(const float *__restrict__ d, uint32_t N, VtState *__restrict__ st) {
+    const uint32_t fe = st->first_enc;
+    if (fe == 0u) return;
+    const uint32_t W = N - fe + 2u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i + 2 < N; i += gridDim.x * 256) {
+        const bool expect = (i + 2u) % W == 0u || (i + 1u) % W == 0u;
+        if (vt_turn(d, i) != expect) st->bad = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vt_perm(uint32_t N, uint32_t th, uint32_t tw, const VtState *__restrict__ st, int64_t *__restrict__ perm) {
+    const uint32_t fe = st->first_enc, W = fe ? N - fe + 2u : 0u;
+    const uint32_t H = W ? N / W : 0u;
+    const bool grid = W >= 16u && N % W == 0u && H >= 8u && st->count == 2u * (H - 1u) && st->bad == 0u;
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < N; p += gridDim.x * 256) {
+        uint32_t src = p;
+        if (grid) {
+            // tile rows hold W * th rays each (the last one fewer rows), a tile rows_here * tw rays (the last one of a tile row fewer columns)
+            const uint32_t ty = p / (W * th), rem = p - ty * W * th;
+            const uint32_t rows_here = min(th, H - ty * th);
+            const uint32_t tx = min(rem / (rows_here * tw), (W - 1u) / tw), r2 = rem - tx * rows_here * tw;
+            const uint32_t cols_here = min(tw, W - tx * tw);
+            src = (ty * th + r2 / cols_here) * W + tx * tw + r2 % cols_here;
+        }
+        perm[p] = (int64_t)src;
+    }
+}
+
 extern "C" {
 
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
@@ -699,6 +750,24 @@ int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *near
     hipLaunchKernelGGL(k_fs_render_infer<true>, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, rgb, nears, fars, noise, bg_ray, bg_scalar, N, T,
                        density_scale, thresh, image, depth, weights_sum, (float *)nullptr, (float4 *)field4);
     FOC_CHECK_LAUNCH("fixed_field_pack");
+    return FOC_OK;
+}
+
+int foc_view_tile_order(const float *rays_d, uint32_t N, uint32_t tile_h, uint32_t tile_w, int64_t *perm, void *state16, void *stream) {
+    FocDeviceGuard foc_guard_(stream);
+    if (N == 0) return FOC_OK;
+    FOC_REQUIRE(rays_d && perm && state16, FOC_E_INVALID, "view_tile_order: null pointer");
+    FOC_REQUIRE(tile_h >= 1 && tile_w >= 1 && tile_h * tile_w <= 4096, FOC_E_INVALID, "view_tile_order: tile %u x %u", tile_h, tile_w);
+    FOC_REQUIRE(N < (1u << 31), FOC_E_INVALID, "view_tile_order: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    VtState *state = reinterpret_cast<VtState *>(state16);
+    if (foc_zero_async(state, sizeof(VtState), st) != hipSuccess) { foc_set_error("view_tile_order: zero fill failed"); return FOC_E_LAUNCH; }
+    if (N >= 3) {
+        hipLaunchKernelGGL(k_vt_find, dim3(foc_grid_1d(N, 256)), dim3(256), 0, st, rays_d, N, state);
+        hipLaunchKernelGGL(k_vt_check, dim3(foc_grid_1d(N, 256)), dim3(256), 0, st, rays_d, N, state);
+    }
+    hipLaunchKernelGGL(k_vt_perm, dim3(foc_grid_1d(N, 256)), dim3(256), 0, st, N, tile_h, tile_w, state, perm);
+    FOC_CHECK_LAUNCH("view_tile_order");
     return FOC_OK;
 }
 

@@ -7,7 +7,9 @@ saves. An 8 x 8 pixel tile is a more compact set of points than a 64 x 1 strip a
 tools/time_render_fixed.py TILE=8x8: 44.8 -> 41.5 ms per view; 16x4 41.8, 4x16 42.7, 2x32 43.9).
 
 `view_tiling(rays_d)` recognises a row-major pixel grid from the directions alone (inside a row consecutive steps point the same way,
-at a row's end the step jumps back across the image) and returns the permutation that lists the rays tile by tile, or None. The
+at a row's end the step jumps back across the image) and returns the permutation that lists the rays tile by tile (the identity for a
+ray set that is no such grid), computed on the device without a host round trip; `detect_image_width` / `tile_permutation` are the
+same recognition and order as torch expressions (host-side, used by the tests and the bench's combined-render leg). The
 staged fixed-step render walks the view in that order and puts the results back where the caller's rays were; nothing else changes (the
 occupancy-grid loop gains nothing from it — 14.8 against 14.6 ms per view: its march and composite kernels read the rays' state through the
 list — and keeps the caller's order). A wrong guess could
@@ -55,12 +57,12 @@ def tile_permutation(n, w, device, th=8, tw=8):
 
 
 def view_tiling(rays_d):
-    """Permutation (int64 [N]) that lists the rays of a row-major view in 8 x 8 pixel tiles, or None (not a pixel grid; FOC_RAY_TILES=0)."""
+    """int64 [N] order in which the staged render walks the view's rays: 8 x 8 pixel tiles if `rays_d` is a row-major pixel grid, else the
+    identity — found and built ON THE DEVICE (csrc/fixedstep.hip, foc_view_tile_order): the caller's thread never waits for the GPU, so
+    the chunks of the next view are enqueued while the previous view is still being rendered. None: not applicable (FOC_RAY_TILES=0, fewer
+    than 4096 rays, not on the GPU)."""
     shape = os.environ.get("FOC_RAY_TILES", "8x8")
-    if shape in ("0", "", "off") or not rays_d.is_cuda or torch.cuda.is_current_stream_capturing():      # (the recognition reads back from the device)
-        return None
-    w = detect_image_width(rays_d)
-    if w is None:
+    if shape in ("0", "", "off") or not rays_d.is_cuda or rays_d.dim() != 2 or rays_d.shape[0] < 4096:
         return None
     try:
         th, tw = (int(v) for v in shape.lower().split("x"))
@@ -68,4 +70,10 @@ def view_tiling(rays_d):
         raise ValueError(f"FOC_RAY_TILES must be 0 or <rows>x<columns> (got {shape!r})") from None
     if th < 1 or tw < 1:
         return None
-    return tile_permutation(rays_d.shape[0], w, rays_d.device, th, tw)
+    from ._lib import lib, ptr, stream_of, check
+    d = rays_d.contiguous().float()
+    n = d.shape[0]
+    perm = torch.empty(n, dtype=torch.int64, device=d.device)
+    state = torch.empty(4, dtype=torch.int32, device=d.device)
+    check(lib.foc_view_tile_order(ptr(d), n, th, tw, ptr(perm), ptr(state), stream_of(d)), "view_tile_order")
+    return perm

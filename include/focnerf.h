@@ -520,6 +520,12 @@ int foc_occ_tail_backward(const float *grad_image, const float *grad_ws, const v
                           const float *image_raw, uint32_t M, uint32_t N, float T_thresh, float density_scale,
                           const float *bg_ray, float bg_scalar, void *grad_c, void *grad_h0, void *stream);
 
+/* Extension (no reference binding; focnerf_amd/rayorder.py): perm [N] int64 = the order in which a staged render walks a view's rays —
+ * tile_h x tile_w pixel tiles when rays_d [N,3] fp32 is a row-major H x W pixel grid (recognised from the directions: W >= 16, H >= 8),
+ * else the identity. Found and built on the device, no host round trip. state16: 16 bytes of device scratch. */
+int foc_view_tile_order(const float *rays_d, uint32_t N, uint32_t tile_h, uint32_t tile_w, int64_t *perm, void *state16,
+                        void *stream);
+
 /* c [M,16] fp16 = colour-net output; rgb = sigmoid(c[:, :3]) (rounded to fp16 like the reference's half
  * sigmoid) where weights > thresh, else 0; image [N,3] = sum w rgb + (1 - sum w) bg. bg_ray [N,3] or NULL
  * (then bg_scalar). */

@@ -60,3 +60,42 @@ def test_renders_are_the_same_with_and_without_the_tile_order(monkeypatch):
         monkeypatch.delenv("FOC_RAY_TILES")
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"].nan_to_num(), b["depth"].nan_to_num())
     assert (a["image"] < 0.99).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fields", [False, True])
+def test_staged_render_in_larger_pieces_is_the_callers_chunking_bit_for_bit(fields, monkeypatch):
+    """The fused inference path walks a view in pieces of at least 16384 rays whatever `max_ray_batch` says (focnerf_amd/renderer.py):
+    same image, depth and per-sample fields as the caller's own chunks (FOC_RENDER_MIN_CHUNK=0), ragged last piece included."""
+    import bench
+    dev = torch.device("cuda", 0)
+    poses, intr = bench.make_training_rays(dev, 1, 2, seed=5)
+    o, d = synthetic.get_rays(poses[:1], intr, 150, 141)                  # 21150 rays: one piece of 16384 + a ragged one; six chunks of 4096
+    m = bench.build_model(1, dev, seed=3).eval()
+    kw = dict(staged=True, max_ray_batch=4096, num_steps=32, upsample_steps=0, perturb=False, fused=True, return_fields=fields)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = m.render(o, d, **kw)
+        monkeypatch.setenv("FOC_RENDER_MIN_CHUNK", "0")
+        b = m.render(o, d, **kw)
+    for k in ("image", "depth") + (("densities", "rgbs") if fields else ()):
+        assert torch.equal(a[k].nan_to_num(), b[k].nan_to_num()), k
+    assert (a["image"] < 0.99).any()
+
+
+@pytest.mark.gpu
+def test_device_side_tile_order_equals_the_host_recognition_and_permutation(monkeypatch):
+    """foc_view_tile_order (no host round trip) against detect_image_width + tile_permutation: the same order for pixel grids (ragged last
+    tiles, non-square tiles, two views behind each other), the identity for everything the host form rejects."""
+    g = torch.Generator().manual_seed(1)
+    cases = [_view(64, 64)[1], _view(70, 90)[1], _view(100, 61)[1], _view(8, 600)[1], _view(80, 80)[1].flip(0).contiguous(),
+             torch.cat([_view(64, 72, 1)[1], _view(64, 72, 2)[1]]),
+             _view(80, 80)[1][torch.randperm(6400, generator=g)], _view(80, 80)[1][: 80 * 60 + 17].contiguous(), _view(7, 700)[1]]
+    for shape in ("8x8", "4x16", "3x5"):
+        monkeypatch.setenv("FOC_RAY_TILES", shape)
+        th, tw = (int(v) for v in shape.split("x"))
+        for d in cases:
+            w = rayorder.detect_image_width(d)
+            want = rayorder.tile_permutation(d.shape[0], w, "cpu", th, tw) if w is not None else torch.arange(d.shape[0])
+            got = rayorder.view_tiling(d.cuda())
+            assert got is not None and torch.equal(got.cpu(), want), (shape, tuple(d.shape), w)
+    assert rayorder.view_tiling(_view(60, 60)[1].cuda()) is None                                  # fewer than 4096 rays: left alone
