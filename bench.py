@@ -494,6 +494,49 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
     return out
 
 
+class ExchangeGuard:
+    """The N-rank exchange is the one part of this file in which a rank can wait for another one. If it makes no progress (a rank that
+    failed and left the others inside a collective), every rank leaves on its own timer — before the process group's timeout would abort the
+    job. Rank 0 still prints ONE line: the headline and what had been measured when the leg started, with the leg's `error` — from a
+    snapshot serialised BEFORE the leg (the timer thread never walks a dictionary the main thread may be changing) — and every rank then
+    exits NON-ZERO: a process that has touched the GPU and cannot finish its job must not report success to the launcher (it does not
+    restart or re-exec anything; it exits)."""
+    EXIT_CODE = 3
+
+    def __init__(self, rank, world, timeout, result):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.base_line = json.dumps(result)
+        self.timer = None
+
+    def start(self):
+        if self.world > 1:
+            import threading
+            self.timer = threading.Timer(self.timeout, self.abandon, args=(f"no progress for {self.timeout} s in the {self.world}-rank exchange: leg abandoned",))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+
+    def abandon(self, reason, trace=None):
+        try:
+            if self.rank == 0:
+                try:
+                    snap = json.loads(self.base_line)
+                    snap["combined_render"] = {"error": reason, "world_size": self.world}
+                    if trace:
+                        snap["combined_render"]["trace"] = trace
+                    line = json.dumps(snap)
+                except Exception:
+                    line = self.base_line
+                print(line, flush=True)
+            else:
+                time.sleep(5.0)          # rank 0's line first: the launcher tears every rank down as soon as one of them has exited
+        finally:
+            os._exit(self.EXIT_CODE)
+
+
 def dry_run_cpu(args):
     """CPU / gloo rehearsal of the N-rank launch and of the combined-render leg's host and collective logic (no GPU, no HIP kernel: the
     per-sample fields are synthetic arrays and the select / composite are the CPU ops the tests inject)."""
@@ -516,6 +559,8 @@ def dry_run_cpu(args):
     f4[..., 0] *= 20.0
 
     def fn(lo, hi, out):
+        if os.environ.get("FOC_BENCH_STALL_RANK") == str(rank):      # test hook: a rank that never reaches the exchange (the others wait inside it)
+            time.sleep(600)
         if out is not None:
             out.copy_(f4[lo:hi])
             return out
@@ -532,11 +577,19 @@ def dry_run_cpu(args):
             return float(t.item())
         return x
     geom = {"nears": torch.full((n_rays,), 0.5), "fars": torch.full((n_rays,), 2.5)}
-    leg = combined_render_leg(rank, world, device, geom, 1, fn, barrier, max_over_ranks, chunk=chunk, ops=CpuOps, n_side=n_side, T=T)
     result = {"metric": "train_samples_per_sec", "value": None, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-              "config": {"workload": "DRY RUN on CPU/gloo: launch + combined-render collective logic only; the training step has no CPU path"},
-              "combined_render": leg}
+              "config": {"workload": "DRY RUN on CPU/gloo: launch + combined-render collective logic only; the training step has no CPU path"}}
+    guard = ExchangeGuard(rank, world, args.exchange_timeout, result)
+    guard.start()
+    try:
+        result["combined_render"] = combined_render_leg(rank, world, device, geom, 1, fn, barrier, max_over_ranks, chunk=chunk, ops=CpuOps, n_side=n_side, T=T)
+    except Exception as e:
+        import traceback
+        if world > 1:                                       # the other ranks may be inside a collective: no orderly shutdown of the group
+            guard.abandon(repr(e), traceback.format_exc()[-800:])
+        raise
+    guard.cancel()
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -894,19 +947,8 @@ def main():
         # The N-rank exchange is the one part of this file in which a rank can wait for another one. If it makes no progress (a rank that
         # failed and left the others inside a collective), every rank leaves on its own timer — before the process group's 240 s timeout
         # would abort the job — and rank 0 still prints the line with the headline and what has been measured so far.
-        abandoned = {"leg": False}
-        guard = None
-        if world > 1:
-            import threading
-
-            def give_up():
-                result["combined_render"] = {"error": f"no progress for {args.exchange_timeout} s in the {world}-rank exchange: leg abandoned", "world_size": world}
-                if rank == 0:
-                    print(json.dumps(result), flush=True)
-                os._exit(0)
-            guard = threading.Timer(args.exchange_timeout, give_up)
-            guard.daemon = True
-            guard.start()
+        guard = ExchangeGuard(rank, world, args.exchange_timeout, result)
+        guard.start()
         try:
             from focnerf_amd import raymarching as rm
             from focnerf_amd.field import half_cache_scope
@@ -957,16 +999,12 @@ def main():
                                                                            "object_rays_per_sec": 4 * VIEW * VIEW / el4,
                                                                            "note": "configs[3] on ONE GPU: 4 resident objects, per chunk 4 field evaluations + "
                                                                                    "one select/composite kernel; the N-GPU job's single-device baseline"}
-        except Exception as e:   # an extra must never take the headline number down with it
+        except Exception as e:   # at N = 1 an extra must never take the headline number down with it
             import traceback
+            if world > 1:                                    # the other ranks may be inside a collective: no orderly shutdown of the group, and
+                guard.abandon(repr(e), traceback.format_exc()[-800:])      # the launcher must see the failure — one line from rank 0, exit code 3
             result["combined_render"] = {"error": repr(e), "trace": traceback.format_exc()[-800:]}
-            abandoned["leg"] = world > 1                     # the other ranks may be inside a collective: no orderly shutdown of the group
-        if guard is not None:
-            guard.cancel()
-        if abandoned["leg"]:
-            if rank == 0:
-                print(json.dumps(result), flush=True)
-            os._exit(0)
+        guard.cancel()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         progress("cpu baseline: C oracle port")

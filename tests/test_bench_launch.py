@@ -33,3 +33,17 @@ def test_a_failing_rank_fails_the_launch():
     env["FOC_BENCH_FAIL_RANK"] = "1"
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
+
+
+def test_a_stuck_exchange_leaves_one_line_and_a_nonzero_exit():
+    """A rank that never reaches the exchange leaves the others waiting inside the collective: every rank gives the leg up on its own timer,
+    rank 0 prints ONE line — the headline, with the leg's `error` — and the launch FAILS (bench.py ExchangeGuard: exit code 3, not 0)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FOC_BENCH_STALL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--exchange-timeout", "6"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0, p.stdout[-1000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "no progress" in r["combined_render"]["error"] and r["combined_render"]["world_size"] == 2
