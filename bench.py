@@ -75,6 +75,27 @@ def pmc_traffic_bytes(op, which="bench", kernels=None):
     return total if found else None
 
 
+def profile_kernel_ms_per_step():
+    """{library kernels ms/step, torch-native kernels ms/step, source file} from the newest committed profiles/*_bench_kernel_stats.csv
+    (rocprofv3 --kernel-trace --stats of `bench.py --no-extras`), or None. A step launches k_gbin_reduce exactly once: its call count is
+    the number of steps in the profiled run (initialisation and warm-up steps included — they are the same step)."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    try:
+        rows = list(csv.DictReader(open(files[-1])))
+        steps = max(int(r["Calls"]) for r in rows if "k_gbin_reduce" in r["Name"])
+        lib = sum(float(r["TotalDurationNs"]) for r in rows if re.search(r"\bk_[a-z]|_Z\d+k_", r["Name"]))
+        rest = sum(float(r["TotalDurationNs"]) for r in rows) - lib
+        return {"profile_library_kernels_ms_per_step": lib / steps / 1e6, "profile_torch_native_ms_per_step": rest / steps / 1e6,
+                "profile_source": os.path.basename(files[-1]), "profile_steps": steps}
+    except Exception:
+        return None
+
+
 def mlp_bytes_per_row(input_dim, hidden, num_layers, train, backward=False):
     # forward (train): read input, write every hidden activation, write 16 outputs   (fp16)
     fwd = 2 * input_dim + (2 * hidden * num_layers if train else 0) + 32
@@ -726,6 +747,11 @@ def main():
                                           "(Adam, GradScaler, casts, fills, loss), measured over 5 extra steps after the timed region")
     except Exception as e:
         step_stats["kernel_only_error"] = repr(e)
+    # the same figure from the committed rocprofv3 kernel trace of this command (profiles/rNN_bench_kernel_stats.csv): sum over this library's
+    # kernels of total duration / steps — no event pairs, no gaps between launches (the event-timed sum above moves by 10 % from run to run)
+    prof = profile_kernel_ms_per_step()
+    if prof is not None:
+        step_stats.update(prof)
     result = {
         "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
@@ -788,6 +814,45 @@ def main():
                 elu = max_over_ranks(time.perf_counter() - t0)
                 result["torch_glue_path"] = {"metric": "train_samples_per_sec", "value": world * samples_per_step * nu / elu, "unit": "samples/s",
                                              "ms_per_step": 1000.0 * elu / nu, "path": "same step, NeRFRenderer.run torch glue around the same kernels"}
+            # ---- what an UNCHANGED FOCNeRF checkout gets: the same step through the public ops only, in the reference's call sequence
+            # (nerf/network_ff.py:51-134 inside nerf/renderer.py:145-221): grid_encode -> FFMLP -> trunc_exp -> SH -> cat / pad -> FFMLP (on
+            # the samples whose weight passes the threshold) -> sigmoid -> torch cumprod composite, every fusion of this library's own
+            # callers switched off (FOC_FUSED_FIELD / HEAD / TAIL / INFER = 0). The four ops are the drop-in boundary; everything between
+            # them is the reference's torch code.
+            if fused:
+                switches = ("FOC_FUSED_FIELD", "FOC_FUSED_HEAD", "FOC_FUSED_TAIL", "FOC_FUSED_INFER", "FOC_FUSED_OCC")
+                saved = {k: os.environ.get(k) for k in switches}
+                try:
+                    for k in switches:
+                        os.environ[k] = "0"
+                    for i in range(3):
+                        train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+                    barrier()
+                    timer.records.clear()
+                    timer.enabled = True
+                    nd = max(5, args.steps // 2)
+                    t0 = time.perf_counter()
+                    for i in range(nd):
+                        train_step(model, opt, scaler, *batches[i % len(batches)], fused=False)
+                    barrier()
+                    eld = max_over_ranks(time.perf_counter() - t0)
+                    timer.enabled = False
+                    kd = timer.summary()
+                    result["dropin_ops_path"] = {
+                        "metric": "train_samples_per_sec", "value": world * samples_per_step * nd / eld, "unit": "samples/s", "ms_per_step": 1000.0 * eld / nd,
+                        "vs_headline": (world * samples_per_step * nd / eld) / value,
+                        "path": "configs[1] step through the public ops only (grid_encode, ffmlp_forward x2, trunc_exp, SH encoder) in the reference's "
+                                "sequence, NeRFRenderer.run torch glue, all fusions off: what nerf/renderer.py + nerf/network_ff.py get on these ops",
+                        "op_share_of_step": {k: {"launches_per_step": v["launches"] / nd, "avg_ms": round(v["avg_ms"], 4), "share": round(v["total_ms"] / (1000.0 * eld), 4)}
+                                             for k, v in sorted(kd.items(), key=lambda kv: -kv[1]["total_ms"])},
+                        "torch_glue_share": round(max(0.0, 1.0 - sum(v["total_ms"] for v in kd.values()) / (1000.0 * eld)), 4)}
+                finally:
+                    timer.enabled = False
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
             # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
             progress("render leg (fixed-step, 800x800 views)")
             model.eval()
@@ -1007,16 +1072,27 @@ def main():
         guard.cancel()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        progress("cpu baseline: C oracle port")
-        result["cpu_baseline"] = cpu_baseline()
-        progress("cpu baseline: configs[0] torch CPU")
+        # The baseline north_star names: the reference's pure-PyTorch network (--ff off, --tcnn off: nerf/network.py) through the fixed-step
+        # renderer on the node's host cores — configs[0] by the protocol of BASELINE.md section 2, IN FULL (one whole 400 x 400 view, median of
+        # five full 4096-ray steps: ~2 min on 16 cores). oracle/torch_cpu_nerf.py is the torch-CPU restatement of that configuration, pinned to
+        # the reference's own network class + run() by tests/golden/cpu_network.npz. Nested beside it: the scalar C oracle port of this
+        # step's own kernels on a bounded sample.
+        progress("cpu baseline: configs[0] torch CPU (BASELINE.md section 2 protocol, ~2 min)")
         try:
-            # configs[0] as BASELINE.md §2 defines it: the reference's pure-PyTorch network through the fixed-step renderer, fp32 torch ops on
-            # the host cores (oracle/torch_cpu_nerf.py, pinned to the reference's own network class + run() by tests/golden/cpu_network.npz)
             from oracle import torch_cpu_nerf
-            result["cpu_baseline"]["configs0_torch_cpu"] = torch_cpu_nerf.time_baseline()
+            c0 = torch_cpu_nerf.time_baseline()
+            result["cpu_baseline"] = {"value": c0["train"]["samples_per_sec"], "unit": "samples/s", "cores": c0["cores"], "kind": "port",
+                                      "cpu_model": c0["cpu_model"], "extrapolated": c0["extrapolated"],
+                                      "sample": "configs[0], BASELINE.md section 2: " + c0["train"]["sample"] + "; render: " + c0["render"]["sample"],
+                                      "render_rays_per_sec": c0["render"]["rays_per_sec"], "render_s_per_view": c0["render"]["s_per_view"],
+                                      "train_s_per_step": c0["train"]["s_per_step"], "config": c0["config"], "protocol": c0["protocol"]}
         except Exception as e:
-            result["cpu_baseline"]["configs0_torch_cpu"] = {"error": repr(e)}
+            result["cpu_baseline"] = {"error": repr(e)}
+        progress("cpu baseline: C oracle port of this step's kernels")
+        try:
+            result["cpu_baseline"]["c_oracle_port"] = cpu_baseline()
+        except Exception as e:
+            result["cpu_baseline"]["c_oracle_port"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))

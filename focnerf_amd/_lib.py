@@ -64,6 +64,7 @@ SIGNATURES = {
                                        u32, i32, u32, i32, i32, c_vp, c_vp]),
     "foc_grid_encode_backward_workspace_bytes": (u64, [u32, u32, u32, u32, i32]),
     "foc_grid_planes_to_rows": (i32, [c_vp, c_vp, u32, u32, u32, c_vp]),
+    "foc_grid_rows_to_planes": (i32, [c_vp, c_vp, u32, u32, u32, c_vp]),
     "foc_grid_encode_backward_binned": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, c_vp, c_vp,
                                               u32, i32, u32, i32, i32, c_vp, c_vp, u64, c_vp]),
     "foc_grid_encode_forward_counted": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, c_vp, c_vp, u64, c_vp]),

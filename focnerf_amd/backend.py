@@ -167,6 +167,11 @@ class _gridencoder:
         check(lib.foc_grid_planes_to_rows(ptr(planes), ptr(rows), B, L, unit_bytes, stream_of(planes)), "grid_planes_to_rows")
 
     @staticmethod
+    def rows_to_planes(rows, planes, B, L, unit_bytes):
+        require_cuda(planes, rows); _contig(planes, rows)
+        check(lib.foc_grid_rows_to_planes(ptr(rows), ptr(planes), B, L, unit_bytes, stream_of(rows)), "grid_rows_to_planes")
+
+    @staticmethod
     def _host_entry(offsets):
         """Host copy of the (tiny, immutable) level-offset table, kept ON the tensor object so that it dies with it and a new tensor at a
         recycled address can never be mistaken for it; cached so that the backward does not synchronise on every call."""

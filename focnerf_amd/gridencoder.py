@@ -59,6 +59,7 @@ class HashGridEncode(AmpOp):
 
         reference_layout = _flag("FOCNERF_GRID_LBC")
         unit = chans * table.element_size()
+        ticket = None
         if reference_layout:
             planes = torch.empty(levels, n, chans, **like)
             _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())
@@ -66,7 +67,12 @@ class HashGridEncode(AmpOp):
         elif unit in (4, 8) and not _flag("FOCNERF_GRID_POINT_MAJOR"):
             planes = torch.empty(levels, n, chans, **like)
             encoded = torch.empty(n, levels * chans, **like)
-            _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())
+            # a forward whose table will receive a gradient lets the backward's count pass ride in its launch (the kernels' own callers do
+            # the same, focnerf_amd/field.py): the backward then starts at its scatter — 0.10 ms of a 2 M-point call
+            if dy_dx is None and dim == 3 and chans == 2 and ctx.needs_input_grad[1] and n:
+                ticket = _kernels.grid_encode_forward_counted(points, table, offsets, planes, *shape, *spec.tail())
+            if ticket is None:
+                _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())
             _kernels.planes_to_rows(planes, encoded, n, levels, unit)
         else:
             encoded = torch.empty(n, levels * chans, **like)
@@ -74,6 +80,7 @@ class HashGridEncode(AmpOp):
 
         ctx.save_for_backward(points, table, offsets, dy_dx)
         ctx.call = (shape, spec, reference_layout)
+        ctx.ticket = ticket
         return encoded
 
     @staticmethod
@@ -83,10 +90,23 @@ class HashGridEncode(AmpOp):
         n, dim, chans, levels = shape[:4]
         upstream = upstream.to(table.dtype)
         planes_in = reference_layout or _flag("FOCNERF_GRID_BWD_LBC")
-        upstream = upstream.view(n, levels, chans).permute(1, 0, 2).contiguous() if planes_in else upstream.contiguous()
+        unit = chans * table.element_size()
+        if planes_in:
+            upstream = upstream.view(n, levels, chans).permute(1, 0, 2).contiguous()
+        elif unit in (4, 8) and dim == 3 and chans == 2 and n:
+            # the binned backward reads planes faster than rows: one transpose kernel, then the [L,B,C] form (FOCNERF_GRID_BWD_ROWS=1: rows as they are)
+            if not _flag("FOCNERF_GRID_BWD_ROWS"):
+                planes = torch.empty(levels, n, chans, device=upstream.device, dtype=table.dtype)
+                _kernels.rows_to_planes(upstream.contiguous(), planes, n, levels, unit)
+                upstream, planes_in = planes, True
+            else:
+                upstream = upstream.contiguous()
+        else:
+            upstream = upstream.contiguous()
         d_table = torch.zeros_like(table)
         d_points = torch.zeros_like(points, dtype=table.dtype) if dy_dx is not None else None
-        _kernels.grid_encode_backward(upstream, points, table, offsets, d_table, *shape, dy_dx, d_points, *spec.tail(), grad_bl=not planes_in)
+        _kernels.grid_encode_backward(upstream, points, table, offsets, d_table, *shape, dy_dx, d_points, *spec.tail(), grad_bl=not planes_in,
+                                      precount=ctx.ticket)
         if d_points is not None:
             d_points = d_points.to(points.dtype)
         return d_points, d_table, None, None, None

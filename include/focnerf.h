@@ -233,6 +233,8 @@ int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, cons
 /* [L,B,C] -> [B,L*C] for C * sizeof(element) = unit_bytes in {4, 8}: the permute + copy of grid.py:57 as one kernel, so that
  * the [B,L*C] result can come from the level-major forward kernel (faster than the point-major one on incoherent points). */
 int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream);
+/* [B,L*C] -> [L,B,C]: the permute + copy of grid.py:75 (the gradient on its way into the backward kernel) as one kernel. */
+int foc_grid_rows_to_planes(const void *rows, void *planes, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream);
 
 /* gridencoder.cu:473-503  grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings,
  *       B, D, C, L, S, H, dy_dx?, grad_inputs?, gridtype, align_corners, interp)

@@ -86,3 +86,8 @@ def test_torch_hash_grid_and_near_far_agree_with_the_c_oracle():
 def test_baseline_timer_runs_on_a_tiny_sample():
     r = tcn.time_baseline(render_budget_s=0.5, train_steps=1, train_rays=8, side=16, num_steps=16, chunk=64, threads=2)
     assert r["render"]["rays_per_sec"] > 0 and r["train"]["samples_per_sec"] > 0 and r["cores"] == 2 and r["kind"] == "port"
+    assert r["extrapolated"] is True and r["train"]["steps_timed"] == 1                    # 8-ray steps are not the protocol's 64-ray (chunk) steps
+    full = tcn.time_baseline(train_steps=3, train_rays=64, side=16, num_steps=16, chunk=64, threads=2)
+    assert full["extrapolated"] is False and full["train"]["steps_timed"] == 3 and "256 of 256 rays" in full["protocol"]      # the whole view, every step
+    short = tcn.time_baseline(train_steps=5, train_rays=64, side=16, num_steps=16, chunk=64, threads=2, budget_s=0.0)          # the safety net: what was reached
+    assert short["extrapolated"] is True and short["train"]["steps_timed"] >= 1

@@ -232,6 +232,16 @@ def test_grid_encode_autograd_and_module():
     assert enc.embeddings.grad.dtype == torch.float32
     refh = oracle.grid_encode_forward(xin, to_np(enc.embeddings).astype(np.float16), to_np(enc.offsets), 3, 2, 16, S, 16)
     assert_bits_equal(to_np(yh), np.ascontiguousarray(np.transpose(refh, (1, 0, 2)).reshape(3000, 32)), "autocast forward")
+    # the module's backward hands the [B, L*C] gradient to the binned kernels as planes (one transpose) or as rows: the same records, the same sums
+    g_planes = enc.embeddings.grad.clone()
+    os.environ["FOCNERF_GRID_BWD_ROWS"] = "1"
+    try:
+        enc.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            enc(x.detach(), bound=1).float().sum().backward()
+    finally:
+        del os.environ["FOCNERF_GRID_BWD_ROWS"]
+    assert torch.equal(enc.embeddings.grad, g_planes) and g_planes.abs().sum() > 0
 
 
 def test_grad_total_variation():
