@@ -449,6 +449,18 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def resident_object_fields(device, bound, vo, vd, K, first=None, rank=0):
+    """K objects RESIDENT on one device, as the field functions `ObjectCombiner.render_view` takes (`fn(lo, hi, out)` -> packed field4 of the
+    object on rays lo:hi of the view vo / vd): FOC object-conditioned networks with their own object features, seeded — the same objects
+    whenever this is called with the same arguments (bench leg `resident_4_objects_one_gpu`; tests/test_gpu_combine.py walks the same view)."""
+    from focnerf_amd.fixedstep import render_field4
+    if first is None:
+        first = (build_foc_model(bound, device, seed=rank).eval(), foc_yolo_details(device, 1, 50 + rank))
+    objs = [first[0]] + [build_foc_model(bound, device, seed=100 + k).eval() for k in range(K - 1)]
+    yolos = [first[1]] + [foc_yolo_details(device, 1, 60 + k) for k in range(K - 1)]
+    return [(lambda lo, hi, out, m=m, y=y: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=y, out=out)) for m, y in zip(objs, yolos)]
+
+
 def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True,
                         ray_order=None):
     """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (4096-ray chunks, packed
@@ -1048,20 +1060,19 @@ def main():
             result["combined_render"]["objects_network"] = "focnerf_amd.network_foc.NeRFNetwork (object-conditioned, 48-wide colour input), one per rank"
             if world == 1:
                 # the single-GPU form of the same job: K = 4 objects RESIDENT on one device (COMBINED.py reloads a checkpoint per object per view)
-                objs = [obj_model] + [build_foc_model(bound, device, seed=100 + k).eval() for k in range(3)]
-                yolos = [obj_yolo] + [foc_yolo_details(device, 1, 60 + k) for k in range(3)]
                 from focnerf_amd.combine import ObjectCombiner
                 comb1 = ObjectCombiner(rank=0, world_size=1)
-                fns = [(lambda lo, hi, out, m=m, y=y: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=y, out=out)) for m, y in zip(objs, yolos)]
+                fns = resident_object_fields(device, bound, vo, vd, 4, first=(obj_model, obj_yolo))
                 with torch.no_grad(), half_cache_scope():
                     comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
                     barrier()
                     t0 = time.perf_counter()
-                    comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
+                    img4_4, _ = comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
                     barrier()
                 el4 = time.perf_counter() - t0
                 result["combined_render"]["resident_4_objects_one_gpu"] = {"s_per_view": el4, "rays_per_sec": VIEW * VIEW / el4,
                                                                            "object_rays_per_sec": 4 * VIEW * VIEW / el4,
+                                                                           "image_checksum": float(img4_4.double().sum().item()),
                                                                            "note": "configs[3] on ONE GPU: 4 resident objects, per chunk 4 field evaluations + "
                                                                                    "one select/composite kernel; the N-GPU job's single-device baseline"}
         except Exception as e:   # at N = 1 an extra must never take the headline number down with it

@@ -240,7 +240,7 @@ __device__ __forceinline__ void ge_forward_one(const float (&x)[D], bool oob, co
 // 8-byte aligned. ge_forward_one with every per-call decision already taken: what is left at run time is dense-or-hashed (wave-uniform,
 // decided by the caller with ge_level_hashed) and, on a hashed level, ONE lane-divergent branch (x odd: the four x+1 corners are no row
 // neighbours and take their own 4-byte loads) instead of four. Same arithmetic in the same order: bit-identical results.
-__device__ __forceinline__ bool ge_level_hashed(uint32_t hashmap_size, uint32_t resolution, uint32_t &st1, uint32_t &st2) {
+__host__ __device__ __forceinline__ bool ge_level_hashed(uint32_t hashmap_size, uint32_t resolution, uint32_t &st1, uint32_t &st2) {
     const uint32_t r1 = resolution + 1u;                 // the reference's uint32 stride walk (gridencoder.cu:70-83), D = 3
     uint32_t stride = 1u;
     st1 = st2 = 0u;
@@ -352,6 +352,12 @@ __device__ __forceinline__ void ge_forward_hash3(const float (&x)[3], bool oob, 
 }
 
 // One level of the fast shape or of the general one (`fast`: the launch-wide part of the decision, taken on the host).
+// ge_forward_hash3 addresses rows by 32-bit BYTE offsets inside the level: levels of up to 2^30 rows of 4 bytes; a hashed level must
+// have a power-of-two size (its `% hashmap_size` is a mask there). Within it, levels of at most 2^22 rows take the 24-bit multiplies.
+__host__ __device__ __forceinline__ bool ge_hash3_admits(uint32_t hashmap_size, bool hashed) {
+    return (!hashed || (hashmap_size & (hashmap_size - 1u)) == 0u) && hashmap_size <= (1u << 30);
+}
+
 template <typename T, uint32_t D, uint32_t C>
 __device__ __forceinline__ void ge_forward_level(const float (&x)[D], bool oob, const T *__restrict__ grid, uint32_t off0, uint32_t hashmap_size, float scale,
                                                  uint32_t resolution, T *__restrict__ out, T *__restrict__ dy, uint32_t gridtype, bool align_corners,
@@ -361,7 +367,7 @@ __device__ __forceinline__ void ge_forward_level(const float (&x)[D], bool oob, 
         if (pairs == 2u && aligned) {
             uint32_t st1, st2;
             const bool hashed = ge_level_hashed(hashmap_size, resolution, st1, st2);
-            if ((!hashed || (hashmap_size & (hashmap_size - 1u)) == 0u) && hashmap_size <= (1u << 30)) {      // 32-bit byte offsets inside the level
+            if (ge_hash3_admits(hashmap_size, hashed)) {
                 ge_forward_hash3(x, oob, reinterpret_cast<const uint32_t *>(grid) + off0, hashmap_size, hashed, st1, st2, scale,
                                  reinterpret_cast<__half *>(out));
                 return;
@@ -1680,6 +1686,15 @@ int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, cons
     FocDeviceGuard foc_guard_(stream);
     (void)offsets_host;
     return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, true, stream);
+}
+
+int foc_grid_forward_index_path(uint32_t level_rows, uint32_t resolution, uint32_t level_offset_rows) {
+    // which index arithmetic the fp16 / D = 3 / C = 2 / hash-grid forward uses for a level (host mirror of ge_forward_level's decision)
+    if (((level_offset_rows | level_rows) & 1u) != 0u) return 0;
+    uint32_t st1, st2;
+    const bool hashed = ge_level_hashed(level_rows, resolution, st1, st2);
+    if (!ge_hash3_admits(level_rows, hashed)) return 0;
+    return level_rows <= (1u << 22) ? 2 : 1;
 }
 
 int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream) {

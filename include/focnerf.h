@@ -233,6 +233,10 @@ int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, cons
 /* [L,B,C] -> [B,L*C] for C * sizeof(element) = unit_bytes in {4, 8}: the permute + copy of grid.py:57 as one kernel, so that
  * the [B,L*C] result can come from the level-major forward kernel (faster than the point-major one on incoherent points). */
 int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream);
+/* Host-only query (tests): the index arithmetic foc_grid_encode_forward uses for one level of an fp16, D = 3, C = 2 hash grid —
+ * 2: 32-bit byte offsets with 24-bit multiplies (levels of at most 2^22 rows: every NeRF grid), 1: 32-bit byte offsets, generic
+ * multiplies (up to 2^30 rows; a hashed level must have a power-of-two size), 0: the general 64-bit form (everything else). */
+int foc_grid_forward_index_path(uint32_t level_rows, uint32_t resolution, uint32_t level_offset_rows);
 /* [B,L*C] -> [L,B,C]: the permute + copy of grid.py:75 (the gradient on its way into the backward kernel) as one kernel. */
 int foc_grid_rows_to_planes(const void *rows, void *planes, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream);
 

@@ -53,6 +53,22 @@ def test_argument_validation_needs_no_gpu():
     assert rc == 1
 
 
+def test_forward_index_path_admission_needs_no_gpu():
+    """Which index arithmetic the fp16 D = 3 C = 2 forward takes per level (csrc/gridencoder.hip ge_forward_level): 24-bit multiplies up to
+    2^22 rows, 32-bit byte offsets up to 2^30 rows (hashed levels: power-of-two sizes only), the general form beyond — the guard itself,
+    asked on the host (a 2^30-row level is 4 GB of table: the GPU tests stop at 2^23)."""
+    from focnerf_amd import _lib
+    path = _lib.lib.foc_grid_forward_index_path
+    assert path(4920, 16, 0) == 2                              # dense level 0 of the NeRF grid
+    assert path(1 << 19, 2048, 373248) == 2                    # a hashed 2^19-row level
+    assert path(1 << 22, 2048, 0) == 2 and path((1 << 22) + 8, 160, 0) == 1      # the 24-bit limit (a dense level of 2^22 + 8 rows: generic offsets)
+    assert path(1 << 23, 2048, 0) == 1 and path(1 << 30, 4096, 0) == 1
+    assert path((1 << 30) + 8, 4096, 0) == 0                   # beyond 2^30 rows: byte offsets no longer fit 32 bits
+    assert path(1 << 31, 4096, 0) == 0
+    assert path((1 << 19) + 8, 2048, 0) == 0                   # hashed, not a power of two: `%` is no mask
+    assert path(1 << 19, 2048, 1) == 0 and path((1 << 19) + 1, 40, 0) == 0       # odd offset / odd size: row pairs not 8-byte aligned
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch

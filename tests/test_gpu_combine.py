@@ -271,3 +271,54 @@ def test_resident_objects_through_the_combiner_equal_the_reload_loop(tmp_path):
         assert torch.equal(img_a[q], i_ref), f"background {bg}"
         assert torch.equal(dep_a, d_ref)
     assert not torch.equal(fields[0][0], fields[1][0])               # the objects do differ
+
+
+def test_combine_at_baseline_size_walked_in_chunks():
+    """configs[3] at BASELINE size on one device: an 800 x 800 view x 512 samples, K = 4 resident objects (the bench's
+    `resident_4_objects_one_gpu` objects and view), walked in 4096-ray chunks by ObjectCombiner.render_view. Properties that do not need
+    an oracle of this size: (1) every chunk's rows of the view's image / depth are `combine_packed` of that chunk's four fields, bit for
+    bit (checked on a spread of chunks incl. the ragged last one); (2) an object that ties with an earlier one on EVERY sample — same
+    densities, other colours — never wins a sample (COMBINED.py:247-251: strict `>`, the first checkpoint keeps ties); (3) the image
+    checksum is the one bench.py reports for the leg."""
+    import bench
+    from focnerf_amd import raymarching as rm, synthetic
+    from focnerf_amd.combine import ObjectCombiner, combine_packed
+    from focnerf_amd.field import half_cache_scope
+    from focnerf_amd.rayorder import view_tiling
+    dev = torch.device("cuda", 0)
+    poses, intr = bench.make_training_rays(dev, 1, 8, seed=0)
+    rays_o, rays_d = synthetic.get_rays(poses[:1], intr, bench.VIEW, bench.VIEW)
+    vo, vd = rays_o[0].contiguous(), rays_d[0].contiguous()
+    order = view_tiling(vd)
+    vo, vd = vo.index_select(0, order), vd.index_select(0, order)             # the bench walks the view in 8 x 8 pixel tiles
+    N, T, chunk = bench.VIEW * bench.VIEW, bench.NUM_STEPS, 4096
+    fns = bench.resident_object_fields(dev, 1, vo, vd, 4)
+    with torch.no_grad(), half_cache_scope():
+        model0 = bench.build_model(1, dev, seed=0)
+        vn, vf = rm.near_far_from_aabb(vo, vd, model0.aabb_infer, model0.min_near)
+        comb = ObjectCombiner(rank=0, world_size=1)
+        img4, depth = comb.render_view(fns, N, vn, vf, T, max_ray_batch=chunk)
+        assert img4.shape == (2, N, 4) and depth.shape == (N,)
+        n_chunks = -(-N // chunk)
+        for c in (0, 1, n_chunks // 2, n_chunks - 2, n_chunks - 1):
+            lo, hi = c * chunk, min((c + 1) * chunk, N)
+            fields = [fn(lo, hi, None).view(hi - lo, T, 4) for fn in fns]
+            i_ref, d_ref = combine_packed(fields, vn[lo:hi], vf[lo:hi], (1.0, 0.0))
+            assert torch.equal(img4[:, lo:hi], i_ref) and torch.equal(depth[lo:hi].nan_to_num(), d_ref.nan_to_num()), f"chunk {c}"
+        assert (img4[0, :, :3] < 0.99).any() and img4[0, :, 3].max() > 0.5
+        checksum = float(img4.double().sum().item())
+        # (2) ties: object 2 := object 0's densities with the colours inverted — it must not change a single value anywhere
+        def tied(lo, hi, out):
+            f = fns[0](lo, hi, out)
+            f.view(-1, 4)[:, 1:].mul_(-1).add_(1)
+            return f
+        img4_t, depth_t = comb.render_view([fns[0], fns[1], tied, fns[3]], N, vn, vf, T, max_ray_batch=chunk)
+        ref4, refd = comb.render_view([fns[0], fns[1], fns[3]], N, vn, vf, T, max_ray_batch=chunk)
+        assert torch.equal(img4_t, ref4) and torch.equal(depth_t.nan_to_num(), refd.nan_to_num()), "a later object tying on every sample must never win one"
+        lo, hi = 200 * chunk // 2, 200 * chunk // 2 + chunk
+        f0, ft = fns[0](lo, hi, None).clone(), tied(lo, hi, None).clone()
+        _, _, merged = combine_packed([f0, ft], vn[lo:hi], vf[lo:hi], (1.0,), want_merged=True)
+        assert torch.equal(merged, f0) and not torch.equal(ft[..., 1:], f0[..., 1:])
+        # (3) what bench.py reports for the same objects and view
+        img4_b, _ = ObjectCombiner(rank=0, world_size=1).render_view(bench.resident_object_fields(dev, 1, vo, vd, 4), N, vn, vf, T, max_ray_batch=chunk)
+        assert float(img4_b.double().sum().item()) == checksum

@@ -627,3 +627,43 @@ def test_factored_records_agree_with_the_two_corner_records(monkeypatch):
     for l in range(L):
         want = grad[l][inb].astype(np.float64).sum(0)
         np.testing.assert_allclose(b[off[l]:off[l + 1]].astype(np.float64).sum(0), want, atol=0.5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_levels_of_2_to_the_23_rows_take_the_generic_index_path(dtype):
+    """log2_hashmap_size = 23, two levels (resolutions 256 and 512: both hashed, 2^23 rows each): beyond the 2^22 rows of the forward's
+    24-bit index arithmetic (csrc/gridencoder.hip ge_forward_hash3) — the 32-bit byte-offset form with full multiplies for fp16 tables,
+    ge_forward_one for fp32 — and beyond the 64 x 8192 rows the binned backward partitions (scattered-atomic kernel). Forward bit-exact
+    against the oracle in both output layouts, backward within the atomic path's tolerances, per-level checksums."""
+    from focnerf_amd._lib import lib
+    D, C, L, H, lh, desired = 3, 2, 2, 256, 23, 512
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 11, dtype)
+    assert [int(off[i + 1] - off[i]) for i in range(L)] == [1 << 23, 1 << 23]
+    assert lib.foc_grid_forward_index_path(1 << 23, 256, 0) == 1 and lib.foc_grid_forward_index_path(1 << 23, 512, 1 << 23) == 1
+    B = 6000
+    x = _points(B, D, 12)
+    ref = oracle.grid_encode_forward(x, table, off, D, C, L, S, H, False, 0, False, 0, acc_mode=1)
+    tdt = torch.float32 if dtype == np.float32 else torch.float16
+    xt, tt, ot = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda()
+    be = _be()
+    out = torch.empty(L, B, C, dtype=tdt, device="cuda")
+    be.grid_encode_forward(xt, tt, ot, out, B, D, C, L, S, H, None, 0, False, 0)
+    assert_bits_equal(to_np(out), ref, "outputs [L,B,C]")
+    out2 = torch.empty(B, L * C, dtype=tdt, device="cuda")
+    be.grid_encode_forward(xt, tt, ot, out2, B, D, C, L, S, H, None, 0, False, 0, out_bl=True)
+    assert np.array_equal(to_np(out2), np.transpose(ref, (1, 0, 2)).reshape(B, L * C))
+    assert np.abs(ref.astype(np.float32)).max() > 0.5
+    # the counted forward declines (no binned backward for these tables) and the backward takes the atomic kernel
+    assert be.grid_encode_forward_counted(xt, tt, ot, out, B, D, C, L, S, H, 0, False, 0) is None
+    grad = (np.random.default_rng(13).standard_normal((L, B, C)) * 0.1).astype(dtype)
+    ge_ref = oracle.grid_encode_backward(grad, x, off, int(off[-1]), D, C, L, S, H, None, 0, False, 0)
+    ge = torch.zeros(int(off[-1]), C, dtype=tdt, device="cuda")
+    be.grid_encode_backward(torch.from_numpy(grad).cuda(), xt, tt, ot, ge, B, D, C, L, S, H, None, None, 0, False, 0, grad_bl=False)
+    got, want = to_np(ge).astype(np.float32), ge_ref.astype(np.float32)
+    if dtype == np.float32:
+        np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
+    else:
+        assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max() + 1e-3
+    inb = np.all((x >= 0) & (x <= 1), axis=1)
+    for l in range(L):
+        np.testing.assert_allclose(got[off[l]:off[l + 1]].astype(np.float64).sum(0), grad[l][inb].astype(np.float64).sum(0), atol=1e-3 if dtype == np.float32 else 0.5)
