@@ -38,6 +38,7 @@ SIGNATURES = {
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_field": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
+    "foc_guard_pick_device": (i32, [i32, i32, i32, i32]),
     "foc_grid_forward_index_path": (i32, [u32, u32, u32]),
     "foc_view_tile_order": (i32, [c_vp, u32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_occ_tail_forward": (i32, [c_vp, c_vp, u32, c_vp, c_vp, u32, u32, f32, f32, c_vp, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

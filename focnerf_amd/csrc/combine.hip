@@ -192,9 +192,14 @@ __global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restric
 
 extern "C" {
 
+int foc_guard_pick_device(int stream_is_null, int stream_device, int pointer_device, int current_device) {
+    return foc_guard_pick(stream_is_null != 0, stream_device, pointer_device, current_device);
+}
+
+
 int foc_combine_select_composite(const float *const *fields4, uint32_t K, const float *nears, const float *fars, uint32_t N, uint32_t T,
                                  const float *bgs, uint32_t n_bg, float *image4, float *depth, float *merged4, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, nears);
     FOC_REQUIRE(K >= 1 && K <= FOC_COMBINE_MAX_OBJECTS, FOC_E_INVALID, "combine_select_composite: 1 <= K <= %d objects per call (got %u)",
                 FOC_COMBINE_MAX_OBJECTS, K);
     FOC_REQUIRE(n_bg >= 1 && n_bg <= 2 && bgs, FOC_E_INVALID, "combine_select_composite: one or two backgrounds");
@@ -214,7 +219,7 @@ int foc_combine_select_composite(const float *const *fields4, uint32_t K, const 
 }
 
 int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, field4);
     FOC_REQUIRE(n == 0 || (field4 && acc4), FOC_E_INVALID, "combine_select4: null pointer");
     FOC_REQUIRE((((uintptr_t)field4 | (uintptr_t)acc4) & 15) == 0, FOC_E_INVALID, "combine_select4: fields must be 16-byte aligned");
     if (n == 0) return FOC_OK;
@@ -229,7 +234,7 @@ const char *foc_last_error(void) { return g_err; }
 const char *foc_arch(void) { return "gfx950"; }
 
 int foc_combine_select(const float *dens, const float *rgb, float *max_dens, float *best_rgb, uint64_t n, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, dens);
     FOC_REQUIRE(n == 0 || (dens && rgb && max_dens && best_rgb), FOC_E_INVALID, "combine_select: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_select, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rgb, max_dens, best_rgb, n);
@@ -238,7 +243,7 @@ int foc_combine_select(const float *dens, const float *rgb, float *max_dens, flo
 }
 
 int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint64_t n, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, dens);
     FOC_REQUIRE(n == 0 || (dens && keys), FOC_E_INVALID, "combine_pack_keys: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_pack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dens, rank, keys, n);
@@ -247,7 +252,7 @@ int foc_combine_pack_keys(const float *dens, uint32_t rank, uint64_t *keys, uint
 }
 
 int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb, float *max_dens, float *masked_rgb, uint64_t n, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, keys);
     FOC_REQUIRE(n == 0 || (keys && rgb && max_dens && masked_rgb), FOC_E_INVALID, "combine_unpack: null pointer");
     if (n == 0) return FOC_OK;
     hipLaunchKernelGGL(k_combine_unpack, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, rank, rgb, max_dens, masked_rgb, n);
@@ -257,7 +262,7 @@ int foc_combine_unpack(const uint64_t *keys, uint32_t rank, const float *rgb, fl
 
 int foc_composite_fixed_steps(const float *sigmas, const float *rgbs, const float *nears, const float *fars, uint32_t N, uint32_t T,
                               float bg, float *image4, float *depth, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, sigmas);
     FOC_REQUIRE(N == 0 || (sigmas && rgbs && nears && fars && image4 && depth), FOC_E_INVALID, "composite_fixed_steps: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "composite_fixed_steps: T must be >= 2");
     if (N == 0) return FOC_OK;

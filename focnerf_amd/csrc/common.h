@@ -31,15 +31,37 @@ void foc_set_error(const char *fmt, ...);
         }                                                                          \
     } while (0)
 
-// Every entry point runs with the device of ITS stream current: a caller holding `cuda:1` tensors while device 0 is current (K resident
-// objects on several GPUs of one process, focnerf_amd/checkpoint.py load_objects) gets the occupancy queries, LDS opt-ins and
-// per-device statics of the right device. Two host calls (hipGetDevice, hipStreamGetDevice) when the devices already agree.
+// Every entry point runs with the device of ITS call current: a caller holding `cuda:1` tensors while device 0 is current (K resident
+// objects on several GPUs of one process, focnerf_amd/checkpoint.py load_objects) gets the occupancy queries, LDS opt-ins, per-device
+// statics and — above all — the launches of the right device. Which device that is:
+//   * a non-null stream belongs to one device: hipStreamGetDevice;
+//   * the NULL stream exists on every device (torch's default stream is the null handle everywhere), so it says nothing: the device
+//     is then the one the first pointer argument lives on (hipPointerGetAttributes) — what the Python binding and the extension shims
+//     already do on their side by making the tensors' device current before they call in;
+//   * neither (null stream, no device pointer): the current device.
+// foc_guard_pick is that rule as a pure function (host-only unit test: foc_guard_pick_device).
+static inline int foc_guard_pick(bool stream_is_null, int stream_device, int pointer_device, int current_device) {
+    if (!stream_is_null && stream_device >= 0) return stream_device;
+    if (pointer_device >= 0) return pointer_device;
+    return current_device;
+}
 struct FocDeviceGuard {
     int prev = -1;
-    explicit FocDeviceGuard(void *stream) {
-        int cur = 0, want = 0;
+    explicit FocDeviceGuard(void *stream, const void *first_pointer = nullptr) {
+        static int n_devices = -1;                         // one visible device: nothing to choose (and no pointer query per call)
+        if (n_devices < 0 && hipGetDeviceCount(&n_devices) != hipSuccess) { (void)hipGetLastError(); n_devices = 0; }
+        if (n_devices == 1) return;
+        int cur = 0;
         if (hipGetDevice(&cur) != hipSuccess) return;
-        if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &want) != hipSuccess) { (void)hipGetLastError(); return; }
+        int sdev = -1, pdev = -1;
+        if (stream != nullptr) {
+            if (hipStreamGetDevice(static_cast<hipStream_t>(stream), &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = -1; }
+        } else if (first_pointer != nullptr) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, first_pointer) == hipSuccess && attr.type == hipMemoryTypeDevice) pdev = attr.device;
+            else (void)hipGetLastError();                  // host memory, or not a HIP allocation: no opinion
+        }
+        const int want = foc_guard_pick(stream == nullptr, sdev, pdev, cur);
         if (want != cur && hipSetDevice(want) == hipSuccess) prev = cur;
     }
     ~FocDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }

@@ -232,7 +232,7 @@ extern "C" {
 
 int foc_mark_untrained_grid(const float *poses, uint32_t B, float fx, float fy, float cx, float cy, float bound, uint32_t C, uint32_t H,
                             float *density_grid, int32_t *count, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, poses);
     int rc = dg_check("mark_untrained_grid", C, H);
     if (rc) return rc;
     FOC_REQUIRE(density_grid && (poses || B == 0), FOC_E_INVALID, "mark_untrained_grid: null pointer");
@@ -247,7 +247,7 @@ int foc_mark_untrained_grid(const float *poses, uint32_t B, float fx, float fy, 
 }
 
 int foc_grid_cells_xyz(uint32_t C, uint32_t H, float bound, const float *jitter, float *xyzs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, xyzs);
     int rc = dg_check("grid_cells_xyz", C, H);
     if (rc) return rc;
     FOC_REQUIRE(xyzs, FOC_E_INVALID, "grid_cells_xyz: null pointer");
@@ -265,7 +265,7 @@ uint64_t foc_grid_update_sample_workspace_bytes(uint32_t C, uint32_t H) {
 
 int foc_grid_update_sample(const float *density_grid, uint32_t C, uint32_t H, float bound, uint32_t N, const int32_t *rand_coords, const float *rand_pick,
                            const float *jitter, int32_t *indices, float *xyzs, void *workspace, uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, density_grid);
     int rc = dg_check("grid_update_sample", C, H);
     if (rc) return rc;
     if (N == 0) return FOC_OK;
@@ -293,7 +293,7 @@ uint64_t foc_grid_update_apply_workspace_bytes(uint32_t C, uint32_t H) { return 
 
 int foc_grid_update_apply(float *density_grid, uint32_t C, uint32_t H, const float *sigmas, const int32_t *indices, uint32_t Mc, float density_scale,
                           float decay, float density_thresh, uint8_t *bitfield, float *mean_out, void *workspace, uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, density_grid);
     int rc = dg_check("grid_update_apply", C, H);
     if (rc) return rc;
     FOC_REQUIRE(density_grid && sigmas && bitfield && workspace, FOC_E_INVALID, "grid_update_apply: null pointer");

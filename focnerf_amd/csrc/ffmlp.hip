@@ -1703,7 +1703,7 @@ extern "C" {
 
 int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                       uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *forward_buffer, void *outputs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     // forward_buffer == NULL: nothing is kept for the backward pass (foc_ffmlp_backward re-evaluates the activations)
     if (!forward_buffer) return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream);
     return mlp_fwd<true>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, forward_buffer, outputs, stream);
@@ -1711,7 +1711,7 @@ int foc_ffmlp_forward(const void *inputs, const void *weights, uint32_t B, uint3
 
 int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                         uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *inference_buffer, void *outputs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     return mlp_fwd<false>(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, inference_buffer, outputs, stream);
 }
 
@@ -1760,21 +1760,21 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                        int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     return mlp_bwd_entry(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                          calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, 0, stream);
 }
 
 int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                              uint32_t num_layers, uint32_t activation, uint32_t output_activation, void *outputs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs_planar);
     return mlp_fwd<false>(inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, nullptr, outputs, stream, 1);
 }
 
 int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                               uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                               void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     return mlp_bwd_entry(grad, inputs_planar, weights, nullptr, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                          calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
 }
@@ -1783,7 +1783,7 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
                              const void *sigma_weights, uint32_t sigma_layers,
                              const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B, float *sigma,
                              float *rgb, const void *obj_feat, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, enc);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(enc && dirs && sigma_weights && color_weights && rgb, FOC_E_INVALID, "nerf_field_inference: null pointer");
     FOC_REQUIRE(hidden_dim == 64 && dir_div >= 1, FOC_E_INVALID, "nerf_field_inference: hidden_dim must be 64 (got %u)", hidden_dim);
@@ -1804,7 +1804,7 @@ int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs,
 // The colour network of the fixed-step training path, fed from the sigma network's output rows and a per-ray SH table (input mode 2).
 int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *weights, uint32_t B, uint32_t hidden_dim,
                            uint32_t num_layers, uint32_t activation, void *outputs, uint32_t out_width, const void *obj_feat, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     int rc = mlp_check("color_head_forward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     if (B == 0) return FOC_OK;
@@ -1819,7 +1819,7 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
                             uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
                             uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
     FOC_REQUIRE(hidden_dim == 64 && (num_layers == 2 || num_layers == 3) && samples_per_ray >= 1, FOC_E_INVALID,

@@ -612,7 +612,7 @@ extern "C" {
 
 int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *nears, const float *fars, const float *aabb, const float *noise,
                      uint32_t N, uint32_t T, float bound, float *xyzs, float *enc_in, void *ray_sh, uint32_t ray_block, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_o);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && nears && fars && aabb && (xyzs || enc_in), FOC_E_INVALID, "fixed_sample: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_sample: T must be >= 2");
@@ -627,7 +627,7 @@ int foc_fixed_sample(const float *rays_o, const float *rays_d, const float *near
 int foc_fixed_head_forward(const void *h, const float *rays_d, const float *nears, const float *fars, const float *noise, uint32_t N, uint32_t T,
                            float density_scale, float *sigma, float *trans, float *weights, float *weights_sum, float *depth, void *cin,
                            const void *obj_feat, uint32_t cin_width, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(h && rays_d && nears && fars && sigma && trans && weights && weights_sum && depth, FOC_E_INVALID, "fixed_head_forward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_forward: T must be >= 2");
@@ -642,7 +642,7 @@ int foc_fixed_head_forward(const void *h, const float *rays_d, const float *near
 int foc_fixed_head_backward(const void *h, const float *sigma, const float *trans, const float *nears, const float *fars, const float *noise,
                             const float *grad_w, const float *grad_ws, const float *grad_depth, const void *grad_cin, uint32_t N, uint32_t T,
                             float density_scale, void *grad_h, uint32_t cin_width, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(h && sigma && trans && nears && fars && grad_h, FOC_E_INVALID, "fixed_head_backward: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_head_backward: T must be >= 2");
@@ -655,7 +655,7 @@ int foc_fixed_head_backward(const void *h, const float *sigma, const float *tran
 
 int foc_fixed_composite_forward(const void *c, const float *weights, const float *bg_ray, float bg_scalar, uint32_t N, uint32_t T, float thresh,
                                 float *image, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, c);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c && weights && image, FOC_E_INVALID, "fixed_composite_forward: null pointer");
     hipLaunchKernelGGL(k_fs_composite_fwd, dim3(foc_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)c, weights, bg_ray, bg_scalar, N, T,
@@ -666,7 +666,7 @@ int foc_fixed_composite_forward(const void *c, const float *weights, const float
 
 int foc_fixed_composite_backward(const float *grad_image, const void *c, const float *weights, const float *bg_ray, float bg_scalar, uint32_t N,
                                  uint32_t T, float thresh, void *grad_c, float *grad_w, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad_image);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(grad_image && c && weights && grad_c && grad_w, FOC_E_INVALID, "fixed_composite_backward: null pointer");
     hipLaunchKernelGGL(k_fs_composite_bwd, dim3(foc_grid_1d((uint64_t)N * T, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, grad_image,
@@ -678,7 +678,7 @@ int foc_fixed_composite_backward(const float *grad_image, const void *c, const f
 int foc_fixed_tail_forward(const void *h, const void *c, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
                            uint32_t N, uint32_t T, float density_scale, float thresh, float *sigma, float *trans, float *weights, float *weights_sum,
                            float *depth, float *image, uint32_t c_width, float *ray_sumsq, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_forward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(h && c && nears && fars && sigma && trans && weights && weights_sum && depth && image, FOC_E_INVALID, "fixed_tail_forward: null pointer");
@@ -694,7 +694,7 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
                             const float *weights, const float *nears, const float *fars, const float *noise, const float *bg_ray, float bg_scalar,
                             uint32_t N, uint32_t T, float density_scale, float thresh, void *grad_c, void *grad_h0, uint32_t c_width, const float *grad_sumsq,
                             void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad_image);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "fixed_tail_backward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(grad_image && c && sigma && trans && weights && nears && fars && grad_c && grad_h0, FOC_E_INVALID, "fixed_tail_backward: null pointer");
@@ -710,7 +710,7 @@ int foc_fixed_tail_backward(const float *grad_image, const float *grad_ws, const
 int foc_fixed_render_inference(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
                                float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
                                float *rgb_masked, uint32_t ray_block, float *sigma_raymajor, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, sigma);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(sigma && rgb && nears && fars && image && depth && weights_sum, FOC_E_INVALID, "fixed_render_inference: null pointer");
     FOC_REQUIRE(T >= 2, FOC_E_INVALID, "fixed_render_inference: T must be >= 2");
@@ -732,7 +732,7 @@ int foc_fixed_render_inference(const float *sigma, const float *rgb, const float
 int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *nears, const float *fars, const float *noise, const float *bg_ray,
                          float bg_scalar, uint32_t N, uint32_t T, float density_scale, float thresh, float *image, float *depth, float *weights_sum,
                          float *field4, uint32_t ray_block, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, sigma);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(sigma && rgb && nears && fars && field4, FOC_E_INVALID, "fixed_field_pack: null pointer");
     FOC_REQUIRE((image && depth && weights_sum) || (!image && !depth && !weights_sum), FOC_E_INVALID,
@@ -754,7 +754,7 @@ int foc_fixed_field_pack(const float *sigma, const float *rgb, const float *near
 }
 
 int foc_view_tile_order(const float *rays_d, uint32_t N, uint32_t tile_h, uint32_t tile_w, int64_t *perm, void *state16, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_d);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_d && perm && state16, FOC_E_INVALID, "view_tile_order: null pointer");
     FOC_REQUIRE(tile_h >= 1 && tile_w >= 1 && tile_h * tile_w <= 4096, FOC_E_INVALID, "view_tile_order: tile %u x %u", tile_h, tile_w);

@@ -14,14 +14,15 @@
 
 #define FQ_ROWS 256u
 
+// R = rows per tile: 256, fewer for wide inputs so that the staged tile stays within 32 KiB of LDS (fq_tile_rows)
 __global__ void __launch_bounds__(256) k_freq_fwd(const float *__restrict__ inputs, uint32_t B, uint32_t D, uint32_t C,
-                                                  float *__restrict__ outputs) {
-    extern __shared__ float s_in[];                        // [FQ_ROWS][D]
+                                                  float *__restrict__ outputs, uint32_t R) {
+    extern __shared__ float s_in[];                        // [R][D]
     const float HALF_PI = 3.141592653589793f / 2;
-    const uint32_t n_tiles = (B + FQ_ROWS - 1) / FQ_ROWS;
+    const uint32_t n_tiles = (B + R - 1) / R;
     const uint32_t step_r = 256u / C, step_c = 256u % C;   // what a stride of 256 elements does to (row, column)
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t row0 = tile * FQ_ROWS, rows = min(FQ_ROWS, B - row0);
+        const uint32_t row0 = tile * R, rows = min(R, B - row0);
         const float *in = inputs + (uint64_t)row0 * D;
         __syncthreads();                                   // the previous tile's reads of s_in are done
         for (uint32_t i = threadIdx.x; i < rows * D; i += 256) s_in[i] = in[i];
@@ -63,23 +64,28 @@ __global__ void __launch_bounds__(256) k_freq_bwd(const float *__restrict__ grad
     }
 }
 
+// rows of a forward tile: 256 while 256 x D floats fit 32 KiB (D <= 32: every NeRF encoder), else as many as do (the reference takes
+// any input dimension, freqencoder.cu:30-94; one row of up to 8192 floats still fits)
+static uint32_t fq_tile_rows(uint32_t D) { return D <= 32u ? FQ_ROWS : (8192u / D > 0u ? 8192u / D : 1u); }
+
 extern "C" {
 
 int foc_freq_encode_forward(const float *inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float *outputs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && outputs, FOC_E_INVALID, "freq_encode_forward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_forward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);
-    FOC_REQUIRE(D <= 32, FOC_E_INVALID, "freq_encode_forward: input dimension %u is beyond the tile kernel (<= 32)", D);
-    hipLaunchKernelGGL(k_freq_fwd, dim3(foc_grid_1d((uint64_t)foc_div_up(B, FQ_ROWS) * 256, 256)), dim3(256), FQ_ROWS * D * sizeof(float), (hipStream_t)stream, inputs,
-                       B, D, C, outputs);
+    FOC_REQUIRE(D <= 8192, FOC_E_INVALID, "freq_encode_forward: input dimension %u is beyond what one tile row holds (<= 8192)", D);
+    const uint32_t R = fq_tile_rows(D);
+    hipLaunchKernelGGL(k_freq_fwd, dim3(foc_grid_1d((uint64_t)foc_div_up(B, R) * 256, 256)), dim3(256), (size_t)R * D * sizeof(float), (hipStream_t)stream, inputs,
+                       B, D, C, outputs, R);
     FOC_CHECK_LAUNCH("freq_encode_forward");
     return FOC_OK;
 }
 
 int foc_freq_encode_backward(const float *grad, const float *outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
                              float *grad_inputs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && outputs && grad_inputs, FOC_E_INVALID, "freq_encode_backward: null pointer");
     FOC_REQUIRE(D >= 1 && C == D + 2 * D * deg, FOC_E_INVALID, "freq_encode_backward: C must equal D + 2*D*deg (D=%u deg=%u C=%u)", D, deg, C);

@@ -1675,7 +1675,7 @@ extern "C" {
 int foc_grid_encode_forward(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
                             uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
                             uint32_t interp, int dtype, const int32_t *offsets_host, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     (void)offsets_host;
     return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, false, stream);
 }
@@ -1683,7 +1683,7 @@ int foc_grid_encode_forward(const float *inputs, const void *embeddings, const i
 int foc_grid_encode_forward_bl(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D,
                                uint32_t C, uint32_t L, float S, uint32_t H, void *dy_dx, uint32_t gridtype, int align_corners,
                                uint32_t interp, int dtype, const int32_t *offsets_host, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     (void)offsets_host;
     return ge_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, true, stream);
 }
@@ -1698,7 +1698,7 @@ int foc_grid_forward_index_path(uint32_t level_rows, uint32_t resolution, uint32
 }
 
 int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, planes);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(planes && rows, FOC_E_INVALID, "grid_planes_to_rows: null pointer");
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && (unit_bytes == 4 || unit_bytes == 8), FOC_E_INVALID, "grid_planes_to_rows: L in [1,%d], 4- or 8-byte units", GE_MAX_LEVELS);
@@ -1710,7 +1710,7 @@ int foc_grid_planes_to_rows(const void *planes, void *rows, uint32_t B, uint32_t
 }
 
 int foc_grid_rows_to_planes(const void *rows, void *planes, uint32_t B, uint32_t L, uint32_t unit_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rows);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(planes && rows, FOC_E_INVALID, "grid_rows_to_planes: null pointer");
     FOC_REQUIRE(L >= 1 && L <= GE_MAX_LEVELS && (unit_bytes == 4 || unit_bytes == 8), FOC_E_INVALID, "grid_rows_to_planes: L in [1,%d], 4- or 8-byte units", GE_MAX_LEVELS);
@@ -1725,7 +1725,7 @@ int foc_grid_encode_backward(const void *grad, const float *inputs, const void *
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
                              const int32_t *offsets_host, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     (void)offsets_host; (void)embeddings;
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(grad && inputs && offsets && grad_embeddings, FOC_E_INVALID, "grid_encode_backward: null pointer");
@@ -1785,7 +1785,7 @@ static int gb_check(uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uin
 int foc_grid_encode_backward_count(const float *inputs, const int32_t *offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, const int32_t *offsets_host, void *workspace,
                                    uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && offsets && workspace && offsets_host, FOC_E_INVALID, "grid_encode_backward_count: null pointer");
     const int rc = gb_check(B, D, C, L, S, H, gridtype, interp, dtype, offsets_host, workspace_bytes);
@@ -1798,7 +1798,7 @@ int foc_grid_encode_backward_count(const float *inputs, const int32_t *offsets, 
 int foc_grid_encode_forward_counted(const float *inputs, const void *embeddings, const int32_t *offsets, void *outputs, uint32_t B, uint32_t D, uint32_t C,
                                     uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
                                     const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && embeddings && offsets && outputs && workspace && offsets_host, FOC_E_INVALID, "grid_encode_forward_counted: null pointer");
     const int rc = gb_check(B, D, C, L, S, H, gridtype, interp, dtype, offsets_host, workspace_bytes);
@@ -1848,7 +1848,7 @@ int foc_grid_encode_backward_binned(const void *grad, const float *inputs, const
                                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
                                     uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
                                     const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     (void)embeddings;
     return gb_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, dtype, grad_is_bl,
                     offsets_host, workspace, workspace_bytes, false, stream);
@@ -1858,7 +1858,7 @@ int foc_grid_encode_backward_binned_counted(const void *grad, const float *input
                                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void *dy_dx, void *grad_inputs,
                                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int grad_is_bl,
                                             const int32_t *offsets_host, void *workspace, uint64_t workspace_bytes, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad);
     (void)embeddings;
     return gb_entry(grad, inputs, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp, dtype, grad_is_bl,
                     offsets_host, workspace, workspace_bytes, true, stream);
@@ -1867,7 +1867,7 @@ int foc_grid_encode_backward_binned_counted(const void *grad, const float *input
 int foc_grad_total_variation(const void *inputs, const void *embeddings, void *grad, const int32_t *offsets, float weight, uint32_t B,
                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, int dtype,
                              void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, inputs);
     if (B == 0) return FOC_OK;
     FOC_REQUIRE(inputs && embeddings && grad && offsets, FOC_E_INVALID, "grad_total_variation: null pointer");
     FOC_REQUIRE(dtype == FOC_F32 || dtype == FOC_F16, FOC_E_DTYPE, "grad_total_variation: dtype must be FOC_F32 or FOC_F16");

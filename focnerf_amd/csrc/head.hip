@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_sh_encode(const float *__restrict__ dir
 extern "C" {
 
 int foc_sh_encode(const float *dirs, uint64_t M, float *out, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, dirs);
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(dirs && out, FOC_E_INVALID, "sh_encode: null pointer");
     hipLaunchKernelGGL(k_sh_encode, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, dirs, M, out);
@@ -139,7 +139,7 @@ int foc_sh_encode(const float *dirs, uint64_t M, float *out, void *stream) {
 }
 
 int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float *sigma, void *cin, const void *obj_feat, uint32_t cin_width, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(h && (sigma || cin) && (!cin || dirs), FOC_E_INVALID, "sample_head_forward: null pointer");
     FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "sample_head_forward: cin_width must be 32 or 48 (got %u)", cin_width);
@@ -151,7 +151,7 @@ int foc_sample_head_forward(const void *h, const float *dirs, uint64_t M, float 
 }
 
 int foc_sample_head_backward(const void *h, const float *grad_sigma, const void *grad_cin, uint64_t M, void *grad_h, uint32_t cin_width, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(h && grad_h, FOC_E_INVALID, "sample_head_backward: null pointer");
     FOC_REQUIRE(cin_width == 32 || cin_width == 48, FOC_E_INVALID, "sample_head_backward: cin_width must be 32 or 48 (got %u)", cin_width);
@@ -162,7 +162,7 @@ int foc_sample_head_backward(const void *h, const float *grad_sigma, const void 
 }
 
 int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, c);
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(c && rgb, FOC_E_INVALID, "rgb_head_forward: null pointer");
     hipLaunchKernelGGL(k_rgb_fwd, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)c, M, rgb);
@@ -171,7 +171,7 @@ int foc_rgb_head_forward(const void *c, uint64_t M, float *rgb, void *stream) {
 }
 
 int foc_rgb_head_backward(const void *c, const float *grad_rgb, uint64_t M, void *grad_c, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, c);
     if (M == 0) return FOC_OK;
     FOC_REQUIRE(c && grad_rgb && grad_c, FOC_E_INVALID, "rgb_head_backward: null pointer");
     hipLaunchKernelGGL(k_rgb_bwd, dim3(foc_grid_1d(M, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16 *)c, grad_rgb, M, (_Float16 *)grad_c);

@@ -51,7 +51,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
                         const void *sigma_weights, uint32_t sigma_layers, const void *color_weights, uint32_t color_layers, uint32_t activation,
                         const void *obj_feat, float T_thresh, float *weights_sum, float *depth, float *image, void *scratch, uint32_t flags, int32_t *deaths, uint32_t deaths_base,
                         uint32_t deaths_len, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     FOC_REQUIRE(count, FOC_E_INVALID, "occ_render_step: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (n_alive == 0) return foc_zero_async(count, sizeof(int32_t), st) == hipSuccess ? FOC_OK : FOC_E_LAUNCH;

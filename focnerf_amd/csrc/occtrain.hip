@@ -191,7 +191,7 @@ extern "C" {
 int foc_occ_tail_forward(const void *h, const void *c, uint32_t c_width, const float *deltas, const int32_t *rays, uint32_t M, uint32_t N,
                          float T_thresh, float density_scale, const float *bg_ray, float bg_scalar, const float *nears, const float *fars,
                          float *weights_sum, float *image_raw, float *image, float *depth, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, h);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "occ_tail_forward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(rays && nears && fars && weights_sum && image_raw && image && depth && (M == 0 || (h && c && deltas)), FOC_E_INVALID, "occ_tail_forward: null pointer");
@@ -204,7 +204,7 @@ int foc_occ_tail_forward(const void *h, const void *c, uint32_t c_width, const f
 int foc_occ_tail_backward(const float *grad_image, const float *grad_ws, const void *h, const void *c, uint32_t c_width, const float *deltas,
                           const int32_t *rays, const int32_t *counter, const float *weights_sum, const float *image_raw, uint32_t M, uint32_t N,
                           float T_thresh, float density_scale, const float *bg_ray, float bg_scalar, void *grad_c, void *grad_h0, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad_image);
     if (N == 0 || M == 0) return FOC_OK;
     FOC_REQUIRE(c_width == 16 || c_width == 4, FOC_E_INVALID, "occ_tail_backward: c_width must be 16 or 4 (got %u)", c_width);
     FOC_REQUIRE(grad_image && h && c && deltas && rays && counter && weights_sum && image_raw && grad_c && grad_h0, FOC_E_INVALID, "occ_tail_backward: null pointer");

@@ -1144,7 +1144,7 @@ extern "C" {
 
 int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb, uint32_t N, float min_near,
                            float *nears, float *fars, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_o);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && aabb && nears && fars, FOC_E_INVALID, "near_far_from_aabb: null pointer");
     hipLaunchKernelGGL(k_near_far_from_aabb, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1154,7 +1154,7 @@ int foc_near_far_from_aabb(const float *rays_o, const float *rays_d, const float
 }
 
 int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N, float *coords, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_o);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && coords, FOC_E_INVALID, "sph_from_ray: null pointer");
     hipLaunchKernelGGL(k_sph_from_ray, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, radius, N, coords);
@@ -1163,7 +1163,7 @@ int foc_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uin
 }
 
 int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, coords);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D: null pointer");
     hipLaunchKernelGGL(k_morton3D, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, coords, N, indices);
@@ -1172,7 +1172,7 @@ int foc_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stre
 }
 
 int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, indices);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(coords && indices, FOC_E_INVALID, "morton3D_invert: null pointer");
     hipLaunchKernelGGL(k_morton3D_invert, dim3(foc_grid_1d(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
@@ -1181,7 +1181,7 @@ int foc_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, voi
 }
 
 int foc_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grid);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(grid && bitfield, FOC_E_INVALID, "packbits: null pointer");
     uint32_t N4 = 0;
@@ -1251,7 +1251,7 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_o);
     return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises, scratch, nullptr, false, 0u,
                           stream);
 }
@@ -1260,7 +1260,7 @@ int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const u
                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                const float *nears, const float *fars, float *enc_in, void *sh_rows, float *deltas,
                                int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, uint32_t pad_align, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_o);
     return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, enc_in, nullptr, deltas, rays, counter, noises, scratch, sh_rows, true,
                           pad_align, stream);
 }
@@ -1268,7 +1268,7 @@ int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const u
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,
                                      uint32_t M, uint32_t N, float T_thresh, float *weights_sum, float *depth, float *image,
                                      void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, sigmas);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays && weights_sum && depth && image, FOC_E_INVALID, "composite_rays_train_forward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas), FOC_E_INVALID, "composite_rays_train_forward: null input with M > 0");
@@ -1282,7 +1282,7 @@ int foc_composite_rays_train_backward(const float *grad_weights_sum, const float
                                       const float *rgbs, const float *deltas, const int32_t *rays, const float *weights_sum,
                                       const float *image, uint32_t M, uint32_t N, float T_thresh, float *grad_sigmas,
                                       float *grad_rgbs, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, grad_image);
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(grad_image && rays && weights_sum && image, FOC_E_INVALID, "composite_rays_train_backward: null pointer");
     FOC_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), FOC_E_INVALID,
@@ -1298,7 +1298,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
                    const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                    const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                    const float *noises, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     (void)nears;
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, FOC_E_INVALID,
@@ -1353,7 +1353,7 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
                              const float *rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                              const uint8_t *grid, const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                              const float *noises, int32_t *scratch, int normalised, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     (void)nears;
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises && scratch, FOC_E_INVALID,
@@ -1404,7 +1404,7 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
 int foc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t *rays_alive, float *rays_t,
                        const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                        float *image, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     if (n_alive == 0) return FOC_OK;
     FOC_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, FOC_E_INVALID,
                 "composite_rays: null pointer");
@@ -1419,7 +1419,7 @@ int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int
                           const float *sigmas, const float *rgbs, const float *deltas, float *weights_sum, float *depth,
                           float *image, int32_t *out, int32_t *n_out, int32_t *block_counts, int32_t *deaths, uint32_t deaths_base, uint32_t deaths_len,
                           int sample_major, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     FOC_REQUIRE(n_alive > 0 && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && out && n_out && block_counts, FOC_E_INVALID,
                 "composite_compact: null pointer");
     FOC_REQUIRE(!deaths || deaths_len >= 1, FOC_E_INVALID, "composite_compact: empty death histogram");
@@ -1436,7 +1436,7 @@ int foc_composite_compact(uint32_t n_alive, uint32_t n_step, float T_thresh, int
 }
 
 int foc_compact_alive(const int32_t *rays_alive, uint32_t n_alive, int32_t *out, int32_t *n_out, int32_t *scratch, void *stream) {
-    FocDeviceGuard foc_guard_(stream);
+    FocDeviceGuard foc_guard_(stream, rays_alive);
     FOC_REQUIRE(n_out && scratch, FOC_E_INVALID, "compact_alive: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nb = foc_div_up(n_alive, 1024);

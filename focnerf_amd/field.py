@@ -74,7 +74,7 @@ def _half_of(param):
     if h.is_cuda:
         st = _raw_stream_of(h.device)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(h.device))         # the stream of the TENSOR's device: it need not be the current device
     _half_scope[id(param)] = (param, h, ev, st)
     return h
 
@@ -94,7 +94,7 @@ def scope_cached(key, owner, make):
     if v.is_cuda:
         st = _raw_stream_of(v.device)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(v.device))
     _half_scope[key] = (owner, v, ev, st)
     return v
 

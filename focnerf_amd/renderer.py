@@ -306,7 +306,9 @@ class NeRFRenderer(nn.Module):
         """The loop of legacy/nerf/renderer.py:323-372 with every iteration ONE call into the library (csrc/occrender.hip: march, encode,
         whole-field kernel, composite, compaction) on buffers allocated once per view; bursts of FOC_RENDER_BURST samples per ray, the live
         count read `FOC_RENDER_COUNT_LAG` iterations late, the reference's stopping point reproduced. Same samples, same per-ray
-        accumulation order, same image and depth bit for bit."""
+        accumulation order: the same image and depth bit for bit on every configuration the tests run (jittered first samples with the
+        same noise included), with one caveat spelled out at the burst rule below — a re-derivation of t that can differ by an ulp where a
+        single advance more than doubles t while fewer than half of the rays are alive."""
         import numpy as np
         from ._lib import lib, ptr, stream_of, check
         from .field import _half_of, half_cache_scope
@@ -370,8 +372,20 @@ class NeRFRenderer(nn.Module):
             while state["marched"] < wide_end and live > 0:
                 ref_burst = rule(live)
                 burst = max(ref_burst, min(wide, wide_end - state["marched"]))
+                if perturb and state["marched"] == 0:
+                    # The jitter belongs to the samples of the reference's FIRST iteration only: its march offsets the start by noise * dt, but
+                    # composite_rays advances rays_t from the UN-jittered start by the deltas (raymarching.cu:736-748, :868-905), so the second
+                    # iteration continues without the offset. A wide first burst would carry it through all of its samples: the first
+                    # iteration keeps the reference's own length.
+                    burst = ref_burst
                 # several of the reference's one-sample iterations in one: every sample starts from the t the reference's NEXT iteration would
-                # start from, last_t + (t - last_t) as composite_rays re-derives it (an ulp off the march's own t when the subtraction rounds)
+                # start from, last_t + (t - last_t) as composite_rays re-derives it (an ulp off the march's own t when the subtraction rounds).
+                # Where the reference's own bursts are 2..7 samples long (fewer than half of the rays alive) it re-derives at ITS iteration
+                # boundaries, which depend on the exact live count of every iteration — not known here without a host round trip per
+                # iteration. The two differ only where fl(t - last_t) is inexact, i.e. t > 2 last_t: one advance that more than doubles t.
+                # That happens at a ray's first samples (camera inside the box, near = min_near, a long empty stretch) — the phase in which
+                # every ray is alive, the reference's burst is 1 and this loop re-derives after every sample — and not later in a
+                # single-object scene, where a ray that has reached the object at t >= 1 finds nothing beyond it at 2 t.
                 step(live, burst, 1 if (ref_burst == 1 and burst > 1) else 0)
                 slot = (state["it"] - 1) % (lag + 1)
                 ring[slot:slot + 1].copy_(count, non_blocking=True)

@@ -40,6 +40,9 @@ extern "C" {
 int         foc_abi_version(void);
 /* Thread-local message of the last non-zero return on this thread ("" if none). */
 const char *foc_last_error(void);
+/* Which device an entry point makes current for its call (host-only query of the rule, for tests): a non-null stream's device; for the
+ * NULL stream (it exists on every device) the device the first pointer argument lives on; else the current device. -1 = unknown. */
+int foc_guard_pick_device(int stream_is_null, int stream_device, int pointer_device, int current_device);
 /* Compiled-for architecture string, e.g. "gfx950". */
 const char *foc_arch(void);
 

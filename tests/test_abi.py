@@ -33,7 +33,7 @@ def test_abi_version_and_arch():
     from focnerf_amd import _lib
     assert _lib.lib.foc_abi_version() == 1
     assert _lib.lib.foc_arch() == b"gfx950"
-    assert _lib.lib.foc_last_error() == b""
+    assert isinstance(_lib.lib.foc_last_error(), bytes)           # (empty in a fresh process; other tests of a session may have left theirs)
 
 
 def test_argument_validation_needs_no_gpu():
@@ -51,6 +51,20 @@ def test_argument_validation_needs_no_gpu():
     assert rc == 1 and b"input_dim" in lib.foc_last_error()
     rc = lib.foc_freq_encode_forward(one, 4, 3, 4, 26, one, None)
     assert rc == 1
+
+
+def test_device_selection_rule_of_the_entry_points():
+    """csrc/common.h FocDeviceGuard: a non-null stream decides; the NULL stream (torch's default stream on EVERY device) says nothing, then
+    the first pointer argument's device does — a C caller with cuda:1 buffers on the default stream while cuda:0 is current; neither: the
+    current device. (The two-device launch itself is tests/test_gpu_edge_cases.py::test_ops_follow_their_tensors_device, skipped below 2 GPUs.)"""
+    from focnerf_amd import _lib
+    pick = _lib.lib.foc_guard_pick_device
+    assert pick(0, 3, 1, 0) == 3            # a real stream: its device, whatever the pointer or the current device say
+    assert pick(1, -1, 1, 0) == 1           # NULL stream, device-1 pointer, device 0 current: device 1
+    assert pick(1, 2, 1, 0) == 1            # a stream device reported for the NULL handle is ignored
+    assert pick(1, -1, -1, 2) == 2          # NULL stream, no device pointer (host memory / NULL): stay where we are
+    assert pick(0, -1, 1, 0) == 1           # a stream whose device cannot be read: fall back to the pointer
+    assert pick(0, -1, -1, 5) == 5
 
 
 def test_forward_index_path_admission_needs_no_gpu():

@@ -362,7 +362,9 @@ def test_freq_encoder():
     torch.manual_seed(0)
     # (degree, rows, input dimension): ragged and whole 256-row tiles, one row, more tiles than workgroups of the grid-stride launch,
     # row widths C = D + 2 D deg below and above the 256-element stride of the tile walk (C = 27, 63, 39, 18, 25, 305)
-    for deg, B, D in [(4, 10007, 3), (10, 513, 3), (6, 1, 3), (4, 256 * 5, 2), (2, 70001, 5), (4, 256 * 2100 + 3, 3), (30, 300, 5)]:
+    # (the reference takes any input dimension: 33, 100 and 3000 columns run with fewer rows per tile — 248, 81 and 2)
+    for deg, B, D in [(4, 10007, 3), (10, 513, 3), (6, 1, 3), (4, 256 * 5, 2), (2, 70001, 5), (4, 256 * 2100 + 3, 3), (30, 300, 5), (2, 1000, 33), (1, 517, 100),
+                      (1, 37, 3000)]:
         enc = FreqEncoder(D, deg)
         x = (torch.randn(B, D, device="cuda")).requires_grad_(True)
         y = enc(x)

@@ -335,12 +335,42 @@ def test_native_inference_loop_edge_cases():
         a = m.render(far_o, away, perturb=False, device_compaction=False, **kw)
         b = m.render(far_o, away, perturb=False, device_compaction=True, **kw)
         assert torch.equal(a["image"], b["image"]) and bool((b["image"] == 1.0).all())
-        # jitter: another draw of the same distribution per loop form — close to each other and to the unjittered image, not equal
+        # jitter: both loop forms draw torch.rand(n) once, first thing — with the same seed they march the SAME jittered first samples, and
+        # the jitter belongs to the reference's first iteration only (its composite_rays continues from the un-jittered t): bit for bit
+        for seed, mx, th in ((0, 1024, 1e-4), (1, 100, 1e-4), (2, 1024, 0.3)):
+            kwp = dict(kw, max_steps=mx, T_thresh=th)
+            torch.manual_seed(seed)
+            p = m.render(o, d, perturb=True, device_compaction=True, **kwp)
+            torch.manual_seed(seed)
+            r = m.render(o, d, perturb=True, device_compaction=False, **kwp)
+            assert torch.equal(p["image"], r["image"]) and torch.equal(p["depth"], r["depth"]), (seed, mx, th)
+        q = m.render(o, d, perturb=False, device_compaction=True, **kw)
         torch.manual_seed(0)
         p = m.render(o, d, perturb=True, device_compaction=True, **kw)
-        q = m.render(o, d, perturb=False, device_compaction=True, **kw)
         assert torch.isfinite(p["image"]).all() and not torch.equal(p["image"], q["image"])
         assert (p["image"] - q["image"]).abs().mean() < 2e-2
+
+
+def test_native_inference_loop_with_the_camera_inside_the_box():
+    """Cameras INSIDE the bound (near = min_near, long empty stretches before the object: single advances that more than double t, where the
+    re-derived t = last_t + fl(t - last_t) of a wide burst can differ from the march's own t): native loop against the Python loop on the
+    reference's schedule, bit for bit, over step caps and thresholds, with cameras close to the object, further out and next to a face of the box."""
+    from focnerf_amd import synthetic
+    bound = 2
+    m = _model(bound, True, seed=7).eval()
+    intr = synthetic.intrinsics(56, 56)
+    for radius, seed in ((0.9, 3), (1.5, 4), (1.95, 5)):                     # inside the box: close to the object / further out / next to a face
+        g = torch.Generator().manual_seed(seed)
+        poses = synthetic.rand_poses(1, "cuda", radius=radius, generator=g)
+        o, d = synthetic.get_rays(poses, intr, 56, 56)
+        assert float(o.abs().max()) < bound                               # the camera is inside the box: every ray starts at min_near
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            for max_steps, thresh in ((1024, 1e-4), (64, 1e-4), (1024, 0.5)):
+                kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=max_steps, bg_color=1.0, T_thresh=thresh)
+                a = m.render(o, d, device_compaction=False, **kw)
+                b = m.render(o, d, device_compaction=True, **kw)
+                assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"]), (radius, max_steps, thresh)
+        assert (a["image"] < 0.99).any(), radius
 
 
 @pytest.mark.parametrize("burst", ["1", "3", "8", "16"])
