@@ -38,6 +38,8 @@ SIGNATURES = {
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_field": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
+    "foc_set_option": (i32, [ctypes.c_char_p, i32]),
+    "foc_get_option": (i32, [ctypes.c_char_p, c_vp]),
     "foc_guard_pick_device": (i32, [i32, i32, i32, i32]),
     "foc_grid_forward_index_path": (i32, [u32, u32, u32]),
     "foc_view_tile_order": (i32, [c_vp, u32, u32, u32, c_vp, c_vp, c_vp]),
@@ -219,3 +221,32 @@ def dtype_code(t):
     if t.dtype == torch.float16:
         return FOC_F16
     raise RuntimeError(f"focnerf_amd: unsupported dtype {t.dtype} (float32 or float16 expected)")
+
+
+# ---------------------------------------------------------------- library options (csrc/common.h FocOpt, include/focnerf.h foc_set_option)
+def get_option(name):
+    """Current value of a library switch (an int; FOC_OCC_MARCH_FORM: -1 auto, 0 two, 1 row, 2 lane, 3 staged)."""
+    v = ctypes.c_int(0)
+    check(lib.foc_get_option(name.encode(), ctypes.cast(ctypes.byref(v), ctypes.c_void_p)), "get_option")
+    return v.value
+
+
+def set_option(name, value):
+    """Set a library switch for the rest of the process (the environment variable of the same name only sets its INITIAL value)."""
+    check(lib.foc_set_option(name.encode(), int(value)), "set_option")
+
+
+class option:
+    """`with option("FOC_GB_FACTORED", 0): ...` — a switch set for the block and put back afterwards (tests, A/B runs)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, int(value)
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False

@@ -190,7 +190,52 @@ __global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restric
     }
 }
 
+// ---------------------------------------------------------------- options (common.h FocOpt)
+#include <stdlib.h>
+#include <string.h>
+struct FocOptionRow { const char *name; int value; };
+static FocOptionRow foc_option_table[FOC_OPT_COUNT] = {
+    {"FOC_MLP_BWD_FUSED", 1}, {"FOC_GB_MERGE_MAX_RES", 480}, {"FOC_GB_FACTORED", 1}, {"FOC_GB_TAIL_SPLIT", 16}, {"FOC_GRID_FUSE_SMALL", 1},
+    {"FOC_GRID_PAIRS", 1}, {"FOC_GRID_FAST", 1}, {"FOC_MARCH_SERIAL", -1}, {"FOC_MARCH_RAYS_ROW_MAX", 131072}, {"FOC_OCC_MARCH_FORM", -1},
+    {"FOC_OCC_SAMPLE_MAJOR", 1}, {"FOC_OCC_FIELD_PIECE", 1 << 23},
+};
+static int foc_option_parse(int which, const char *text) {
+    if (which == FOC_OPT_OCC_MARCH_FORM) {                  // the forms have names: two | row | lane | staged (or 0..3, -1 = by burst length)
+        if (text[0] == 't') return 0;
+        if (text[0] == 'r') return 1;
+        if (text[0] == 'l') return 2;
+        if (text[0] == 's') return 3;
+    }
+    return atoi(text);
+}
+static void foc_options_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (int i = 0; i < FOC_OPT_COUNT; i++) {               // the ONE place the library reads its environment
+        const char *e = getenv(foc_option_table[i].name);
+        if (e && e[0]) foc_option_table[i].value = foc_option_parse(i, e);
+    }
+}
+int foc_opt(FocOpt which) { foc_options_init(); return foc_option_table[which].value; }
+
 extern "C" {
+
+int foc_set_option(const char *name, int value) {
+    foc_options_init();
+    for (int i = 0; i < FOC_OPT_COUNT; i++)
+        if (name && strcmp(name, foc_option_table[i].name) == 0) { foc_option_table[i].value = value; return FOC_OK; }
+    foc_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+    return FOC_E_INVALID;
+}
+
+int foc_get_option(const char *name, int *value) {
+    foc_options_init();
+    for (int i = 0; i < FOC_OPT_COUNT; i++)
+        if (name && value && strcmp(name, foc_option_table[i].name) == 0) { *value = foc_option_table[i].value; return FOC_OK; }
+    foc_set_error("get_option: unknown option '%s'", name ? name : "(null)");
+    return FOC_E_INVALID;
+}
 
 int foc_guard_pick_device(int stream_is_null, int stream_device, int pointer_device, int current_device) {
     return foc_guard_pick(stream_is_null != 0, stream_device, pointer_device, current_device);

@@ -12,6 +12,26 @@
 // thread-local error message (foc_last_error)
 void foc_set_error(const char *fmt, ...);
 
+// Tuning / test switches of the library, ONE table (combine.hip foc_option_table): each is an int with a default, initialised from the
+// environment variable of the same name the first time any option is read (library load, in effect) and changeable at run time through
+// foc_set_option (tests, A/B runs) — no getenv on any call path.
+enum FocOpt {
+    FOC_OPT_MLP_BWD_FUSED,        // 1: single-pass fused MLP backward where it applies; 0: the two-kernel form (stored activations)
+    FOC_OPT_GB_MERGE_MAX_RES,     // binned grid backward: levels up to this resolution merge runs of equal cells (default 480)
+    FOC_OPT_GB_FACTORED,          // 1: 8-byte factored records on the unmerged hashed levels; 0: 12-byte two-corner records everywhere
+    FOC_OPT_GB_TAIL_SPLIT,        // scatter: most workgroups a tile of the last partial round is dealt out to (16; 1 = whole tiles only)
+    FOC_OPT_GRID_FUSE_SMALL,      // 1: the coarse levels of the forward share a workgroup
+    FOC_OPT_GRID_PAIRS,           // 1: 8-byte row-pair loads in the fp16 forward
+    FOC_OPT_GRID_FAST,            // 1: the FOC-shape code path of the forward (ge_forward_hash3)
+    FOC_OPT_MARCH_SERIAL,         // march_rays_train's walk: -1 by ray count, 1 one ray per lane, 0 one wave per ray
+    FOC_OPT_MARCH_RAYS_ROW_MAX,   // march_rays: 16 lanes per ray up to this many live rays (131072; 0 = one ray per lane)
+    FOC_OPT_OCC_MARCH_FORM,       // native occupancy loop's march: -1 by burst length, 0 two phases, 1 row, 2 lane, 3 staged
+    FOC_OPT_OCC_SAMPLE_MAJOR,     // 1: sample-major sample arrays inside the native occupancy step
+    FOC_OPT_OCC_FIELD_PIECE,      // samples per field evaluation inside the native occupancy step (2^23)
+    FOC_OPT_COUNT
+};
+int foc_opt(FocOpt which);
+
 #define FOC_REQUIRE(cond, code, ...)                    \
     do {                                                \
         if (!(cond)) {                                  \

@@ -1019,12 +1019,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                                     if (col < in_dim) {
                                         const h4 v = {(_Float16)x[nb][4 * q], (_Float16)x[nb][4 * q + 1], (_Float16)x[nb][4 * q + 2], (_Float16)x[nb][4 * q + 3]};
                                         const u32x2 w = __builtin_bit_cast(u32x2, v);
-#ifdef FOC_TIMING_NO_GRAD_PLANES
-                                        if (w.x == 0x7FC17FC1u) gp[row] = w.y;      // TIMING BUILD: the planes are (practically) never written; the values stay live
-#else
                                         gp[(uint64_t)(col / 2) * B + row] = w.x;
                                         gp[(uint64_t)(col / 2 + 1) * B + row] = w.y;
-#endif
                                     }
                                 }
                             }
@@ -1486,9 +1482,6 @@ static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
     static const void *seen[MLP_MAX_DEVICES][64];
     static uint32_t blocks[MLP_MAX_DEVICES][64];
     static int n_seen[MLP_MAX_DEVICES];
-    static int forced = -1;                     // FOC_MLP_BLOCKS_PER_CU=n overrides (tuning runs)
-    if (forced < 0) { const char *e = getenv("FOC_MLP_BLOCKS_PER_CU"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) return (uint32_t)forced;
     const int dev = mlp_device();
     for (int i = 0; i < n_seen[dev]; i++) if (seen[dev][i] == kern) return blocks[dev][i];
     int n = 0;
@@ -1626,8 +1619,7 @@ static int mlp_dw_launch(const void *grad, const void *inputs, const void *fwd_b
     const uint32_t n_w = HIDDEN * (in_dim + HIDDEN * (num_layers - 1) + 16);
     if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t gx = foc_div_up(B, DW_CHUNK);
-    static int wgs_per_cu = 0;                   // split-K workgroups per CU over all layers (FOC_DW_WGS_PER_CU overrides, for tuning)
-    if (!wgs_per_cu) { const char *e = getenv("FOC_DW_WGS_PER_CU"); wgs_per_cu = e ? atoi(e) : 8; if (wgs_per_cu < 1) wgs_per_cu = 1; }
+    const int wgs_per_cu = 8;                    // split-K workgroups per CU over all layers
     constexpr uint32_t GZ = HIDDEN > 128 ? (uint32_t)((HIDDEN / 32) * (HIDDEN / 32) + 15) / 16 : 1u;      // 16 output tiles per workgroup
     const uint32_t capx = foc_div_up(mlp_num_cus() * (uint32_t)wgs_per_cu, (num_layers + 1) * GZ);
     if (gx > capx) gx = capx;
@@ -1646,8 +1638,7 @@ static int mlp_bwd_launch(const void *grad, const void *inputs, const void *weig
     const bool gen = act != FOC_ACT_RELU && act != FOC_ACT_NONE;      // the single-pass kernel is built for ReLU / None: the others take the reference's data flow
     const int relu = act == FOC_ACT_RELU;
     // fused single-pass kernel for the shapes the NeRF networks use; FOC_MLP_BWD_FUSED=0 forces the two-kernel form (tuning / tests)
-    static int use_fused = -1;
-    if (use_fused < 0) { const char *e = getenv("FOC_MLP_BWD_FUSED"); use_fused = e ? atoi(e) : 1; }
+    const int use_fused = foc_opt(FOC_OPT_MLP_BWD_FUSED);
     if constexpr (HIDDEN <= 64) {
         if (use_fused && in_dim <= 64 && !gen) {
             switch (num_layers) {

@@ -1393,8 +1393,9 @@ static int ge_make_levels(uint32_t L, float S, uint32_t H, GeLevels &lv) {
         lv.resolution[l] = (uint32_t)ceil((double)sc) + 1;
     }
     for (uint32_t l = L; l < GE_MAX_LEVELS; l++) { lv.scale[l] = 0; lv.resolution[l] = 1; }
-    static int merge_res = -1;                   // FOC_GB_MERGE_MAX_RES: tuning knob (<= 1023: the run key packs 10 bits per axis)
-    if (merge_res < 0) { const char *e = getenv("FOC_GB_MERGE_MAX_RES"); merge_res = e ? atoi(e) : (int)GB_MERGE_MAX_RES; if (merge_res > 1023) merge_res = 1023; if (merge_res < 0) merge_res = 0; }
+    int merge_res = foc_opt(FOC_OPT_GB_MERGE_MAX_RES);                 // <= 1023: the run key packs 10 bits per axis
+    if (merge_res > 1023) merge_res = 1023;
+    if (merge_res < 0) merge_res = 0;
     lv.merge_max_res = (uint32_t)merge_res;
     return 0;
 }
@@ -1405,13 +1406,10 @@ static inline uint32_t ge_xcd_grid(uint32_t chunks, uint32_t L) { return 8u * ch
 // walk. Measured on FOC's 16-level grid (forward + count, 2 M points): threshold 63 0.358 ms, 120 0.353, 160 0.350 (8 levels),
 // 250 without the L / 2 cap 0.353, 600 0.422, every level 0.640. FOC_GRID_FUSE_SMALL=0 switches it off.
 static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("FOC_GRID_FUSE_SMALL"); on = e ? atoi(e) : 1; }
+    const int on = foc_opt(FOC_OPT_GRID_FUSE_SMALL);
     if (!on) return 0u;
     const uint32_t finest = on > 1 ? (uint32_t)on : 160u;            // a value above 1 is taken as the resolution threshold (A/B runs)
-    static int cap = -1;                                             // FOC_GRID_FUSE_CAP: most levels in the shared group (A/B runs; default L / 2)
-    if (cap < 0) { const char *e = getenv("FOC_GRID_FUSE_CAP"); cap = e ? atoi(e) : 0; }
-    const uint32_t most = cap > 0 ? (uint32_t)cap : L / 2;
+    const uint32_t most = L / 2;                                     // most levels in the shared group (10 / 12 / 14 / 16 of 16 measured: DESIGN.md section 9)
     uint32_t lc = 0;
     while (lc < most && lc < L && lv.resolution[lc] <= finest) lc++;
     return lc >= 2u ? lc : 0u;
@@ -1420,15 +1418,12 @@ static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
 // FOC_GRID_PAIRS=0: one 4-byte load per corner (A/B runs). 16-byte groups of 4 rows (which would also cover x = 1 mod 4 on a hashed
 // level) were measured SLOWER: 0.064 vs 0.052 ms per 2 M random points and level — the 16-byte gather is not free like the 8-byte one.
 static bool ge_pairs_enabled() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("FOC_GRID_PAIRS"); on = e ? atoi(e) : 1; }
-    return on != 0;
+    return foc_opt(FOC_OPT_GRID_PAIRS) != 0;
 }
 // The `pairs` argument of the level-major forward kernels: 0 = one load per corner, 1 = row pairs, 2 = row pairs and the call is of the
 // shape ge_forward_hash3 serves (the per-level part of that decision is taken in the kernel). FOC_GRID_FAST=0: never 2 (A/B runs).
 static uint32_t ge_pairs_mode(const void *emb, const void *dy_dx, size_t elem, uint32_t D, uint32_t C, uint32_t gridtype, bool ac, uint32_t interp) {
-    static int fast = -1;
-    if (fast < 0) { const char *e = getenv("FOC_GRID_FAST"); fast = e ? atoi(e) : 1; }
+    const int fast = foc_opt(FOC_OPT_GRID_FAST);
     if (!ge_pairs_enabled() || ((uintptr_t)emb & 7u) != 0u || dy_dx) return 0u;
     return (fast && elem == 2 && D == 3 && C == 2 && gridtype == 0u && !ac && interp == 0u) ? 2u : 1u;
 }
@@ -1436,8 +1431,7 @@ static uint32_t ge_pairs_mode(const void *emb, const void *dy_dx, size_t elem, u
 template <typename T, uint32_t D, uint32_t C>
 static int ge_forward_launch(const float *inputs, const void *emb, const int32_t *offsets, void *outputs, uint32_t B, uint32_t L,
                              const GeLevels &lv, void *dy_dx, uint32_t gridtype, bool ac, uint32_t interp, bool bl, hipStream_t st) {
-    static int lm_plain = -1;                    // FOC_GRID_LM_PLAIN=0: pin each level to one XCD instead of walking the levels chip-wide (tuning)
-    if (lm_plain < 0) { const char *e = getenv("FOC_GRID_LM_PLAIN"); lm_plain = e ? atoi(e) : 1; }
+    const int lm_plain = 1;                      // blocks numbered level by level: the whole chip walks one level at a time (pinning a level to one XCD balanced badly)
     if (bl) {
         const uint64_t total = (uint64_t)B * L;
         const uint32_t grid = (uint32_t)((total + 255) / 256 > 0x7FFFFFFFull ? 0x7FFFFFFFull : (total + 255) / 256);
@@ -1449,9 +1443,7 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
         const uint32_t groups = lc >= 2u ? L - lc + 1u : L;
         // FOC_GRID_FWD_LDS=<bytes>: unused dynamic LDS per workgroup — caps the resident workgroups per CU (occupancy experiments: what the
         // forward's gathers cost with fewer waves in flight)
-        static int pad_lds = -1;
-        if (pad_lds < 0) { const char *e = getenv("FOC_GRID_FWD_LDS"); pad_lds = e ? atoi(e) : 0; }
-        if (pad_lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_grid_fwd_lbc<T, D, C>), hipFuncAttributeMaxDynamicSharedMemorySize, pad_lds);
+        const int pad_lds = 0;
         hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), (size_t)pad_lds, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,
                            ge_pairs_mode(emb, dy_dx, sizeof(T), D, C, gridtype, ac, interp), lc);
@@ -1615,8 +1607,7 @@ static int gb_forward_counted(const float *inputs, const void *emb, const int32_
 // decision, in its uint32 arithmetic) with a power-of-two size of at least one segment, above the run-merging threshold.
 // FOC_GB_FACTORED=0 keeps the 12-byte records everywhere (A/B runs).
 static uint32_t gb_fact_mask(uint32_t L, const GeLevels &lv, const int32_t *offsets_host, uint32_t gridtype, bool ac, int dtype) {
-    const char *e = getenv("FOC_GB_FACTORED");     // read per call (tests compare the two record forms in one process)
-    const int on = e ? atoi(e) : 1;
+    const int on = foc_opt(FOC_OPT_GB_FACTORED);
     if (!on || dtype != FOC_F16 || gridtype != 0u) return 0u;
     uint32_t m = 0;
     for (uint32_t l = 0; l < L && l < 32u; l++) {
@@ -1660,7 +1651,8 @@ static int gb_run(const void *grad, const float *inputs, const int32_t *offsets,
     const uint32_t resident = gb_scatter_resident(sizeof(T));
     const uint32_t n_tail = n_tiles % resident, n_whole = n_tiles - n_tail;
     uint32_t split = 1u;
-    while (n_tail && split * 2u <= L && n_tail * split * 2u <= resident && split < 16u) split *= 2u;
+    const uint32_t split_max = (uint32_t)max(1, foc_opt(FOC_OPT_GB_TAIL_SPLIT));
+    while (n_tail && split * 2u <= L && n_tail * split * 2u <= resident && split * 2u <= split_max) split *= 2u;
     hipLaunchKernelGGL((k_gbin_scatter_pms<T>), dim3(n_whole + n_tail * split), dim3(GB_PMS_WG), 0, st, (const T *)grad, inputs, offsets, hdr, wg_hist, recs, max_recs, B, L, lv,
                        gridtype, ac, interp, bl, fact_mask, sz, n_tiles, n_whole, split);
     FOC_CHECK_LAUNCH("grid_encode_backward(scatter)");

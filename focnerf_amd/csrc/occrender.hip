@@ -66,8 +66,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     // the sample slots are zeroed here (the reference's torch.zeros) unless the march kernel of this burst length writes every one of them itself
     int march_flags = 1 | ((flags & 1u) ? 2 : 0);          // normalised positions; flags bit 0: t re-derived after every sample (focnerf.h)
     // sample-major sample arrays ([n_step][n_alive]) where the march kernel of this call can write them (FOC_OCC_SAMPLE_MAJOR=0: ray-major)
-    const char *sm_env = getenv("FOC_OCC_SAMPLE_MAJOR");
-    const int sample_major = (n_step > 1 && !(sm_env && sm_env[0] == '0') && foc_march_rays_two_phase_sample_major(n_alive, n_step, march_flags)) ? 1 : 0;
+    const int sample_major = (n_step > 1 && foc_opt(FOC_OPT_OCC_SAMPLE_MAJOR) != 0 && foc_march_rays_two_phase_sample_major(n_alive, n_step, march_flags)) ? 1 : 0;
     if (sample_major) march_flags |= 4;
     const uint64_t to_zero = foc_march_rays_two_phase_fills(n_step, march_flags) ? 0 : M * 8;
     hipLaunchKernelGGL(k_occ_prepare, dim3(foc_grid_1d((to_zero > n_alive ? to_zero : n_alive) + 1, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t *>(samples), to_zero,
@@ -79,8 +78,7 @@ int foc_occ_render_step(uint32_t n_alive, uint32_t n_step, const int32_t *rays_a
     // the field in pieces of at most `piece` samples: the [L, piece, 2] planes between the encoder and the whole-field kernel (64 B per sample)
     // are bounded whatever the burst length (FOC_OCC_FIELD_PIECE, samples; default 2^23. Measured on the 800 x 800 view, 5.1 M samples per iteration:
     // one piece 18.5 ms per view, pieces of 2^21 — planes that fit the 256 MiB Infinity Cache — 19.3, of 2^20 20.0: fewer launches win)
-    const char *piece_env = getenv("FOC_OCC_FIELD_PIECE");
-    uint64_t piece = piece_env ? (uint64_t)atoll(piece_env) : (1ull << 23);
+    uint64_t piece = (uint64_t)(uint32_t)foc_opt(FOC_OPT_OCC_FIELD_PIECE);
     if (piece < 1024) piece = 1024;
     piece &= ~(uint64_t)63;
     for (uint64_t m0 = 0; m0 < M; m0 += piece) {

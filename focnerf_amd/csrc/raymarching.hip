@@ -684,77 +684,6 @@ __global__ void __launch_bounds__(64) k_march_rays_staged(uint32_t n_alive, uint
     }
 }
 
-// ---------------------------------------------------------------- R9, one ray per lane, K lattice points per round
-// With hundreds of thousands of rays alive an iteration asks every ray for ONE sample: a ray inside the object evaluates one cell and is
-// done, but every iteration also has rays that have just left the object and walk ~100 empty cells to the far side of the box — a chain
-// of ~100 dependent bitfield lookups that their whole wave waits for (51 us per launch, of which the cell evaluations proper are ~3 us).
-// The values t can take are a fixed lattice per ray (see k_march_count_wave), so a lane can look K lattice points AHEAD with K
-// independent loads and then replay the loop's control flow on the K results: visits, emissions and voxel-exit skips are those of the
-// serial loop (raymarching.cu:745-795), bit for bit, with chains K times shorter. The first window is one point wide (the common case
-// costs what it did); every later window K = 8.
-struct RmWalk { float t, last_t, tt; uint32_t step; bool skipping, done; };
-
-template <int K, bool MED3>
-__device__ __forceinline__ void rm_window(RmWalk &w, const uint8_t *__restrict__ grid, const RmParams &p, float ox, float oy, float oz, float dx, float dy,
-                                          float dz, float rdx, float rdy, float rdz, float far, uint32_t n_step, float *__restrict__ px, float *__restrict__ pd,
-                                          float *__restrict__ pl) {
-    float L[K], cx[K], cy[K], cz[K], cdt[K], ex[K];
-    bool occ[K];
-    float t = w.t;
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        L[j] = t;
-        const float raw = t * p.dt_gamma;
-        t += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
-    }
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        RmCell c;
-        occ[j] = rm_cell(grid, p, ox, oy, oz, dx, dy, dz, L[j], c);
-        cx[j] = c.x; cy[j] = c.y; cz[j] = c.z; cdt[j] = c.dt;
-        ex[j] = rm_skip_target(p, c, L[j], dx, dy, dz, rdx, rdy, rdz);
-    }
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        if (w.done || (w.skipping && L[j] < w.tt)) continue;                 // past the loop's end / still inside `do { t += dt } while (t < tt)`
-        w.skipping = false;
-        if (!(L[j] < far) || w.step >= n_step) { w.done = true; continue; }    // the loop condition of raymarching.cu:745
-        if (occ[j]) {
-            const float t_new = L[j] + cdt[j];
-            px[w.step * 3] = rm_out(p, cx[j]); px[w.step * 3 + 1] = rm_out(p, cy[j]); px[w.step * 3 + 2] = rm_out(p, cz[j]);
-            pd[w.step * 3] = dx; pd[w.step * 3 + 1] = dy; pd[w.step * 3 + 2] = dz;
-            pl[w.step * 2] = cdt[j]; pl[w.step * 2 + 1] = t_new - w.last_t;
-            w.last_t = t_new;
-            w.step++;
-        } else { w.skipping = true; w.tt = ex[j]; }        // at least one advance: the next candidate is point j + 1
-    }
-    w.t = t;
-}
-
-template <bool MED3>
-__global__ void __launch_bounds__(64) k_march_rays_spec(uint32_t n_alive, uint32_t n_step, const int32_t *__restrict__ rays_alive,
-                             const float *__restrict__ rays_t, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                             const uint8_t *__restrict__ grid, RmParams p, const float *__restrict__ fars,
-                             float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                             const float *__restrict__ noises) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    if (index < 0) return;             // dead list entry (see k_march_rays)
-    const float ox = rays_o[index * 3], oy = rays_o[index * 3 + 1], oz = rays_o[index * 3 + 2];
-    const float dx = rays_d[index * 3], dy = rays_d[index * 3 + 1], dz = rays_d[index * 3 + 2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    float *px = xyzs + (uint64_t)n * n_step * 3, *pd = dirs + (uint64_t)n * n_step * 3, *pl = deltas + (uint64_t)n * n_step * 2;
-    const float far = fars[index];
-    RmWalk w;
-    w.t = rays_t[index];
-    w.t = fmaf(rm_clamp(w.t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], w.t);
-    w.last_t = w.t; w.tt = 0.0f; w.step = 0; w.skipping = false; w.done = false;
-    rm_window<1, MED3>(w, grid, p, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, n_step, px, pd, pl);
-    for (uint32_t round = 0; round < RM_MAX_ROUNDS && !w.done; round++)
-        rm_window<8, MED3>(w, grid, p, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, far, n_step, px, pd, pl);
-}
-
 // ---------------------------------------------------------------- R9, G lanes per ray
 // k_march_rays above is a chain of dependent bitfield lookups per ray, and a render iteration has few rays left alive (the host loop keeps
 // live x n_step <= N, so most iterations march ~N/8 rays by 8 samples: about one wave per SIMD, nothing to hide a lookup's latency
@@ -1222,9 +1151,8 @@ static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_
     // of dependent lookups 64x shorter. That pays while the lane-per-ray kernel is latency-bound. Measured per call (tools/
     // time_march_modes.py, wave / lane): 4096 rays 77 / 138 us, 8192 127 / 178, 16384 221 / 267, 32768 417 / 278, 65536 825 / 460.
     // FOC_MARCH_SERIAL=1 / 0 forces one.
-    static int forced = -2;
-    if (forced == -2) { const char *e = getenv("FOC_MARCH_SERIAL"); forced = e ? (atoi(e) ? 1 : 0) : -1; }
-    const bool serial = forced >= 0 ? forced == 1 : N > 16384u;
+    const int forced = foc_opt(FOC_OPT_MARCH_SERIAL);
+    const bool serial = forced >= 0 ? forced != 0 : N > 16384u;
     if (serial)
         hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
     else
@@ -1311,15 +1239,11 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
     // the row form takes; 0 = never). Measured on the 800 x 800 occupancy render (profiles/, tools/quick_render_stats.sh; 549 launches,
     // most of them with > 262 144 rays alive and one sample per ray): one ray per lane 48.1 us average; the row form for every launch
     // 79.9 us (16x the cell evaluations where a ray needs one); row form up to 65 536 / 131 072 rays: 26-28 us on those launches (120 of
-    // 549) against ~40 us. The 8-points-ahead lane form (k_march_rays_spec, FOC_MARCH_RAYS_SPEC=1) measured 53.8 us against 48.1: with
+    // 549) against ~40 us. A lane form looking 8 lattice points ahead measured 53.8 us against 48.1 (round 3; removed): with
     // ~10 waves per SIMD the big launches are bound by the divergent walks' instruction count, not by their lookup chains.
-    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");          // read per call: the tests run all forms in one process
-    const long row_max = row_env ? atol(row_env) : 131072;
+    const long row_max = foc_opt(FOC_OPT_MARCH_RAYS_ROW_MAX);
     if ((long)n_alive <= row_max && n_step <= 16u)
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_row<true> : k_march_rays_row<false>, dim3(foc_div_up((uint64_t)n_alive * 16u, 256)), dim3(256), 0,
-                           (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
-    else if (getenv("FOC_MARCH_RAYS_SPEC"))                // one ray per lane, 8 lattice points per round (A/B runs, tests)
-        hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_rays_spec<true> : k_march_rays_spec<false>, dim3(foc_div_up(n_alive, 64)), dim3(64), 0,
                            (hipStream_t)stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars, xyzs, dirs, deltas, noises);
     else
         hipLaunchKernelGGL(k_march_rays, dim3(foc_div_up(n_alive, 64)), dim3(64), 0, (hipStream_t)stream, n_alive, n_step, rays_alive,
@@ -1333,9 +1257,7 @@ int foc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
 // (tools/time_occ_burst.py; 640 000 rays alive for most of it, bursts of 8): form 3 15.8 ms per view, form 1 17.4, form 2 18.2, form 0 18.8
 // — with ten waves per SIMD the lanes' lookup chains hide each other and what counts is instructions and how the samples reach memory.
 static int rm_burst_form(uint32_t n_step, uint32_t n_alive, bool rederive = false) {
-    const char *form_env = getenv("FOC_OCC_MARCH_FORM");
-    int forced = -1;
-    if (form_env && form_env[0]) forced = form_env[0] == 'r' ? 1 : form_env[0] == 'l' ? 2 : form_env[0] == 's' ? 3 : 0;
+    const int forced = foc_opt(FOC_OPT_OCC_MARCH_FORM);
     // the forms that generate a ray's lattice 16 points ahead (row, the walkers of the two phases) cannot re-derive t sample by sample
     if (rederive && n_step > 1u) return forced == 2 ? 2 : 3;
     if (forced >= 0) return forced;
@@ -1391,8 +1313,7 @@ int foc_march_rays_two_phase(uint32_t n_alive, uint32_t n_step, const int32_t *r
     hipLaunchKernelGGL(k_march_rays_first, dim3(foc_div_up(n_alive, 256)), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid, p, fars,
                        xyzs, dirs, deltas, noises, worklist, wl_count);
     FOC_CHECK_LAUNCH("march_rays(first visits)");
-    const char *row_env = getenv("FOC_MARCH_RAYS_ROW_MAX");
-    const uint32_t row_max = (uint32_t)(row_env ? atol(row_env) : 131072);
+    const uint32_t row_max = (uint32_t)max(0, foc_opt(FOC_OPT_MARCH_RAYS_ROW_MAX));
     uint32_t blocks = foc_div_up((uint64_t)n_alive * 16u, 256);
     if (blocks > 4096u) blocks = 4096u;                     // 16 workgroups per CU; longer worklists are walked grid-stride
     hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_walkers<true> : k_march_walkers<false>, dim3(blocks), dim3(256), 0, st, n_alive, n_step, rays_alive, rays_t,

@@ -36,7 +36,12 @@ def single_pass_backward(input_dim, hidden_dim, num_layers, activation=0):
     every NeRF network; the reference's other hidden activations (exponential, sine, sigmoid, squareplus, softplus, utils.h:424-589) take
     its own data flow, stored activations and a [layers, B, hidden] gradient buffer."""
     return (activation in (ACTIVATIONS['relu'], NO_ACTIVATION) and hidden_dim <= 64 and input_dim <= 64 and 2 <= num_layers <= 4
-            and os.environ.get("FOC_MLP_BWD_FUSED", "1") != "0")
+            and _fused_backward_switch())
+
+
+def _fused_backward_switch():
+    from ._lib import get_option
+    return get_option("FOC_MLP_BWD_FUSED") != 0
 
 
 _fused_backward_ok = single_pass_backward       # name used by focnerf_amd.field

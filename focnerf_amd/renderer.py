@@ -330,7 +330,8 @@ class NeRFRenderer(nn.Module):
         # would run them (its burst rule on the exact live count, one host round trip each) — same image, bit for bit, cap included.
         wide = min(max(int(os.environ.get("FOC_RENDER_BURST", "8")), 1), 16)
         cap = n * wide                                         # most samples of one iteration (the reference's own bursts keep live x burst <= n)
-        piece = min(cap, max(1024, int(os.environ.get("FOC_OCC_FIELD_PIECE", str(1 << 23)))))
+        from ._lib import get_option
+        piece = min(cap, max(1024, get_option("FOC_OCC_FIELD_PIECE")))
         samples = torch.empty(cap * 8, dtype=torch.float32, device=dev)
         planes = torch.empty(L * piece * 2, dtype=torch.float16, device=dev)
         sigma, rgb = torch.empty(cap, dtype=torch.float32, device=dev), torch.empty(cap * 3, dtype=torch.float32, device=dev)

@@ -40,6 +40,12 @@ extern "C" {
 int         foc_abi_version(void);
 /* Thread-local message of the last non-zero return on this thread ("" if none). */
 const char *foc_last_error(void);
+/* Tuning / test switches (csrc/common.h FocOpt): ints with a default, initialised once from the environment variable of the same name
+ * (FOC_MLP_BWD_FUSED, FOC_GB_MERGE_MAX_RES, FOC_GB_FACTORED, FOC_GB_TAIL_SPLIT, FOC_GRID_FUSE_SMALL, FOC_GRID_PAIRS, FOC_GRID_FAST,
+ * FOC_MARCH_SERIAL, FOC_MARCH_RAYS_ROW_MAX, FOC_OCC_MARCH_FORM, FOC_OCC_SAMPLE_MAJOR, FOC_OCC_FIELD_PIECE — INTEGRATION.md has the table)
+ * and changeable at run time; no entry point reads the environment per call. Unknown name: FOC_E_INVALID. */
+int foc_set_option(const char *name, int value);
+int foc_get_option(const char *name, int *value);
 /* Which device an entry point makes current for its call (host-only query of the rule, for tests): a non-null stream's device; for the
  * NULL stream (it exists on every device) the device the first pointer argument lives on; else the current device. -1 = unknown. */
 int foc_guard_pick_device(int stream_is_null, int stream_device, int pointer_device, int current_device);

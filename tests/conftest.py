@@ -23,3 +23,21 @@ def golden_dir():
 def _build_oracle():
     import oracle
     oracle.build()
+
+
+@pytest.fixture
+def lib_option():
+    """`lib_option(name, value)` sets a switch of libfocnerf_hip.so (include/focnerf.h foc_set_option) for the rest of the test; every
+    switch touched goes back to what it was afterwards. FOC_OCC_MARCH_FORM takes its names ("two", "row", "lane", "staged"; "" = by
+    burst length). The library reads its environment once, at load: setting the variable inside a test would reach nothing."""
+    from focnerf_amd import _lib
+    forms = {"": -1, "two": 0, "row": 1, "lane": 2, "staged": 3}
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, forms[value] if isinstance(value, str) and value in forms else int(value))
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -598,7 +598,7 @@ def test_encoder_mlp_node_replays_in_a_hip_graph_with_new_data():
             assert (gw_s.float() - gw.float()).abs().max().item() <= 2e-3 * scale, f"weight gradient, round {rounds}"
 
 
-def test_factored_records_agree_with_the_two_corner_records(monkeypatch):
+def test_factored_records_agree_with_the_two_corner_records(lib_option):
     """Unmerged hashed levels send a pair of corners as 8 bytes {row, jb, fx, half2 p} and the reduce rebuilds (1 - fx) p and fx p
     (csrc/gridencoder.hip, k_gbin_scatter_pms / k_gbin_reduce). Against the 12-byte form (both addends rounded to half by the scatter):
     p is rounded once before the split and fx carries 15 bits, so an addend moves by at most ~1 half-ulp; both forms are deterministic,
@@ -613,7 +613,7 @@ def test_factored_records_agree_with_the_two_corner_records(monkeypatch):
     g = torch.from_numpy(grad).cuda()
     res = {}
     for mode in ("0", "1", "1"):
-        monkeypatch.setenv("FOC_GB_FACTORED", mode)
+        lib_option("FOC_GB_FACTORED", int(mode))
         ge = torch.zeros(int(off[-1]), C, dtype=torch.float16, device="cuda")
         _be().grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=False)
         if mode in res:
@@ -669,3 +669,27 @@ def test_levels_of_2_to_the_23_rows_take_the_generic_index_path(dtype):
     inb = np.all((x >= 0) & (x <= 1), axis=1)
     for l in range(L):
         np.testing.assert_allclose(got[off[l]:off[l + 1]].astype(np.float64).sum(0), grad[l][inb].astype(np.float64).sum(0), atol=1e-3 if dtype == np.float32 else 0.5)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_scatter_tail_split_is_bitwise_the_whole_tile_form(dtype, lib_option):
+    """The last partial round of scatter workgroups is dealt out by level group (csrc/gridencoder.hip k_gbin_scatter_pms: FOC_GB_TAIL_SPLIT
+    workgroups per tile, 16 / 8 / 4 / 2 levels each): the same record ranges, the same records, the same sums as whole tiles
+    (FOC_GB_TAIL_SPLIT=1) — bit for bit, for every split the launch rule can pick, ragged last tile and clustered points included."""
+    D, C, L, H, lh, desired, gridtype, ac, interp = CASES[0]
+    pls, S, off, table = _setup(D, C, L, H, lh, desired, 3, dtype)
+    B = 5 * 1024 + 77                                  # six tiles, the last one ragged; every one of them is "tail" on a 256-CU chip
+    x = _points(B, D, 31)
+    x[::5] = x[::5] * 0.03 + 0.45                       # clustered points: uneven segments
+    grad = (np.random.default_rng(32).standard_normal((L, B, C)) * 0.25).astype(dtype)
+    xt, tt, ot, g = torch.from_numpy(x).cuda(), torch.from_numpy(table).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(grad).cuda()
+    tdt = torch.float16 if dtype == np.float16 else torch.float32
+    res = {}
+    for split in (1, 2, 4, 8, 16):
+        lib_option("FOC_GB_TAIL_SPLIT", split)
+        ge = torch.zeros(int(off[-1]), C, dtype=tdt, device="cuda")
+        _be().grid_encode_backward(g, xt, tt, ot, ge, B, D, C, L, S, H, None, None, gridtype, ac, interp, grad_bl=False)
+        res[split] = ge
+    for split in (2, 4, 8, 16):
+        assert torch.equal(res[split], res[1]), split
+    assert res[1].abs().max() > 0

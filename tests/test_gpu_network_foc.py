@@ -439,9 +439,9 @@ def test_occ_render_step_with_object_feature():
     M = n * burst
     S = float(np.log2(enc.per_level_scale))
     results = {}
+    from focnerf_amd._lib import option
     for sm in ("1", "0"):
-        os.environ["FOC_OCC_SAMPLE_MAJOR"] = sm
-        try:
+        with option("FOC_OCC_SAMPLE_MAJOR", int(sm)):
             samples = torch.full((M * 8,), float("nan"), device="cuda")
             planes = torch.empty(L * M * 2, dtype=torch.float16, device="cuda")
             sigma, rgb = torch.empty(M, device="cuda"), torch.empty(M * 3, device="cuda")
@@ -475,7 +475,5 @@ def test_occ_render_step_with_object_feature():
                 assert torch.equal(a, b)
             assert int(count) == int((alive2 >= 0).sum()) and ws.max() > 0.05
             results[sm] = (ws, dp, im)
-        finally:
-            os.environ.pop("FOC_OCC_SAMPLE_MAJOR", None)
     for a, b in zip(results["1"], results["0"]):
         assert torch.equal(a, b)

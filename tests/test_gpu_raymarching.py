@@ -268,24 +268,19 @@ def _analytic_field(x, d):
     return sig, rgb
 
 
-def _set_march_form(monkeypatch, form):
-    """R9's three forms: 16 lanes per ray (k_march_rays_row), one ray per lane looking 8 lattice points ahead (k_march_rays_spec), and
-    the plain one-lookup-at-a-time loop (k_march_rays)."""
-    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "1000000000" if form == "row" else "0")
-    if form == "spec":
-        monkeypatch.setenv("FOC_MARCH_RAYS_SPEC", "1")
-    else:
-        monkeypatch.delenv("FOC_MARCH_RAYS_SPEC", raising=False)
+def _set_march_form(lib_option, form):
+    """R9's two forms behind foc_march_rays: 16 lanes per ray (k_march_rays_row) and the plain one-lookup-at-a-time loop (k_march_rays)."""
+    lib_option("FOC_MARCH_RAYS_ROW_MAX", 1000000000 if form == "row" else 0)
 
 
-@pytest.mark.parametrize("form", ["row", "spec", "serial"])
+@pytest.mark.parametrize("form", ["row", "serial"])
 @pytest.mark.parametrize("perturb", [False, True])
-def test_inference_loop_final_image_without_resync(rm, form, perturb, monkeypatch):
+def test_inference_loop_final_image_without_resync(rm, form, perturb, lib_option):
     """The whole inference loop of legacy/nerf/renderer.py:323-372 run TWICE, independently: on the oracle and on the GPU, each on its own
     state from the first iteration to the last (device-side compaction, no per-iteration re-synchronisation) — an error that builds up in
     composite_rays or march_rays over the iterations would show in the final image. Tolerated: the counted rays whose transmittance crosses
     T_thresh one sample earlier or later (__expf vs expf at the boundary), each of which moves a pixel by <= ~T_thresh. All forms of R9."""
-    _set_march_form(monkeypatch, form)
+    _set_march_form(lib_option, form)
     N = 4000                                           # scene() draws from a 64 x 64 view: at most 4096 rays
     s, n_ref, f_ref, noises = _march_case(2, N, 1 / 128, perturb, seed=13)
     assert s["rays_o"].shape[0] == N
@@ -342,13 +337,13 @@ def test_inference_loop_final_image_without_resync(rm, form, perturb, monkeypatc
     np.testing.assert_allclose(to_np(gdp)[~flips], dp[~flips], atol=2e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("form", ["row", "spec", "serial"])
-def test_inference_march_and_composite_loop(rm, form, monkeypatch):
+@pytest.mark.parametrize("form", ["row", "serial"])
+def test_inference_march_and_composite_loop(rm, form, lib_option):
     """legacy/nerf/renderer.py:323-372 loop, oracle vs GPU, with an analytic field standing in for the network. Per iteration: sample
     positions / directions / deltas bit for bit (all forms of R9), composite state within RGB_TOL; the
     state is re-synchronised to the oracle's after each iteration so that every iteration's inputs are identical (the un-synchronised
     end-to-end comparison is test_inference_loop_final_image_without_resync)."""
-    _set_march_form(monkeypatch, form)
+    _set_march_form(lib_option, form)
     N = 3000
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
     C, H, max_steps, T_thresh = s["cascade"], 128, 1024, 1e-4
@@ -440,13 +435,13 @@ def test_full_view_march_properties(rm):
     assert torch.allclose(im[:, 0].double(), 0.25 * want, atol=2e-5)
 
 
-@pytest.mark.parametrize("form", ["row", "spec", "serial"])
-def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
+@pytest.mark.parametrize("form", ["row", "serial"])
+def test_dead_list_entries_are_skipped(rm, form, lib_option):
     """A ray list with -1 entries (what composite_rays leaves behind, and what `compact_alive(pad=True)` puts behind the count): march_rays
     writes nothing for them (their slots stay zero = "terminated"), composite_rays leaves them and every per-ray accumulator alone — the
     live entries get exactly what the compacted list gets. This is what lets the render loop hand on a list whose true length it has not
     read back yet."""
-    _set_march_form(monkeypatch, form)
+    _set_march_form(lib_option, form)
     N, n_step = 1500, 4
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
     C, H = s["cascade"], 128
@@ -483,18 +478,15 @@ def test_dead_list_entries_are_skipped(rm, form, monkeypatch):
 
 @pytest.mark.parametrize("n_step", [1, 4, 8, 16])
 @pytest.mark.parametrize("row_max,form", [("1000000000", "two"), ("0", "two"), ("0", "row"), ("0", "lane"), ("0", "staged"), ("0", "")])
-def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, form, monkeypatch):
+def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step, row_max, form, lib_option):
     """foc_march_rays_two_phase == foc_march_rays bit for bit in each of its forms — the two phases (first visits per lane, walkers compacted
     and marched again, 16 lanes per ray / one ray per lane), the 16-lanes-per-ray kernel that stages a ray's samples in LDS and writes every
     slot itself (buffers handed over full of NaN), one ray per lane, and the form it picks by burst length; its normalised output ==
     (x + bound) * (1 / (2 bound)); foc_composite_compact (register-resident bursts of 4, 8, 16) == composite_rays + compact_alive (list, count,
     every accumulator)."""
     from focnerf_amd._lib import lib, ptr, stream_of, check
-    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
-    if form:
-        monkeypatch.setenv("FOC_OCC_MARCH_FORM", form)
-    else:
-        monkeypatch.delenv("FOC_OCC_MARCH_FORM", raising=False)
+    lib_option("FOC_MARCH_RAYS_ROW_MAX", row_max)
+    lib_option("FOC_OCC_MARCH_FORM", form or "")
     N = 3000
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=9)
     C, H = s["cascade"], 128
@@ -505,9 +497,9 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
     t_now = nears.clone()
     noises = torch.zeros(N, device="cuda")
     M = N * n_step
-    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "0")             # reference call: the plain serial kernel
+    lib_option("FOC_MARCH_RAYS_ROW_MAX", 0)                       # reference call: the plain serial kernel
     x0, d0, l0 = rm.march_rays(N, n_step, lst, t_now, o, d, s["bound"], bits, C, H, nears, fars, -1, False, 1 / 128, 1024)
-    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", row_max)
+    lib_option("FOC_MARCH_RAYS_ROW_MAX", row_max)
     st = stream_of(o)
     for normalised in (0, 1):
         fills = bool(lib.foc_march_rays_two_phase_fills(n_step, normalised))
@@ -562,15 +554,12 @@ def test_two_phase_march_and_composite_compact_equal_the_single_calls(rm, n_step
 
 @pytest.mark.parametrize("form", ["staged", "lane", ""])
 @pytest.mark.parametrize("max_steps", [37, 1024])
-def test_rederived_burst_equals_single_sample_calls(rm, form, max_steps, monkeypatch):
+def test_rederived_burst_equals_single_sample_calls(rm, form, max_steps, lib_option):
     """foc_march_rays_two_phase with flag bit 1: a burst of k samples == k calls of the reference kernel with n_step = 1, each continued from
     rays_t + deltas[:,1] the way composite_rays hands t to the next call (raymarching.cu:871, 899) — bit for bit, also where a skip over
     empty space more than doubles t and t - last_t is rounded (max_steps 37: steps of dt_max; rays starting inside the box at t = 0.2)."""
     from focnerf_amd._lib import lib, ptr, stream_of, check
-    if form:
-        monkeypatch.setenv("FOC_OCC_MARCH_FORM", form)
-    else:
-        monkeypatch.delenv("FOC_OCC_MARCH_FORM", raising=False)
+    lib_option("FOC_OCC_MARCH_FORM", form or "")
     N, k = 4000, 8
     s, n_ref, f_ref, _ = _march_case(2, N, 1 / 128, False, seed=11, max_steps=max_steps)
     C, H = s["cascade"], 128
@@ -583,7 +572,7 @@ def test_rederived_burst_equals_single_sample_calls(rm, form, max_steps, monkeyp
     nears, fars = torch.from_numpy(n_ref).cuda(), torch.from_numpy(f_ref).cuda()
     lst = torch.arange(N, dtype=torch.int32, device="cuda")
     # reference: k single-sample calls, t handed on as composite_rays does (fp32 add of deltas[:,1]); a ray that returned no sample is finished
-    monkeypatch.setenv("FOC_MARCH_RAYS_ROW_MAX", "0")
+    lib_option("FOC_MARCH_RAYS_ROW_MAX", 0)
     t_now = nears.clone()
     alive = torch.ones(N, dtype=torch.bool, device="cuda")
     want_x, want_l = torch.zeros(N, k, 3, device="cuda"), torch.zeros(N, k, 2, device="cuda")

@@ -3,6 +3,7 @@ reference's schedule (boolean-mask compaction): prints every combination whose i
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from focnerf_amd import _lib
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from focnerf_amd import synthetic
 from test_gpu_network import _model
@@ -13,7 +14,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
     for burst in ("1", "2", "3", "4", "5", "8"):
         for form in ("", "row", "staged", "lane", "two"):
             os.environ["FOC_RENDER_BURST"] = burst
-            os.environ["FOC_OCC_MARCH_FORM"] = form
+            _lib.set_option("FOC_OCC_MARCH_FORM", {"": -1, "two": 0, "row": 1, "lane": 2, "staged": 3}[form])
             for max_steps, thresh in ((1024, 1e-4), (100, 1e-4), (37, 1e-4), (1024, 0.3)):
                 kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=max_steps, bg_color=1.0, T_thresh=thresh)
                 a = m.render(o, d, device_compaction=False, **kw)

@@ -16,12 +16,9 @@ alive = torch.arange(N, dtype=torch.int32, device="cuda")
 print("setup done", flush=True)
 for n_step in (1, 3, 8):
     outs = {}
-    for form, v in (("lane", "0"), ("row", "1000000000"), ("spec", "0")):
-        os.environ["FOC_MARCH_RAYS_ROW_MAX"] = v
-        if form == "spec":
-            os.environ["FOC_MARCH_RAYS_SPEC"] = "1"
-        else:
-            os.environ.pop("FOC_MARCH_RAYS_SPEC", None)
+    for form, v in (("lane", 0), ("row", 1000000000)):
+        from focnerf_amd import _lib
+        _lib.set_option("FOC_MARCH_RAYS_ROW_MAX", v)
         M = N * n_step
         x = torch.zeros(M, 3, device="cuda"); dd = torch.zeros(M, 3, device="cuda"); dl = torch.zeros(M, 2, device="cuda")
         t0 = time.perf_counter()
@@ -30,7 +27,7 @@ for n_step in (1, 3, 8):
         torch.cuda.synchronize()
         print(form, "n_step", n_step, "ms", 1000 * (time.perf_counter() - t0), flush=True)
         outs[form] = (x.cpu().numpy(), dd.cpu().numpy(), dl.cpu().numpy())
-    for other in ("row", "spec"):
+    for other in ("row",):
         for a, b, name in zip(outs["lane"], outs[other], ("xyzs", "dirs", "deltas")):
             same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
             print(" ", other, name, "bitwise equal" if same else f"DIFFER at {np.argwhere(a != b)[:5].tolist()}", flush=True)

@@ -14,9 +14,11 @@ kw = dict(staged=False, perturb=False, dt_gamma=1 / 128, max_steps=1024, T_thres
 
 
 def run(env, reps=4):
-    for k in ("FOC_RENDER_BURST", "FOC_OCC_MARCH_FORM", "FOC_OCC_FIELD_PIECE"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    # FOC_RENDER_BURST is read by the Python loop per view; the other two are switches of the library (set through foc_set_option)
+    from focnerf_amd import _lib
+    os.environ["FOC_RENDER_BURST"] = env.get("FOC_RENDER_BURST", "8")
+    _lib.set_option("FOC_OCC_MARCH_FORM", {"": -1, "two": 0, "row": 1, "lane": 2, "staged": 3}[env.get("FOC_OCC_MARCH_FORM", "")])
+    _lib.set_option("FOC_OCC_FIELD_PIECE", int(env.get("FOC_OCC_FIELD_PIECE", str(1 << 23))))
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         out = m.render(o, d, **kw)
         torch.cuda.synchronize()
