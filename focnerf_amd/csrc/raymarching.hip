@@ -149,6 +149,8 @@ struct RmParams {
     float norm_inv;                    // 0: sample positions leave as they are; else they leave as (x + bound) * norm_inv, the encoder's [0,1] coordinates
     int rederive;                      // != 0: after every emitted sample t continues from last_t + (t - last_t), the value composite_rays hands to the NEXT call
                                        // (raymarching.cu:871, 899) — a burst of k samples then marches what k calls of one sample would (see foc_march_rays_two_phase)
+    int gamma_pow2;                    // dt_gamma is a power of two (1/128, the reference's default for its scenes): t * dt_gamma is exact, so t + t * dt_gamma
+                                       // rounds once — it IS fmaf(t, dt_gamma, t)
 };
 // position of an emitted sample as it is stored (the native render step asks for the normalised form: csrc/occrender.hip)
 __device__ __forceinline__ float rm_out(const RmParams &p, float x) { return p.norm_inv != 0.0f ? (x + p.bound) * p.norm_inv : x; }
@@ -204,6 +206,8 @@ static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, 
     p.H = H;
     p.norm_inv = 0.0f;
     p.rederive = 0;
+    int e = 0;
+    p.gamma_pow2 = (dt_gamma > 0.0f && frexpf(dt_gamma, &e) == 0.5f) ? 1 : 0;
     return p;
 }
 
@@ -264,11 +268,48 @@ __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restric
         // lane j: t_cur advanced j times. Every lane runs the same recurrence; each new value enters at lane 63 while the earlier
         // ones move down one lane (DPP wave_shl:1), so the 64th insertion leaves value j in lane j and costs one move per step.
         float T = t_cur, t_next = t_cur;
+        // The step clamp(t dt_gamma, dt_min, dt_max) has three regimes and t only grows: a ray walks dt_min steps near the camera, then
+        // t dt_gamma, then dt_max. A round that lies in ONE regime needs no clamp — its 64 steps are `t += dt_min`, `t += t dt_gamma`
+        // (one fma when dt_gamma is a power of two) or `t += dt_max`, the same values bit for bit — which halves the instructions of the
+        // recurrence (move + 1 instead of move + mul + med3 + add; the recurrence is half of this kernel's VALU work). The regime is
+        // read off the round's first point and confirmed on its last one (lane 63 after the loop); a round that crosses a boundary —
+        // at most two per ray — is generated again with the general step.
+        bool fast = false;
+        if constexpr (MED3) {
+            const float raw0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t_cur * p.dt_gamma)));
+            const int regime = raw0 <= p.dt_min ? 0 : (raw0 >= p.dt_max ? 2 : 1);
+            if (regime == 0 || regime == 2) {
+                const float step = regime == 0 ? p.dt_min : p.dt_max;
 #pragma unroll 8
-        for (uint32_t j = 0; j < 64; j++) {
-            T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
-            const float raw = t_next * p.dt_gamma;             // for ordered operands the median IS fminf(hi, fmaxf(lo, x)), bit for bit
-            t_next += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
+                for (uint32_t j = 0; j < 64; j++) {
+                    T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
+                    t_next += step;
+                }
+            } else if (p.gamma_pow2) {
+#pragma unroll 8
+                for (uint32_t j = 0; j < 64; j++) {
+                    T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
+                    t_next = fmaf(t_next, p.dt_gamma, t_next);
+                }
+            } else {
+#pragma unroll 8
+                for (uint32_t j = 0; j < 64; j++) {
+                    T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
+                    t_next += t_next * p.dt_gamma;
+                }
+            }
+            // the last point the general step would have clamped: lattice point 63 (in lane 63 now)
+            const float raw63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T), 63)) * p.dt_gamma;
+            fast = regime == 0 ? raw63 <= p.dt_min : (regime == 2 ? true : raw63 <= p.dt_max);
+        }
+        if (!fast) {
+            T = t_cur; t_next = t_cur;
+#pragma unroll 8
+            for (uint32_t j = 0; j < 64; j++) {
+                T = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t_next), __builtin_bit_cast(int, T), 0x130, 0xf, 0xf, false));
+                const float raw = t_next * p.dt_gamma;             // for ordered operands the median IS fminf(hi, fmaxf(lo, x)), bit for bit
+                t_next += MED3 ? __builtin_amdgcn_fmed3f(raw, p.dt_min, p.dt_max) : rm_clamp(raw, p.dt_min, p.dt_max);
+            }
         }
         const uint64_t in_range = __ballot(T < far);
         uint32_t k = 0;                                    // lane of the lattice point the loop is at
@@ -287,26 +328,60 @@ __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restric
         const float exit_here = rm_skip_target(p, c, T, dx, dy, dz, rdx, rdy, rdz);
         const uint64_t emit_ok = __ballot(occupied_here) & in_range;
         uint64_t emitted = 0ull;
-        uint32_t room = max_steps - num_steps;             // > 0 here
-        bool done = false;
-        while (k < 64u) {
-            if (!((in_range >> k) & 1ull) || room == 0u) { done = true; break; }       // the loop condition of :359
-            if ((emit_ok >> k) & 1ull) {                   // a run of occupied points: each emits and steps to its successor
-                const uint64_t rest = ~(emit_ok >> k);     // bit 0 clear
-                uint32_t len = rest ? (uint32_t)__builtin_ctzll(rest) : 64u - k;
-                len = len < 64u - k ? len : 64u - k;
-                len = len < room ? len : room;
-                emitted |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << k;
-                room -= len;
-                k += len;
-            } else {
-                const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, exit_here), (int)k));
-                const uint64_t above = k >= 63u ? 0ull : (~0ull << (k + 1u));
-                const uint64_t landed = __ballot(!(T < tt)) & above;                    // do { advance } while (t < tt): at least one advance
-                if (landed == 0ull) { skipping = true; skip_to = tt; break; }
-                k = (uint32_t)__builtin_ctzll(landed);
-            }
+        uint32_t room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(max_steps - num_steps));
+        // The replay is scalar code — one iteration per visited point, ~50 of them per round in empty space — and the CU has ONE scalar unit
+        // for its sixteen waves: the kernel was bound by it (SQ counters: 3970 scalar against 3040 vector instructions per wave, the
+        // compiler's lowering of the loop with its `done` / `skipping` flags ran to ~40 scalar instructions per iteration). Hence the
+        // spare form: in_range is a PREFIX mask (t only grows), so "the point is out of range" is k >= k_far; one exit code instead of
+        // flags; the mask of the lanes above k as one shift; and the walk over empty points as a hand-written block.
+        const uint32_t k_far = ~in_range ? (uint32_t)__builtin_ctzll(~in_range) : 64u;       // first lattice point at or beyond `far`
+        int state = room == 0u ? 1 : 0;                    // 0: ran off the 64 points; 1: the loop of :359 ended (far / step cap); 2: a skip carries over
+        uint32_t ks = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        // (wave-uniform by construction; said again so that the block's scalar operands are scalar registers)
+        const uint32_t k_far_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_far);
+        const uint64_t emit_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(emit_ok >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)emit_ok);
+        while (state == 0) {
+            // Walk over EMPTY points until an occupied one, the end of the range or a skip that leaves the 64 points. Hand-written: nine
+            // instructions per visited point (seven of them scalar) where the compiler's lowering of the same loop took about thirty.
+            //   why 0: ks >= k_far      why 1: the point at ks is occupied      why 2: no point of this round lies at or beyond the voxel exit
+            uint32_t why, tt_bits;
+            uint64_t tmp;
+            asm volatile("1:\n\t"
+                         "s_cmp_ge_u32 %[k], %[kfar]\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_bitcmp1_b64 %[emit], %[k]\n\t"
+                         "s_cbranch_scc1 3f\n\t"
+                         "s_nop 3\n\t"                                      // SALU wrote %[k]: four wait states before it selects a lane
+                         "v_readlane_b32 %[tt], %[exitv], %[k]\n\t"         // the voxel exit of the point at ks
+                         "s_lshl_b64 %[tmp], -2, %[k]\n\t"                  // the lanes above ks: do { advance } while (t < tt) advances at least once
+                         "v_cmp_ngt_f32_e32 vcc, %[tt], %[T]\n\t"           // !(tt > T) == !(T < tt)
+                         "s_and_b64 %[tmp], vcc, %[tmp]\n\t"
+                         "s_cbranch_scc0 4f\n\t"
+                         "s_ff1_i32_b64 %[k], %[tmp]\n\t"
+                         "s_branch 1b\n\t"
+                         "2: s_mov_b32 %[why], 0\n\t"
+                         "s_branch 5f\n\t"
+                         "3: s_mov_b32 %[why], 1\n\t"
+                         "s_branch 5f\n\t"
+                         "4: s_mov_b32 %[why], 2\n\t"
+                         "5:"
+                         : [k] "+s"(ks), [tt] "=&s"(tt_bits), [tmp] "=&s"(tmp), [why] "=&s"(why)
+                         : [kfar] "s"(k_far_s), [emit] "s"(emit_s), [exitv] "v"(exit_here), [T] "v"(T)
+                         : "vcc", "scc");
+            if (why == 0u) { state = ks >= 64u ? 0 : 1; break; }
+            if (why == 2u) { state = 2; skip_to = __builtin_bit_cast(float, tt_bits); break; }
+            // a run of occupied points: each emits and steps to its successor
+            const uint64_t rest = ~(emit_s >> ks);         // bit 0 clear; for ks > 0 the bits shifted in end the run at lane 63
+            uint32_t len = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+            len = (uint32_t)__builtin_amdgcn_readfirstlane((int)(len < room ? len : room));      // (uniform; a scalar register for the block above)
+            emitted |= (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << ks;
+            room -= len;
+            ks += len;
+            if (room == 0u) state = 1;                     // what the loop condition finds at its next test (:359)
         }
+        skipping = state == 2;
+        const bool done = state == 1;
         if ((emitted >> lane) & 1ull) strip[num_steps + (uint32_t)__builtin_popcountll(emitted & ((1ull << lane) - 1ull))] = T;
         num_steps += (uint32_t)__builtin_popcountll(emitted);
         if (done) break;

@@ -83,7 +83,10 @@ def _march_case(bound, N, dt_gamma, perturb, seed, max_steps=1024):
 
 
 @pytest.mark.parametrize("bound,dt_gamma,perturb,repeat", [(1, 0.0, False, 1), (2, 1 / 128, False, 1), (2, 1 / 128, True, 1), (4, 1 / 64, True, 1),
-                                                           (2, 1 / 128, True, 9)])
+                                                           (2, 1 / 128, True, 9),
+                                                           # dt_gamma that is no power of two (t + t * dt_gamma rounds twice: the recurrence's
+                                                           # mul + add form), and large ones whose rays cross all three step regimes in a round or two
+                                                           (2, 0.013, True, 1), (4, 0.05, False, 1), (1, 0.3, True, 1), (4, 0.25, True, 1)])
 def test_march_rays_train_bit_exact(rm, bound, dt_gamma, perturb, repeat):
     """`repeat` > 1: more than 16384 rays, which the library marches with one ray per lane instead of one per wave."""
     from focnerf_amd.backend import _raymarching as be
