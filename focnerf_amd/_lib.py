@@ -37,7 +37,7 @@ SIGNATURES = {
     "foc_march_rays_train": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_field": (i32, [c_vp, c_vp, c_vp, f32, f32, u32, u32, u32, u32, u32, c_vp, c_vp,
-                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
+                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp, f32, c_vp]),
     "foc_set_option": (i32, [ctypes.c_char_p, i32]),
     "foc_get_option": (i32, [ctypes.c_char_p, c_vp]),
     "foc_guard_pick_device": (i32, [i32, i32, i32, i32]),

@@ -49,33 +49,40 @@ __device__ __forceinline__ int rm_frexp_exp(float x) {
 }
 
 // ---------------------------------------------------------------- R1 (raymarching.cu:92-145)
+// slab test of one ray against the box a[0..5]; a miss gives FLT_MAX twice
+__device__ __forceinline__ void rm_near_far(float ox, float oy, float oz, float dx, float dy, float dz, float a0, float a1, float a2, float a3, float a4, float a5,
+                                            float min_near, float &near_out, float &far_out) {
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx, t;
+    if (near > far) { t = near; near = far; far = t; }
+    float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
+    if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
+    bool miss = (near > far_y || near_y > far);
+    if (!miss) {
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
+        if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
+        miss = (near > far_z || near_z > far);
+        if (!miss) {
+            if (near_z > near) near = near_z;
+            if (far_z < far) far = far_z;
+            if (near < min_near) near = min_near;
+        }
+    }
+    near_out = miss ? FLT_MAX : near;
+    far_out = miss ? FLT_MAX : far;
+}
+
 __global__ void __launch_bounds__(256) k_near_far_from_aabb(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                      const float *__restrict__ aabb, uint32_t N, float min_near,
                                      float *__restrict__ nears, float *__restrict__ fars) {
     const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
-        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-        float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx, t;
-        if (near > far) { t = near; near = far; far = t; }
-        float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
-        if (near_y > far_y) { t = near_y; near_y = far_y; far_y = t; }
-        bool miss = (near > far_y || near_y > far);
-        if (!miss) {
-            if (near_y > near) near = near_y;
-            if (far_y < far) far = far_y;
-            float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
-            if (near_z > far_z) { t = near_z; near_z = far_z; far_z = t; }
-            miss = (near > far_z || near_z > far);
-            if (!miss) {
-                if (near_z > near) near = near_z;
-                if (far_z < far) far = far_z;
-                if (near < min_near) near = min_near;
-            }
-        }
-        nears[n] = miss ? FLT_MAX : near;
-        fars[n] = miss ? FLT_MAX : far;
+        float near, far;
+        rm_near_far(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], a0, a1, a2, a3, a4, a5, min_near, near, far);
+        nears[n] = near;
+        fars[n] = far;
     }
 }
 
@@ -212,17 +219,23 @@ static RmParams rm_make_params(float bound, float dt_gamma, uint32_t max_steps, 
 }
 
 // ---------------------------------------------------------------- R6 pass 1: count (raymarching.cu:348-400)
+// aabb != NULL (both count kernels): nears / fars are OUTPUTS — the ray's slab test (k_near_far_from_aabb's expressions) is done here
 __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                               const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
-                              const float *__restrict__ nears, const float *__restrict__ fars,
-                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip) {
+                              float *__restrict__ nears, float *__restrict__ fars,
+                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip,
+                              const float *__restrict__ aabb, float min_near) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    const float far = fars[n];
-    float t = nears[n];
+    float near_n, far;
+    if (aabb) {
+        rm_near_far(ox, oy, oz, dx, dy, dz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], min_near, near_n, far);
+        nears[n] = near_n; fars[n] = far;
+    } else { near_n = nears[n]; far = fars[n]; }
+    float t = near_n;
     t = fmaf(rm_clamp(t * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t);
     uint32_t num_steps = 0;
     RmCell c;
@@ -249,16 +262,21 @@ __global__ void __launch_bounds__(64) k_march_count(const float *__restrict__ ra
 template <bool MED3>                                       // dt_min <= dt_max (any real setting): the clamp of the recurrence is one v_med3_f32
 __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                               const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
-                              const float *__restrict__ nears, const float *__restrict__ fars,
-                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip) {
+                              float *__restrict__ nears, float *__restrict__ fars,
+                              const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip,
+                              const float *__restrict__ aabb, float min_near) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (n >= N) return;                                    // whole wave
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    const float far = fars[n];
-    float t_cur = nears[n];
+    float near_n, far;
+    if (aabb) {                                            // wave-uniform
+        rm_near_far(ox, oy, oz, dx, dy, dz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], min_near, near_n, far);
+        if (lane == 0) { nears[n] = near_n; fars[n] = far; }
+    } else { near_n = nears[n]; far = fars[n]; }
+    float t_cur = near_n;
     t_cur = fmaf(rm_clamp(t_cur * p.dt_gamma, p.dt_min, p.dt_max), noises[n], t_cur);
     float *strip = tstrip + (uint64_t)n * max_steps;
     uint32_t num_steps = 0;
@@ -1209,8 +1227,9 @@ uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps) { re
 
 static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
-                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *sh_rows, bool field, uint32_t pad_align, void *stream) {
+                          float *nears, float *fars, float *xyzs, float *dirs, float *deltas,
+                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *sh_rows, bool field, uint32_t pad_align,
+                          const float *aabb, float min_near, void *stream) {
     if (N == 0) return FOC_OK;
     FOC_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises && scratch, FOC_E_INVALID,
                 "march_rays_train: null pointer");
@@ -1229,10 +1248,10 @@ static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_
     const int forced = foc_opt(FOC_OPT_MARCH_SERIAL);
     const bool serial = forced >= 0 ? forced != 0 : N > 16384u;
     if (serial)
-        hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
+        hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip, aabb, min_near);
     else
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_count_wave<true> : k_march_count_wave<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d,
-                           grid, p, max_steps, N, nears, fars, noises, scratch, tstrip);
+                           grid, p, max_steps, N, nears, fars, noises, scratch, tstrip, aabb, min_near);
     FOC_CHECK_LAUNCH("march_rays_train(count)");
     // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
@@ -1255,17 +1274,18 @@ int foc_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t
                          const float *nears, const float *fars, float *xyzs, float *dirs, float *deltas,
                          int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, void *stream) {
     FocDeviceGuard foc_guard_(stream, rays_o);
-    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises, scratch, nullptr, false, 0u,
-                          stream);
+    return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, const_cast<float *>(nears), const_cast<float *>(fars), xyzs, dirs, deltas, rays,
+                          counter, noises, scratch, nullptr, false, 0u, nullptr, 0.0f, stream);
 }
 
 int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound, float dt_gamma,
                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                               const float *nears, const float *fars, float *enc_in, void *sh_rows, float *deltas,
-                               int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, uint32_t pad_align, void *stream) {
+                               float *nears, float *fars, float *enc_in, void *sh_rows, float *deltas,
+                               int32_t *rays, int32_t *counter, const float *noises, int32_t *scratch, uint32_t pad_align,
+                               const float *aabb, float min_near, void *stream) {
     FocDeviceGuard foc_guard_(stream, rays_o);
     return rm_march_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, enc_in, nullptr, deltas, rays, counter, noises, scratch, sh_rows, true,
-                          pad_align, stream);
+                          pad_align, aabb, min_near, stream);
 }
 
 int foc_composite_rays_train_forward(const float *sigmas, const float *rgbs, const float *deltas, const int32_t *rays,

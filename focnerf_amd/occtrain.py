@@ -51,10 +51,10 @@ def _no_jitter(n, dev):
 
 class _occ_train(Function):
     @staticmethod
-    def forward(ctx, emb, w_sigma, w_color, o, d, nears, fars, bitfield, counter, bg_ray, cfg):
+    def forward(ctx, emb, w_sigma, w_color, o, d, aabb, bitfield, counter, bg_ray, cfg):
         from .field import _half_of
         (bound, cascade, grid_size, mean_count, perturb, align, force_all_rays, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar,
-         offsets, enc_cfg, sig_cfg, col_cfg) = cfg
+         offsets, enc_cfg, sig_cfg, col_cfg, min_near) = cfg
         S, H, gridtype, align_corners, interp = enc_cfg
         n, dev = o.shape[0], o.device
         st = stream_of(o)
@@ -65,11 +65,13 @@ class _occ_train(Function):
         block = torch.empty(o2 + 8 * cap, dtype=torch.float32, device=dev)
         enc_in, deltas, sh = block[: 3 * cap].view(cap, 3), block[o1: o1 + 2 * cap].view(cap, 2), block[o2:].view(torch.float16).view(cap, 16)
         rays = torch.empty(n, 3, dtype=torch.int32, device=dev)
+        nf = torch.empty(2, n, dtype=torch.float32, device=dev)         # nears, fars: written by the march's count pass (the box test of near_far_from_aabb)
+        nears, fars = nf[0], nf[1]
         jitter = torch.rand(n, dtype=torch.float32, device=dev) if perturb else _no_jitter(n, dev)
         scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(n, max_steps), dev)
         check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(bitfield), float(bound), float(dt_gamma), int(max_steps), n, int(cascade), int(grid_size), cap,
                                              ptr(nears), ptr(fars), ptr(enc_in), ptr(sh), ptr(deltas), ptr(rays), ptr(counter), ptr(jitter), ptr(scratch),
-                                             0 if budgeted else max(int(align), 1), st), "march_rays_train_field")
+                                             0 if budgeted else max(int(align), 1), ptr(aabb), float(min_near), st), "march_rays_train_field")
         M = cap
         if not budgeted:                                        # raymarching.py:223-229: the list is cut to the samples marched (one device -> host copy)
             M = min(cap, _round_up(int(counter[0].item()), align))
@@ -92,6 +94,7 @@ class _occ_train(Function):
                                        ptr(nears), ptr(fars), ptr(ws), ptr(image_raw), ptr(image), ptr(depth), st), "occ_tail_forward")
         ctx.save_for_backward(enc_in, emb16, ws16, wc16, offsets, planes, h, c, sh, deltas, rays, counter, ws, image_raw,
                               bg_ray if bg_ray is not None else torch.empty(0, device=dev))
+        ctx.nears_fars = nf
         ctx.cfg = (M, n, float(T_thresh), float(density_scale), float(bg_scalar), bg_ray is not None, enc_cfg, sig_cfg, col_cfg)
         ctx.ticket = ticket
         ctx.mark_non_differentiable(depth)
@@ -127,8 +130,9 @@ class _occ_train(Function):
         return g_emb, g_wsig, g_wcol, None, None, None, None, None, None, None, None
 
 
-def render_occupancy_train(model, o, d, nears, fars, counter, bg_color, perturb, force_all_rays, dt_gamma, max_steps, T_thresh, align):
-    """o, d [n,3] fp32 contiguous, nears / fars [n], counter int32[2] (zeroed by the caller) -> (image [n,3], weights_sum [n], depth [n])."""
+def render_occupancy_train(model, o, d, counter, bg_color, perturb, force_all_rays, dt_gamma, max_steps, T_thresh, align):
+    """o, d [n,3] fp32 contiguous, counter int32[2] (zeroed by the caller) -> (image [n,3], weights_sum [n], depth [n]); the rays' box test
+    against the model's training box (near_far_from_aabb, min_near) happens inside the march."""
     from .fixedstep import _background
     enc, sn, cn = model.encoder, model.sigma_net, model.color_net
     n, dev = o.shape[0], o.device
@@ -136,5 +140,5 @@ def render_occupancy_train(model, o, d, nears, fars, counter, bg_color, perturb,
     cfg = (float(model.bound), int(model.cascade), int(model.grid_size), int(model.mean_count), bool(perturb), int(align), bool(force_all_rays), float(dt_gamma),
            int(max_steps), float(T_thresh), float(model.density_scale), float(bg_scalar), enc.offsets,
            (float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners, enc.interp_id),
-           (sn.input_dim, sn.hidden_dim, sn.num_layers, sn.activation), (cn.num_layers, cn.activation))
-    return _occ_train.apply(enc.embeddings, sn.weights, cn.weights, o, d, nears, fars, model.density_bitfield, counter, bg_ray, cfg)
+           (sn.input_dim, sn.hidden_dim, sn.num_layers, sn.activation), (cn.num_layers, cn.activation), float(model.min_near))
+    return _occ_train.apply(enc.embeddings, sn.weights, cn.weights, o, d, model._aabb().contiguous().float(), model.density_bitfield, counter, bg_ray, cfg)

@@ -213,21 +213,26 @@ class NeRFRenderer(nn.Module):
         opaque or out of the box."""
         o, d, lead = _flat_rays(rays_o, rays_d)
         n, dev = o.shape[0], o.device
+        out = {}
+        if self.training:
+            from .occtrain import occ_train_fusable, render_occupancy_train
+            if o.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and occ_train_fusable(self):
+                # the whole training forward as one autograd node (focnerf_amd/occtrain.py): same samples, same image; the box test of
+                # near_far_from_aabb rides in the march's count pass
+                slot = self.step_counter[self.local_step % 16]
+                slot.zero_()
+                self.local_step += 1
+                image, opacity, depth = render_occupancy_train(self, o.float(), d.float(), slot, bg_color, perturb, force_all_rays, dt_gamma, max_steps, T_thresh,
+                                                               _MARCH_ALIGN)
+                out['weights_sum'] = opacity
+                out['image'], out['depth'] = image.view(*lead, 3), depth.view(*lead)
+                return out
         near, far = raymarching.near_far_from_aabb(o, d, self._aabb(), self.min_near)
         background = self._background_colour(o, d, bg_color)
-        out = {}
         if self.training:
             slot = self.step_counter[self.local_step % 16]
             slot.zero_()
             self.local_step += 1
-            from .occtrain import occ_train_fusable, render_occupancy_train
-            if o.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and occ_train_fusable(self):
-                # the whole training forward as one autograd node (focnerf_amd/occtrain.py): same samples, same image
-                image, opacity, depth = render_occupancy_train(self, o, d, near, far, slot, bg_color if self.bg_radius <= 0 else background, perturb,
-                                                               force_all_rays, dt_gamma, max_steps, T_thresh, _MARCH_ALIGN)
-                out['weights_sum'] = opacity
-                out['image'], out['depth'] = image.view(*lead, 3), depth.view(*lead)
-                return out
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size, near,
                                                                     far, slot, self.mean_count, perturb, _MARCH_ALIGN, force_all_rays,
                                                                     dt_gamma, max_steps)

@@ -106,14 +106,16 @@ uint64_t foc_march_rays_train_scratch_bytes(uint32_t N, uint32_t max_steps);
  *   sh_rows [M,16] fp16 = the degree-4 SH values of each sample's ray direction (k-chunk 0 of the colour network's input);
  *   deltas [M,2] as above. No `dirs`. EVERY row of the three arrays is written (rays that do not fit the list and the rows behind the
  *   last ray receive zeros): the caller does not pre-zero them. pad_align > 0: the rows behind the last ray are zeroed only up to the
- *   next multiple of pad_align above counter[0] (a caller that cuts the list there, raymarching.py:223-229, reads nothing beyond). */
+ *   next multiple of pad_align above counter[0] (a caller that cuts the list there, raymarching.py:223-229, reads nothing beyond).
+ *   aabb != NULL: nears / fars [N] are OUTPUTS — the slab test of foc_near_far_from_aabb(aabb [6], min_near) is done by the count pass
+ *   (same expressions, same bits); aabb == NULL: they are inputs as in foc_march_rays_train. */
 int foc_march_rays_train_field(const float *rays_o, const float *rays_d, const uint8_t *grid,
                                float bound, float dt_gamma, uint32_t max_steps,
                                uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                               const float *nears, const float *fars,
+                               float *nears, float *fars,
                                float *enc_in, void *sh_rows, float *deltas,
                                int32_t *rays, int32_t *counter, const float *noises,
-                               int32_t *scratch, uint32_t pad_align, void *stream);
+                               int32_t *scratch, uint32_t pad_align, const float *aabb, float min_near, void *stream);
 
 /* raymarching.cu:500-588  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                      weights_sum, depth, image) */

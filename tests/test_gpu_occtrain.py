@@ -115,7 +115,7 @@ def test_march_field_layout_equals_the_reference_layout():
         c2 = torch.zeros(2, dtype=torch.int32, device="cuda")
         scratch = torch.empty(lib.foc_march_rays_train_scratch_bytes(o.shape[0], 1024), dtype=torch.uint8, device="cuda")
         check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(nears), ptr(fars),
-                                             ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 0, stream_of(o)), "march_field")
+                                             ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 0, None, 0.0, stream_of(o)), "march_field")
         assert torch.equal(r2, rays) and torch.equal(c2, c_ref)
         rr = to_np(rays)
         fits = (rr[:, 2] > 0) & (rr[:, 1] + rr[:, 2] <= cap)
@@ -137,8 +137,16 @@ def test_march_field_layout_equals_the_reference_layout():
     dl = torch.full((cap, 2), float("nan"), device="cuda")
     c2.zero_()
     check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(nears), ptr(fars),
-                                         ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 128, stream_of(o)), "march_field")
+                                         ptr(enc_in), ptr(sh), ptr(dl), ptr(r2), ptr(c2), ptr(jitter), ptr(scratch), 128, None, 0.0, stream_of(o)), "march_field")
     cut = total + (128 - total % 128)
+    # aabb given: nears / fars are outputs of the count pass — the bits of near_far_from_aabb — and the march is the same
+    n2, f2 = torch.full_like(nears, float("nan")), torch.full_like(fars, float("nan"))
+    r3, c3 = torch.empty_like(rays), torch.zeros(2, dtype=torch.int32, device="cuda")
+    x3 = torch.empty(cap, 3, device="cuda")
+    check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(m.density_bitfield), float(bound), 1 / 128, 1024, o.shape[0], m.cascade, 128, cap, ptr(n2), ptr(f2),
+                                         ptr(x3), ptr(sh), ptr(dl), ptr(r3), ptr(c3), ptr(jitter), ptr(scratch), 128, ptr(m.aabb_train.contiguous()), float(m.min_near),
+                                         stream_of(o)), "march_field")
+    assert torch.equal(n2, nears) and torch.equal(f2, fars) and torch.equal(r3, rays) and torch.equal(c3, c_ref)
     assert cut == M and not to_np(enc_in)[total:cut].any() and not to_np(sh)[total:cut].any() and np.isnan(to_np(enc_in)[cut:]).all() and np.isnan(to_np(dl)[cut:]).all()
 
 

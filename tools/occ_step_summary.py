@@ -1,11 +1,11 @@
 """Per-step kernel time of the occupancy-grid training step from a rocprofv3 --kernel-trace CSV of tools/prof_occupancy.py: the last
-STEPS steps only (steady state: sample budget set, no warm-up launches), a step = the launches between two k_near_far_from_aabb.
+STEPS steps only (steady state: sample budget set, no warm-up launches), a step = the launches between two k_march_count_wave.
 Library kernels (this repo's) against torch's own; sum of durations per step.  usage: occ_step_summary.py <kernel_trace.csv> [steps]"""
 import csv, re, sys
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "k_near_far_from_aabb" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_march_count" in r["Kernel_Name"]]            # the step's first library kernel
 lo, hi = marks[-STEPS - 1], marks[-1]                     # STEPS whole steps (the last, incomplete one is dropped)
 acc = {}
 for r in rows[lo:hi]:
