@@ -966,10 +966,29 @@ def main():
             per_step = float(m2.step_counter[:, 0].float().mean().item())
             result["occupancy_path"] = {"metric": "train_samples_per_sec", "value": world * per_step * n2 / el2, "unit": "samples/s",
                                         "ms_per_step": 1000 * el2 / n2, "rays_per_step": NUM_RAYS, "samples_per_step": per_step,
-                                        "path": "configs[2]: march_rays_train + composite_rays_train (occupancy grid), bound 2"}
+                                        "path": "configs[2]: occupancy-grid training step, bound 2, eager: NeRFRenderer.run_cuda -> focnerf_amd/occtrain.py (march in the "
+                                                "field's layout, encoder + count, both MLPs, ragged tail: ONE autograd node, 16 library launches) + MSE + GradScaler + fused "
+                                                "Adam; FOC_FUSED_OCC=0 is the chain of separate ops (march_rays_train, grid_encode, FFMLP x2, composite_rays_train)"}
+            # the same step as the chain of separate public ops (what round 3 measured as `occupancy_path`)
+            try:
+                os.environ["FOC_FUSED_OCC"] = "0"
+                for i in range(4):
+                    cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    cuda_ray_train_step(m2, opt2, sc2, *b2[i % 4])
+                barrier()
+                elc = max_over_ranks(time.perf_counter() - t0)
+                result["occupancy_path"]["op_chain"] = {"ms_per_step": 1000 * elc / n2, "value": world * per_step * n2 / elc,
+                                                        "note": "FOC_FUSED_OCC=0: one autograd node per op, the caller-side torch glue between them"}
+            except Exception as e:
+                result["occupancy_path"]["op_chain"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("FOC_FUSED_OCC", None)
 
-            # the eager step is ~80 launches for ~1.05 ms of GPU work and Python needs ~1.2 ms to enqueue them: replayed as one HIP graph
-            # (focnerf_amd.graph.GraphedStep, static shapes thanks to the sample budget) it runs at GPU speed
+            # replayed as one HIP graph (focnerf_amd.graph.GraphedStep, static shapes thanks to the sample budget): what the step costs with no
+            # host in the loop (round 3's chain of ops needed 1.2 ms of Python per step for 1.05 ms of GPU work; the fused node 0.75 for 0.8)
             try:
                 from focnerf_amd.graph import GraphedStep
                 optg = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)

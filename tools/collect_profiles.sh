@@ -6,7 +6,7 @@
 # (written under gpurun_out/profiles/, copy them into profiles/ afterwards).
 # usage: tools/collect_profiles.sh r01
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"

@@ -3,7 +3,7 @@
 # pass; never combined with a trace domain), summarised per kernel into gpurun_out/profiles/<tag>_bench_pmc_sq.csv.
 # usage: tools/collect_sq.sh r02            (SQ_SCRIPT=tools/time_render_fixed.py tools/collect_sq.sh r02_render: another program's kernels)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"
