@@ -214,3 +214,25 @@ def test_tail_kernels_against_the_oracle_composite(c_width):
         assert gh0[s_] == 0 or want_h0[s_] == 0, "a sample on one side of a threshold flip only"
     assert not gc[:, 3:].any()
     assert np.abs(want_h0).max() > 0 and (gh0 != 0).sum() > 100
+
+
+def test_fused_training_path_edge_cases(monkeypatch):
+    """Rays that all miss the occupied region or the box (no sample at all: the image is the background, every gradient is zero and finite),
+    a ray count that is no multiple of the kernels' four rays per workgroup, a colour given as a [3] tensor."""
+    bound = 2
+    m = _model(bound)
+    o, d = _rays(bound, 1001, 11)
+    away_o, away_d = o * 4.0, -d                                     # outside the box, pointing away
+    for oo, dd, kw in ((away_o, away_d, dict(perturb=False, force_all_rays=True, bg_color=None)),
+                       (o, d, dict(perturb=True, force_all_rays=True, bg_color=torch.tensor([0.2, 0.5, 0.9], device="cuda")))):
+        ref, g_ref = _step(m, oo, dd, False, monkeypatch, **kw)
+        got, g_got = _step(m, oo, dd, True, monkeypatch, **kw)
+        for k in ("image", "weights_sum"):
+            assert torch.equal(ref[k], got[k]), k
+        assert torch.equal(ref["depth"].nan_to_num(), got["depth"].nan_to_num())
+        for a, b in zip(g_ref, g_got):
+            assert torch.isfinite(b).all()
+            assert (a.float() - b.float()).abs().max() <= 4e-3 * max(float(a.abs().max()), 1e-30)
+    # the rays that miss everything: nothing marched, white image, zero gradients
+    got, g_got = _step(m, away_o, away_d, True, monkeypatch, perturb=False, force_all_rays=True, bg_color=None)
+    assert bool((got["image"] == 1.0).all()) and bool((got["weights_sum"] == 0).all()) and all(not g.any() for g in g_got)
