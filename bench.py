@@ -75,6 +75,28 @@ def pmc_traffic_bytes(op, which="bench", kernels=None):
     return total if found else None
 
 
+def profile_occupancy_kernel_us_per_step():
+    """Library / torch kernel time per configs[2] training step from the newest committed profiles/*_occupancy_train_kernel_stats.csv
+    (rocprofv3 --kernel-trace --stats of tools/prof_occupancy.py: 37 steps, one k_march_count_wave launch each), or None."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_occupancy_train_kernel_stats.csv")))
+    if not files:
+        return None
+    try:
+        rows = list(csv.DictReader(open(files[-1])))
+        steps = max(int(r["Calls"]) for r in rows if "k_march_count" in r["Name"])
+        is_lib = lambda n: re.search(r"\bk_[a-z]|_Z\d+k_", n) is not None
+        lib = sum(float(r["TotalDurationNs"]) for r in rows if is_lib(r["Name"]))
+        launches = sum(int(r["Calls"]) for r in rows if is_lib(r["Name"]))
+        rest = sum(float(r["TotalDurationNs"]) for r in rows) - lib
+        return {"profile_library_kernels_us_per_step": lib / steps / 1e3, "profile_library_launches_per_step": launches / steps,
+                "profile_torch_native_us_per_step": rest / steps / 1e3, "profile_source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def profile_kernel_ms_per_step():
     """{library kernels ms/step, torch-native kernels ms/step, source file} from the newest committed profiles/*_bench_kernel_stats.csv
     (rocprofv3 --kernel-trace --stats of `bench.py --no-extras`), or None. A step launches k_gbin_reduce exactly once: its call count is
@@ -461,9 +483,9 @@ def resident_object_fields(device, bound, vo, vd, K, first=None, rank=0):
     return [(lambda lo, hi, out, m=m, y=y: render_field4(m, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=y, out=out)) for m, y in zip(objs, yolos)]
 
 
-def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=4096, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True,
+def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=16384, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True,
                         ray_order=None):
-    """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (4096-ray chunks, packed
+    """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (16384-ray pieces, packed
     per-sample fields), the chunks are exchanged by ray (all-to-all over xGMI), every rank selects + composites its ray slices for both
     backgrounds, one all-gather per view assembles the images. Timed against the same view with the field evaluation alone.
     `fused_fn(lo, hi, out)` = this rank's object; `ops` = None (HIP) or injected CPU ops (dry run)."""
@@ -522,7 +544,7 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
                     "note": "bytes this rank put on the wire per view / wall time per view; peak = (N-1) point-to-point links x 153 GB/s"},
            "image_checksum": float(img.double().sum().item()),
            "path": "per rank: near/far -> sample -> hash-grid -> whole-field kernel -> own weights + mask + pack (16 B/sample); all-to-all by ray per "
-                   "4096-ray chunk, overlapped with the next chunk's evaluation; fused select + composite of the rank's ray slices, both backgrounds; "
+                   "16384-ray piece (134 MB per object; 4096-ray pieces are 10 % slower: 44.4 against 40.4 ms per view at N = 1), overlapped with the next piece's evaluation; fused select + composite of the rank's ray slices, both backgrounds; "
                    "one all-gather per view (COMBINED.py:592-618, 141-200, 247-251)"}
     return out
 
@@ -969,6 +991,9 @@ def main():
                                         "path": "configs[2]: occupancy-grid training step, bound 2, eager: NeRFRenderer.run_cuda -> focnerf_amd/occtrain.py (march in the "
                                                 "field's layout, encoder + count, both MLPs, ragged tail: ONE autograd node, 16 library launches) + MSE + GradScaler + fused "
                                                 "Adam; FOC_FUSED_OCC=0 is the chain of separate ops (march_rays_train, grid_encode, FFMLP x2, composite_rays_train)"}
+            po = profile_occupancy_kernel_us_per_step()
+            if po is not None:
+                result["occupancy_path"].update(po)
             # the same step as the chain of separate public ops (what round 3 measured as `occupancy_path`)
             try:
                 os.environ["FOC_FUSED_OCC"] = "0"
@@ -1083,10 +1108,10 @@ def main():
                 comb1 = ObjectCombiner(rank=0, world_size=1)
                 fns = resident_object_fields(device, bound, vo, vd, 4, first=(obj_model, obj_yolo))
                 with torch.no_grad(), half_cache_scope():
-                    comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
+                    comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=16384)
                     barrier()
                     t0 = time.perf_counter()
-                    img4_4, _ = comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=4096)
+                    img4_4, _ = comb1.render_view(fns, VIEW * VIEW, vn, vf, NUM_STEPS, max_ray_batch=16384)
                     barrier()
                 el4 = time.perf_counter() - t0
                 result["combined_render"]["resident_4_objects_one_gpu"] = {"s_per_view": el4, "rays_per_sec": VIEW * VIEW / el4,
