@@ -275,11 +275,12 @@ class ObjectCombiner:
         fields = [recv[k * per:(k + 1) * per] for k in range(self.world)] if self.world > 1 else [recv]
         return self.ops.select_composite(fields, nears_mine, fars_mine, tuple(bgs))
 
-    def render_view(self, field_fns, n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=4096, overlap=True):
+    def render_view(self, field_fns, n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=16384, overlap=True):
         """One view, the loop of COMBINED.py:592-618 + compute_metrics_both_backgrounds' composites, sharded by object and exchanged by ray.
         field_fns: THIS rank's objects in checkpoint order, each `fn(lo, hi, out)` -> packed field4 [hi-lo, T, 4] fp32 of the object on
         rays lo:hi of the view (it may write into `out`, a [hi-lo, T, 4] buffer, and return it). Ranks hold consecutive runs of the
-        checkpoint list (rank order = checkpoint order). nears / fars [n_rays]: of the view's own rays.
+        checkpoint list (rank order = checkpoint order). nears / fars [n_rays]: of the view's own rays. `max_ray_batch` = rays per piece (field
+        evaluation and exchange granularity; 16384: 134 MB per object and piece at 512 samples — 10 % faster per view than 4096-ray pieces).
         Returns (image4 [len(bgs), n_rays, 4], depth [n_rays]) on every rank."""
         dev = nears.device
         p, chunk = self.world, int(max_ray_batch)
