@@ -914,6 +914,37 @@ def main():
                     result["roofline"]["render"] = rr
             except Exception as e:
                 result.setdefault("roofline", {})["render"] = {"error": repr(e)}
+            # the same views on an OPAQUE field (density_scale 1e4: alpha ~ 1 at a ray's first sample, as behind a trained object's surface): the
+            # reference evaluates the colour network only where weights > 1e-10 (nerf/renderer.py:185-187), this path evaluates it densely and
+            # masks in the composite — so the time of a view must not depend on the field, and `colour_mask_fraction` says how sparse the
+            # reference's mask would be here (4096 rays of view 0, weights formed in torch from the returned densities)
+            try:
+                from focnerf_amd import raymarching
+                saved_scale = model.density_scale
+                model.density_scale = 1.0e4
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                    model.render(rays_o, rays_d, return_fields=False, **rkw)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(args.render_views):
+                        model.render(*view_rays[i % len(view_rays)], return_fields=False, **rkw)
+                    barrier()
+                    relq = max_over_ranks(time.perf_counter() - t0) / max(1, args.render_views)
+                    so, sd = view_rays[0][0][:, :4096].contiguous(), view_rays[0][1][:, :4096].contiguous()
+                    part = model.render(so, sd, return_fields=True, **rkw)
+                    sig = part["densities"].float().view(-1, NUM_STEPS)
+                    nf_near, nf_far = raymarching.near_far_from_aabb(so.view(-1, 3), sd.view(-1, 3), model.aabb_infer, model.min_near)
+                    step = ((nf_far - nf_near) / NUM_STEPS).view(-1, 1)
+                    alpha = 1 - torch.exp(-step * model.density_scale * sig)
+                    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-15], dim=-1), dim=-1)[:, :-1]
+                    frac = float(((alpha * trans) > 1e-10).float().mean())
+                result["render"]["opaque_field"] = {"s_per_view": relq, "vs_render": relq / result["render"]["s_per_view"], "density_scale": 1.0e4,
+                                                    "colour_mask_fraction": frac,
+                                                    "note": "same 8 poses; the colour network runs densely, the weights > 1e-10 mask is applied in the composite"}
+            except Exception as e:
+                result["render"]["opaque_field"] = {"error": repr(e)}
+            finally:
+                model.density_scale = saved_scale
             # the reference's eval render also assembles the per-sample fields of the whole view for the combiner (renderer.py:524-547)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 # the SAME views as the `render` leg, in the same order: a view costs 40 - 45 ms depending on its pose, and with one fixed view here
