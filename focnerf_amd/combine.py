@@ -184,11 +184,15 @@ class ObjectCombiner:
     """One object per rank. All tensors live on the rank's device; collectives go over `group`
     (backend nccl == RCCL on ROCm, gloo in the CPU tests)."""
 
-    def __init__(self, rank=None, world_size=None, group=None, ops=HipCombineOps):
+    def __init__(self, rank=None, world_size=None, group=None, ops=HipCombineOps, collectives_at_world_1=False):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world_size is None else world_size
         self.ops = ops
+        # A single rank needs no exchange and issues none. `collectives_at_world_1` issues every collective anyway (needs an initialised
+        # process group of one rank): the rehearsal of the RCCL path — buffers, split sizes, the order of the collective's stream against
+        # this library's launches — on a box with one GPU (tests/test_gpu_rccl.py). Same results either way.
+        self.xch = self.world > 1 or bool(collectives_at_world_1)
         self.bytes_sent = 0            # bytes this rank put on the wire in the last render_view
 
     # ---- faithful per-sample select across ranks
@@ -197,10 +201,10 @@ class ObjectCombiner:
         dens = dens.contiguous().float()
         rgb = rgb.contiguous().float()
         keys = self.ops.pack_keys(dens, self.rank)
-        if self.world > 1:
+        if self.xch:
             dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=self.group)
         max_dens, masked = self.ops.unpack(keys, self.rank, rgb)
-        if self.world > 1:
+        if self.xch:
             dist.all_reduce(masked, op=dist.ReduceOp.SUM, group=self.group)
         return max_dens, masked
 
@@ -222,7 +226,7 @@ class ObjectCombiner:
                                        fars[lo:hi].contiguous().float(), bg)
             img[: hi - lo] = i4
             dep[: hi - lo] = d
-        if self.world > 1:
+        if self.xch:
             imgs = [torch.empty_like(img) for _ in range(self.world)]
             deps = [torch.empty_like(dep) for _ in range(self.world)]
             dist.all_gather(imgs, img, group=self.group)
@@ -243,7 +247,7 @@ class ObjectCombiner:
         `bufs` = (send, recv) of [world*per, T, 4] to reuse (double-buffered by render_view), else allocated here."""
         n, T = field4.shape[0], field4.shape[1]
         per = self._slice_len(n)
-        if self.world == 1:
+        if not self.xch:
             return (None, field4.contiguous(), n, per)
         if bufs is None:
             bufs = (torch.empty(self.world * per, T, 4, dtype=torch.float32, device=field4.device),
@@ -303,7 +307,7 @@ class ObjectCombiner:
         far_tab = torch.where(ok, fars.float()[ray], torch.full((), 2.0, device=dev)).contiguous()
         mine4 = torch.zeros(n_chunks, len(bgs), per, 4, dtype=torch.float32, device=dev)
         mined = torch.zeros(n_chunks, per, dtype=torch.float32, device=dev)
-        bufs = [tuple(torch.empty(p * per, T, 4, dtype=torch.float32, device=dev) for _ in range(2)) for _ in range(2)] if p > 1 else None
+        bufs = [tuple(torch.empty(p * per, T, 4, dtype=torch.float32, device=dev) for _ in range(2)) for _ in range(2)] if self.xch else None
         self.bytes_sent = 0
 
         def finish(pending):
@@ -334,7 +338,7 @@ class ObjectCombiner:
                 pending = None
         if pending is not None:
             finish(pending)
-        if p == 1:
+        if not self.xch:
             return mine4.permute(1, 0, 2, 3).reshape(len(bgs), -1, 4)[:, :n_rays].contiguous(), mined.reshape(-1)[:n_rays].contiguous()
         # ONE gather per view: image rows and depths of this rank's slices in one flat buffer
         flat = torch.cat([mine4.reshape(-1), mined.reshape(-1)])
@@ -360,6 +364,6 @@ class ObjectCombiner:
         """image [N,3] (premultiplied, no background), depth [N], weights_sum [N] of this rank's object.
         One all-reduce(SUM) of the packed [N,5]; the caller adds the background with the summed weight."""
         packed = torch.cat([image.float(), depth.float().unsqueeze(-1), weights_sum.float().unsqueeze(-1)], dim=-1).contiguous()
-        if self.world > 1:
+        if self.xch:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
         return packed[:, :3], packed[:, 3], packed[:, 4]

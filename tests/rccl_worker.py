@@ -8,7 +8,8 @@ all-to-all of the packed per-sample fields by ray, fused select + composite of e
 (COMBINED.py:592-618). Every rank compares what it got with the single-device `combine_packed` of all objects, BIT FOR BIT (same kernels,
 same operand order: the select's tie rule runs in rank = checkpoint order), and with the reference's images within 1e-4. Overlap on and
 off (async all-to-all under the next chunk's evaluation, double-buffered), a ragged last chunk, a chunk smaller than the world's slices.
-Writes <out_dir>/rank<r>.json; exit code 0 = all checks passed."""
+With WORLD_SIZE=1 the combiner is told to issue its collectives all the same (`collectives_at_world_1`): every case then goes through
+RCCL on the one device. Writes <out_dir>/rank<r>.json; exit code 0 = all checks passed, 77 = the process group could not be created."""
 import json
 import os
 import sys
@@ -33,9 +34,18 @@ def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
+    try:
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
+        probe = torch.ones(8, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as e:                                  # noqa: BLE001 — RCCL cannot start on this box: nothing of this repo was reached
+        print("RCCL_UNAVAILABLE", repr(e), flush=True)
+        sys.exit(77)
     from focnerf_amd.combine import ObjectCombiner, combine_packed
-    comb = ObjectCombiner()
+    # started as the only rank (a one-GPU box), the combiner issues its collectives anyway: the same cases then rehearse the RCCL calls
+    # themselves — RCCL moves the data on the device — instead of skipping them (a single rank needs no exchange)
+    comb = ObjectCombiner(collectives_at_world_1=world == 1)
     report = {"rank": rank, "world": dist.get_world_size(), "backend": dist.get_backend(), "device": torch.cuda.get_device_name(dev), "cases": []}
     assert comb.rank == rank and comb.world == world
     ok_all = True

@@ -190,6 +190,43 @@ def test_render_view_by_ray_exchange_equals_serial(tmp_path, world, K, N, chunk,
         assert g["sent"] >= (world - 1) * N * T * 16 // world
 
 
+def _one_rank_worker(rank, world, port, K, N, T, chunk, out_dir):
+    _init(rank, world, port)
+    from focnerf_amd.combine import ObjectCombiner
+    dens, rgb, nears, fars = _fields(K, N, T, 3)
+    fns = [lambda lo, hi, out, f4=_packed(dens[k], rgb[k]): f4[lo:hi].clone() for k in range(K)]
+    res = {}
+    for name, comb in (("plain", ObjectCombiner(ops=CpuOps)), ("forced", ObjectCombiner(ops=CpuOps, collectives_at_world_1=True))):
+        assert comb.world == 1 and comb.xch == (name == "forced")
+        for overlap in (True, False):
+            img, dep = comb.render_view(fns, N, torch.from_numpy(nears), torch.from_numpy(fars), T, bgs=(1.0, 0.0), max_ray_batch=chunk, overlap=overlap)
+            res[f"{name}_img_{int(overlap)}"], res[f"{name}_dep_{int(overlap)}"] = img.numpy(), dep.numpy()
+        md, best = comb.select(torch.from_numpy(dens[0]), torch.from_numpy(rgb[0]))
+        i4, dp = comb.render_chunk(torch.from_numpy(dens[0]), torch.from_numpy(rgb[0]), torch.from_numpy(nears), torch.from_numpy(fars), bg=1.0)
+        fi, fd, fw = comb.render_chunk_fast(torch.full((N, 3), 2.0), torch.full((N,), 0.5), torch.full((N,), 0.25))
+        res.update({f"{name}_md": md.numpy(), f"{name}_best": best.numpy(), f"{name}_i4": i4.numpy(), f"{name}_dp": dp.numpy(), f"{name}_fi": fi.numpy(),
+                    f"{name}_fw": fw.numpy()})
+        assert comb.bytes_sent == 0                                   # nothing leaves a single rank, collectives or not
+    np.savez(os.path.join(out_dir, "one.npz"), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,N,chunk", [(3, 101, 32), (2, 40, 64)])       # ragged last chunk; one chunk larger than the view
+def test_single_rank_issuing_its_collectives_equals_the_exchange_free_path(tmp_path, K, N, chunk):
+    """`ObjectCombiner(collectives_at_world_1=True)`: the switch tests/test_gpu_rccl.py uses to push the N > 1 code through RCCL on a one-GPU
+    box. Here over gloo with one rank: every entry point gives what the exchange-free combiner gives and what the serial object loop gives."""
+    T = 24
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), K, N, T, chunk, str(tmp_path)), nprocs=1, join=True)
+    g = np.load(os.path.join(tmp_path, "one.npz"))
+    dens, rgb, nears, fars = _fields(K, N, T, 3)
+    _, _, img_s, dep_s = _serial(dens, rgb, nears, fars, (1.0, 0.0))
+    for ov in (0, 1):
+        for name in ("plain", "forced"):
+            assert np.array_equal(g[f"{name}_img_{ov}"], img_s) and np.array_equal(g[f"{name}_dep_{ov}"], dep_s), (name, ov)
+    for key in ("md", "best", "i4", "dp", "fi", "fw"):
+        assert np.array_equal(g[f"plain_{key}"], g[f"forced_{key}"]), key
+
+
 def _editable_worker(rank, world, port, out_dir):
     """editable.npz through 4 ranks x 2 objects: rays per object from RayEditor (state carried over the two views), the fixture's own
     per-object fields as what each object's evaluation returned."""
