@@ -484,14 +484,14 @@ def resident_object_fields(device, bound, vo, vd, K, first=None, rank=0):
 
 
 def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, max_over_ranks, chunk=16384, ops=None, n_side=VIEW, T=NUM_STEPS, overlap=True,
-                        ray_order=None):
+                        ray_order=None, collectives_at_world_1=False):
     """COMBINED.py:592-618 on one object per rank: every rank evaluates ITS object on all rays of an n_side^2 view (16384-ray pieces, packed
     per-sample fields), the chunks are exchanged by ray (all-to-all over xGMI), every rank selects + composites its ray slices for both
     backgrounds, one all-gather per view assembles the images. Timed against the same view with the field evaluation alone.
     `fused_fn(lo, hi, out)` = this rank's object; `ops` = None (HIP) or injected CPU ops (dry run)."""
     import torch.distributed as dist
     from focnerf_amd.combine import ObjectCombiner, HipCombineOps
-    comb = ObjectCombiner(rank=rank, world_size=world, ops=ops or HipCombineOps)
+    comb = ObjectCombiner(rank=rank, world_size=world, ops=ops or HipCombineOps, collectives_at_world_1=collectives_at_world_1)
     n_rays = n_side * n_side
     nears, fars = model["nears"], model["fars"]
 
@@ -525,7 +525,7 @@ def combined_render_leg(rank, world, device, model, views, fused_fn, barrier, ma
     el_eval = max_over_ranks(time.perf_counter() - t0) / views
     links = max(world - 1, 1)
     el_other = None
-    if world > 1:                                          # the other exchange mode on the same box, for an A/B on real links
+    if comb.xch:                                           # the other exchange mode on the same box, for an A/B on real links
         one_view(not overlap)
         barrier()
         t0 = time.perf_counter()
@@ -676,9 +676,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FOC_BENCH_SHARE_GPU") == "1":      # rehearsal of the N-rank path on a one-GPU box (every rank on device 0); never set by the driver
         local_rank = 0
-    if world > 1:
+    # FOC_BENCH_REHEARSE_RCCL=1 with ONE rank (never set by the driver): this file's N-rank branch — nccl process group, barrier, the MAX over
+    # ranks, the combined leg with the combiner issuing its collectives, the teardown — runs through RCCL on a one-GPU box. Labelled in the line.
+    rehearse = world == 1 and os.environ.get("FOC_BENCH_REHEARSE_RCCL") == "1"
+    dist_on = world > 1 or rehearse
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            os.environ.setdefault("MASTER_PORT", "29751"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         import datetime
         # a rank that fails inside a collective leg must not leave the others waiting for the driver's kill: collectives time out
@@ -690,13 +696,13 @@ def main():
     torch.cuda.set_device(device)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             t = torch.tensor([x], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1122,7 +1128,11 @@ def main():
                 return render_field4(obj_model, vo[lo:hi], vd[lo:hi], num_steps=NUM_STEPS, yolo_details=obj_yolo, out=out)
             with torch.no_grad(), half_cache_scope():
                 result["combined_render"] = combined_render_leg(rank, world, device, {"nears": vn, "fars": vf}, args.combined_views, my_object, barrier,
-                                                                max_over_ranks, overlap=not args.combined_no_overlap, ray_order=tile_order)
+                                                                max_over_ranks, overlap=not args.combined_no_overlap, ray_order=tile_order,
+                                                                collectives_at_world_1=rehearse)
+            if rehearse:
+                result["combined_render"]["rehearsal"] = ("ONE rank with the nccl process group, every collective issued (RCCL copies on the device): NOT an N > 1 "
+                                                          "measurement — no byte leaves the GPU")
             result["combined_render"]["ray_order"] = "8x8 pixel tiles" if tile_order is not None else "as given"
             cr = result["combined_render"]
             # the N-rank half of BASELINE's metric inside `roofline` (the driver's record keeps `roofline` and `config` whole)
@@ -1182,7 +1192,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -28,6 +28,8 @@ occlusion); it is offered and labelled as such.
 The kernels live in libfocnerf_hip.so; `ops` can be replaced by a CPU implementation in the gloo tests,
 which exercise only the host/collective logic.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -193,6 +195,7 @@ class ObjectCombiner:
         # process group of one rank): the rehearsal of the RCCL path — buffers, split sizes, the order of the collective's stream against
         # this library's launches — on a box with one GPU (tests/test_gpu_rccl.py). Same results either way.
         self.xch = self.world > 1 or bool(collectives_at_world_1)
+        self._side = {}                # device index -> the stream render_view evaluates on while collectives are in flight
         self.bytes_sent = 0            # bytes this rank put on the wire in the last render_view
 
     # ---- faithful per-sample select across ranks
@@ -280,6 +283,30 @@ class ObjectCombiner:
         return self.ops.select_composite(fields, nears_mine, fars_mine, tuple(bgs))
 
     def render_view(self, field_fns, n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=16384, overlap=True):
+        """`_render_view` (below), on a stream of this combiner's own while collectives are in flight. Measured with one rank on RCCL
+        (tools/time_rccl_one_rank.py): when RCCL's stream is the first stream a process uses after the default one —
+        bench.py at N > 1, or a fresh COMBINED.py-style process — it shares a hardware queue with the DEFAULT stream, and an all-to-all
+        "under" a field evaluation enqueued on the default stream runs strictly in turn with it (44.5 ms per view overlapped = not
+        overlapped); with the evaluation on any other stream the two run side by side (43.1), whichever of the two was created first.
+        To the caller nothing changes: the work is ordered behind what the caller's current stream holds, and the returned tensors
+        may be used on that stream. FOC_COMBINE_SIDE_STREAM=0 evaluates on the caller's stream as before."""
+        dev = nears.device
+        if self.xch and overlap and dev.type == "cuda" and os.environ.get("FOC_COMBINE_SIDE_STREAM", "1") != "0":
+            cur = torch.cuda.current_stream(dev)
+            side = self._side.get(dev.index)
+            if side is None:
+                side = self._side[dev.index] = torch.cuda.Stream(dev)
+            if cur != side:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    image4, depth = self._render_view(field_fns, n_rays, nears, fars, T, bgs, max_ray_batch, overlap)
+                cur.wait_stream(side)
+                image4.record_stream(cur)              # allocated under `side`, consumed by the caller on `cur`
+                depth.record_stream(cur)
+                return image4, depth
+        return self._render_view(field_fns, n_rays, nears, fars, T, bgs, max_ray_batch, overlap)
+
+    def _render_view(self, field_fns, n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=16384, overlap=True):
         """One view, the loop of COMBINED.py:592-618 + compute_metrics_both_backgrounds' composites, sharded by object and exchanged by ray.
         field_fns: THIS rank's objects in checkpoint order, each `fn(lo, hi, out)` -> packed field4 [hi-lo, T, 4] fp32 of the object on
         rays lo:hi of the view (it may write into `out`, a [hi-lo, T, 4] buffer, and return it). Ranks hold consecutive runs of the

@@ -66,6 +66,21 @@ for mrb in (4096, 1600, 100):
     ref4, refd = plain.render_view(fns, N, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=mrb)
     assert torch.equal(img1, ref4) and torch.equal(dep1, refd), f"pieces of {mrb} rays"
 
+# the caller on a stream of its own: render_view evaluates on the combiner's stream behind it, the result is used at once on the caller's
+caller = torch.cuda.Stream()
+caller.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(caller):
+    scale = torch.full((), 2.0, device="cuda")
+    for rep in range(2):
+        img1, dep1 = rccl.render_view(fns, N, nears * scale / 2, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk)
+        twice = img1 * scale                                           # consumed on the caller's stream without any synchronisation in between
+        assert torch.equal(twice, img0 * 2) and torch.equal(dep1, dep0), f"caller stream, view {rep}"
+torch.cuda.current_stream().wait_stream(caller)
+os.environ["FOC_COMBINE_SIDE_STREAM"] = "0"                           # the evaluation on the caller's stream, as before: same bits
+img1, dep1 = rccl.render_view(fns, N, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=chunk)
+assert torch.equal(img1, img0) and torch.equal(dep1, dep0)
+del os.environ["FOC_COMBINE_SIDE_STREAM"]
+
 # the faithful per-sample select, the chunk form and the per-ray sum model on random fields
 g = torch.Generator(device="cuda").manual_seed(5)
 n, t = 333, 48

@@ -25,11 +25,38 @@ from focnerf_amd.combine import ObjectCombiner
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+# DUMMY_STREAMS=k: k torch streams created (and used once) BEFORE RCCL makes its own — shifts which hardware queue RCCL's stream lands on
+# (HIP deals streams onto a few hardware queues in turn; two streams on one queue run one after the other)
+_dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY_STREAMS", "0")))]
+for _s in _dummies:
+    with torch.cuda.stream(_s):
+        torch.zeros(1, device=dev)
+torch.cuda.synchronize()
+# SIDE_COMPUTE=before|after: everything timed runs on a torch side stream instead of the default stream, the side stream first used before /
+# after RCCL's first collective (which is when RCCL's own stream is first used)
+side_mode = os.environ.get("SIDE_COMPUTE", "")
+side = None
+if side_mode == "before":
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+_t = torch.ones(4, device=dev)
+dist.all_reduce(_t)                                     # RCCL's stream exists and has run from here on, as after bench.py's first barrier()
+torch.cuda.synchronize()
+if side_mode == "after":
+    side = torch.cuda.Stream()
 
 poses, intr = bench.make_training_rays(dev, 1, 8, seed=0)
 vo, vd = synthetic.get_rays(poses[:1], intr, bench.VIEW, bench.VIEW)
 vo, vd = vo[0].contiguous(), vd[0].contiguous()
+# as bench.py's combined_render leg sets the view up: rays in 8 x 8 pixel tiles, no_grad, fp16 parameter copies made once per scope
+from focnerf_amd.field import half_cache_scope
+from focnerf_amd.rayorder import view_tiling
+tile_order = view_tiling(vd)
+if tile_order is not None:
+    vo, vd = vo.index_select(0, tile_order), vd.index_select(0, tile_order)
 n_rays, T = vo.shape[0], bench.NUM_STEPS
 fn = bench.resident_object_fields(dev, 1, vo, vd, 1)[0]
 probe = bench.build_foc_model(1, dev, seed=0)
@@ -65,11 +92,16 @@ def eval_only(chunk=16384):
 
 plain, rccl = ObjectCombiner(rank=0, world_size=1), ObjectCombiner(collectives_at_world_1=True)
 out = {"views": views, "rays": n_rays, "samples_per_ray": T, "piece_rays": 16384, "pieces_per_view": (n_rays + 16383) // 16384, "backend": dist.get_backend()}
-for rep in range(2):                                    # interleaved: the boxes drift by a percent or two over seconds
-    out[f"field_eval_only_s_{rep}"] = eval_only()
-    out[f"exchange_free_s_{rep}"], cs0 = timed(plain, True)
-    out[f"rccl_overlap_s_{rep}"], cs1 = timed(rccl, True)
-    out[f"rccl_no_overlap_s_{rep}"], cs2 = timed(rccl, False)
+out["ray_order"] = "8x8 pixel tiles" if tile_order is not None else "as given"
+out["compute_stream"] = ("side stream, first used %s RCCL's first collective" % side_mode) if side is not None else "default stream"
+out["dummy_streams_before_rccl"] = len(_dummies)
+reps = int(os.environ.get("REPS", "3"))
+for rep in range(reps):                                 # interleaved: the boxes drift by a percent or two over seconds
+    with torch.no_grad(), half_cache_scope(), torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+        out[f"field_eval_only_s_{rep}"] = eval_only()
+        out[f"exchange_free_s_{rep}"], cs0 = timed(plain, True)
+        out[f"rccl_overlap_s_{rep}"], cs1 = timed(rccl, True)
+        out[f"rccl_no_overlap_s_{rep}"], cs2 = timed(rccl, False)
     assert cs0 == cs1 == cs2, (cs0, cs1, cs2)
     print(f"rep {rep}: field evaluation alone {1e3 * out[f'field_eval_only_s_{rep}']:.2f} ms/view | exchange-free {1e3 * out[f'exchange_free_s_{rep}']:.2f} | "
           f"through RCCL, overlapped {1e3 * out[f'rccl_overlap_s_{rep}']:.2f} | through RCCL, not overlapped {1e3 * out[f'rccl_no_overlap_s_{rep}']:.2f}", flush=True)
