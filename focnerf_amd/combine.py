@@ -298,9 +298,11 @@ class ObjectCombiner:
                 side = self._side[dev.index] = torch.cuda.Stream(dev)
             if cur != side:
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    image4, depth = self._render_view(field_fns, n_rays, nears, fars, T, bgs, max_ray_batch, overlap)
-                cur.wait_stream(side)
+                try:
+                    with torch.cuda.stream(side):
+                        image4, depth = self._render_view(field_fns, n_rays, nears, fars, T, bgs, max_ray_batch, overlap)
+                finally:
+                    cur.wait_stream(side)              # also when a field function raised: kernels on `side` may still read the caller's buffers
                 image4.record_stream(cur)              # allocated under `side`, consumed by the caller on `cur`
                 depth.record_stream(cur)
                 return image4, depth
