@@ -24,6 +24,40 @@ i32 = ctypes.c_int
 FOC_F32 = 0
 FOC_F16 = 1
 
+
+
+class FocOccTrainNode(ctypes.Structure):
+    """include/focnerf.h `FocOccTrainNode`, field for field (tests/test_abi.py parses the header and compares names, order and size)."""
+    _fields_ = [
+        ("struct_bytes", u32),
+        ("n_rays", u32), ("max_steps", u32), ("cascade", u32), ("grid_size", u32), ("cap", u32), ("pad_align", u32),
+        ("bound", f32), ("dt_gamma", f32), ("min_near", f32),
+        ("rays_o", c_vp), ("rays_d", c_vp), ("aabb", c_vp), ("jitter", c_vp),
+        ("bitfield", c_vp),
+        ("nears", c_vp), ("fars", c_vp), ("enc_in", c_vp), ("deltas", c_vp),
+        ("sh_rows", c_vp),
+        ("rays", c_vp), ("counter", c_vp), ("march_scratch", c_vp),
+        ("levels", u32), ("base_resolution", u32), ("gridtype", u32), ("interp", u32),
+        ("align_corners", ctypes.c_int32), ("table_dtype", ctypes.c_int32),
+        ("per_level_scale_log2", f32),
+        ("embeddings", c_vp),
+        ("offsets", c_vp), ("offsets_host", c_vp),
+        ("planes", c_vp), ("grid_workspace", c_vp),
+        ("grid_workspace_bytes", u64),
+        ("sigma_input_dim", u32), ("sigma_hidden", u32), ("sigma_layers", u32), ("sigma_activation", u32), ("sigma_output_activation", u32),
+        ("color_hidden", u32), ("color_layers", u32), ("color_activation", u32), ("c_width", u32),
+        ("w_sigma", c_vp), ("w_color", c_vp),
+        ("h", c_vp), ("c", c_vp),
+        ("T_thresh", f32), ("density_scale", f32), ("bg_scalar", f32),
+        ("bg_ray", c_vp),
+        ("weights_sum", c_vp), ("image_raw", c_vp), ("image", c_vp), ("depth", c_vp),
+        ("precounted", ctypes.c_int32),
+        ("grad_image", c_vp), ("grad_ws", c_vp),
+        ("grad_c", c_vp), ("grad_h0", c_vp), ("grad_h", c_vp), ("grad_planes", c_vp), ("grad_w_color", c_vp), ("grad_w_sigma", c_vp),
+        ("grad_embeddings", c_vp), ("mlp_workspace", c_vp),
+    ]
+
+
 # name -> (restype, [argtypes]) — one entry per declaration in include/focnerf.h
 SIGNATURES = {
     "foc_abi_version": (i32, []),
@@ -43,6 +77,8 @@ SIGNATURES = {
     "foc_guard_pick_device": (i32, [i32, i32, i32, i32]),
     "foc_grid_forward_index_path": (i32, [u32, u32, u32]),
     "foc_view_tile_order": (i32, [c_vp, u32, u32, u32, c_vp, c_vp, c_vp]),
+    "foc_occ_train_forward": (i32, [ctypes.POINTER(FocOccTrainNode), c_vp]),
+    "foc_occ_train_backward": (i32, [ctypes.POINTER(FocOccTrainNode), c_vp]),
     "foc_occ_tail_forward": (i32, [c_vp, c_vp, u32, c_vp, c_vp, u32, u32, f32, f32, c_vp, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "foc_occ_tail_backward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, f32, c_vp, f32, c_vp, c_vp, c_vp]),
     "foc_march_rays_train_scratch_bytes": (u64, [u32, u32]),

@@ -215,4 +215,52 @@ int foc_occ_tail_backward(const float *grad_image, const float *grad_ws, const v
     return FOC_OK;
 }
 
+// ---------------------------------------------------------------- the node as one call each way
+// Sequencing only: each step is the public entry point a caller would have called itself, with its own argument checks and device guard.
+static int ot_check_node(const FocOccTrainNode *n, const char *who) {
+    FOC_REQUIRE(n != nullptr, FOC_E_INVALID, "%s: null node", who);
+    FOC_REQUIRE(n->struct_bytes == (uint32_t)sizeof(FocOccTrainNode), FOC_E_INVALID, "%s: node of %u bytes, this library's FocOccTrainNode has %zu", who,
+                n->struct_bytes, sizeof(FocOccTrainNode));
+    FOC_REQUIRE(n->cap > 0 && n->n_rays > 0, FOC_E_INVALID, "%s: empty node (cap %u, rays %u): nothing to sequence, call nothing", who, n->cap, n->n_rays);
+    FOC_REQUIRE(n->grid_workspace && n->grid_workspace_bytes && n->offsets_host, FOC_E_INVALID, "%s: the binned encoder backward's workspace is required", who);
+    return FOC_OK;
+}
+
+int foc_occ_train_forward(const FocOccTrainNode *n, void *stream) {
+    int rc = ot_check_node(n, "occ_train_forward");
+    if (rc != FOC_OK) return rc;
+    const uint32_t M = n->cap;
+    rc = foc_march_rays_train_field(n->rays_o, n->rays_d, n->bitfield, n->bound, n->dt_gamma, n->max_steps, n->n_rays, n->cascade, n->grid_size, M, n->nears, n->fars,
+                                    n->enc_in, n->sh_rows, n->deltas, n->rays, n->counter, n->jitter, n->march_scratch, n->pad_align, n->aabb, n->min_near, stream);
+    if (rc != FOC_OK) return rc;
+    rc = foc_grid_encode_forward_counted(n->enc_in, n->embeddings, n->offsets, n->planes, M, 3, 2, n->levels, n->per_level_scale_log2, n->base_resolution, n->gridtype,
+                                         n->align_corners, n->interp, n->table_dtype, n->offsets_host, n->grid_workspace, n->grid_workspace_bytes, stream);
+    if (rc != FOC_OK) return rc;
+    rc = foc_ffmlp_forward_planar(n->planes, n->w_sigma, M, n->sigma_input_dim, 16, n->sigma_hidden, n->sigma_layers, n->sigma_activation, n->sigma_output_activation,
+                                  n->h, stream);
+    if (rc != FOC_OK) return rc;
+    rc = foc_color_head_forward(n->h, n->sh_rows, 1, n->w_color, M, n->color_hidden, n->color_layers, n->color_activation, n->c, n->c_width, nullptr, stream);
+    if (rc != FOC_OK) return rc;
+    return foc_occ_tail_forward(n->h, n->c, n->c_width, n->deltas, n->rays, M, n->n_rays, n->T_thresh, n->density_scale, n->bg_ray, n->bg_scalar, n->nears, n->fars,
+                                n->weights_sum, n->image_raw, n->image, n->depth, stream);
+}
+
+int foc_occ_train_backward(const FocOccTrainNode *n, void *stream) {
+    int rc = ot_check_node(n, "occ_train_backward");
+    if (rc != FOC_OK) return rc;
+    const uint32_t M = n->cap;
+    rc = foc_occ_tail_backward(n->grad_image, n->grad_ws, n->h, n->c, n->c_width, n->deltas, n->rays, n->counter, n->weights_sum, n->image_raw, M, n->n_rays, n->T_thresh,
+                               n->density_scale, n->bg_ray, n->bg_scalar, n->grad_c, n->grad_h0, stream);
+    if (rc != FOC_OK) return rc;
+    rc = foc_color_head_backward(n->grad_c, n->h, n->sh_rows, 1, n->grad_h0, n->w_color, M, n->color_hidden, n->color_layers, n->color_activation, n->grad_h,
+                                 n->grad_w_color, n->mlp_workspace, n->c_width, nullptr, nullptr, stream);
+    if (rc != FOC_OK) return rc;
+    rc = foc_ffmlp_backward_planar(n->grad_h, n->planes, n->w_sigma, M, n->sigma_input_dim, 16, n->sigma_hidden, n->sigma_layers, n->sigma_activation,
+                                   n->sigma_output_activation, 1, n->grad_planes, n->grad_w_sigma, n->mlp_workspace, stream);
+    if (rc != FOC_OK) return rc;
+    return (n->precounted ? foc_grid_encode_backward_binned_counted : foc_grid_encode_backward_binned)(
+        n->grad_planes, n->enc_in, n->embeddings, n->offsets, n->grad_embeddings, M, 3, 2, n->levels, n->per_level_scale_log2, n->base_resolution, nullptr, nullptr,
+        n->gridtype, n->align_corners, n->interp, n->table_dtype, 0, n->offsets_host, n->grid_workspace, n->grid_workspace_bytes, stream);
+}
+
 } // extern "C"

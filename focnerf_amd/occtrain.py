@@ -18,7 +18,9 @@ import numpy as np
 import torch
 from torch.autograd import Function
 
-from ._lib import lib, ptr, stream_of, check
+import ctypes
+
+from ._lib import lib, ptr, stream_of, check, FocOccTrainNode, FOC_F16
 from .backend import _gridencoder, _ffmlp, _scratch
 
 _C_WIDTH = 4
@@ -49,6 +51,31 @@ def _no_jitter(n, dev):
     return z[:n]
 
 
+_plan_bytes = {}
+
+
+def _native_plan(offsets, S, H, L, gridtype, M, sig_cfg, col_cfg):
+    """(grid workspace bytes, MLP workspace bytes) when the node can run as ONE library call each way (include/focnerf.h FocOccTrainNode:
+    the encoder's counted forward and binned backward must apply, the switches that take other paths must be at their defaults), else None.
+    FOC_OCC_NATIVE_NODE=0: always the call-by-call chain below (the tests compare the two)."""
+    if (os.environ.get("FOC_OCC_NATIVE_NODE", "1") == "0" or os.environ.get("FOC_GRID_PRECOUNT", "1") != "1"
+            or os.environ.get("FOCNERF_GRID_ATOMIC", "0") == "1"):
+        return None
+    key = (M, L, sig_cfg[:3], col_cfg[0])
+    sizes = _plan_bytes.get(key)
+    if sizes is None:
+        sizes = _plan_bytes[key] = (int(lib.foc_grid_encode_backward_workspace_bytes(M, 3, 2, L, FOC_F16)),
+                                    max(int(lib.foc_ffmlp_backward_workspace_bytes(32, 64, int(col_cfg[0]))),
+                                        int(lib.foc_ffmlp_backward_workspace_bytes(int(sig_cfg[0]), int(sig_cfg[1]), int(sig_cfg[2])))))
+    if not sizes[0] or M * 8 * L >= 2 ** 32 or not _gridencoder._binned_ok(offsets, S, H, L, gridtype):
+        return None
+    return sizes
+
+
+def _a(t):
+    return t.data_ptr() if t is not None else None
+
+
 class _occ_train(Function):
     @staticmethod
     def forward(ctx, emb, w_sigma, w_color, o, d, aabb, bitfield, counter, bg_ray, cfg):
@@ -69,6 +96,51 @@ class _occ_train(Function):
         nears, fars = nf[0], nf[1]
         jitter = torch.rand(n, dtype=torch.float32, device=dev) if perturb else _no_jitter(n, dev)
         scratch = _scratch.get("march", lib.foc_march_rays_train_scratch_bytes(n, max_steps), dev)
+        L = offsets.shape[0] - 1
+        plan = _native_plan(offsets, S, H, L, gridtype, cap, sig_cfg, col_cfg) if (budgeted and cap > 0 and n > 0) else None
+        if plan is not None:
+            # the whole forward as one library call (csrc/occtrain.hip foc_occ_train_forward): the same five entry points in the same order,
+            # enqueued from C — the step's host time no longer depends on nine trips through the binding
+            M = cap
+            emb16, ws16, wc16 = _half_of(emb), _half_of(w_sigma), _half_of(w_color)
+            planes = torch.empty(L, M, 2, dtype=torch.float16, device=dev)
+            hc = torch.empty(M * (16 + _C_WIDTH), dtype=torch.float16, device=dev)
+            h, c = hc[: M * 16].view(M, 16), hc[M * 16:].view(M, _C_WIDTH)
+            out = torch.empty(n * 8, dtype=torch.float32, device=dev)
+            ws, depth, image_raw, image = out[:n], out[n: 2 * n], out[2 * n: 5 * n].view(n, 3), out[5 * n:].view(n, 3)
+            gws = _scratch.get("grid_bwd", plan[0], dev)
+            nd = FocOccTrainNode()
+            nd.struct_bytes = ctypes.sizeof(FocOccTrainNode)
+            nd.n_rays, nd.max_steps, nd.cascade, nd.grid_size, nd.cap, nd.pad_align = n, int(max_steps), int(cascade), int(grid_size), M, 0
+            nd.bound, nd.dt_gamma, nd.min_near = float(bound), float(dt_gamma), float(min_near)
+            nd.rays_o, nd.rays_d, nd.aabb, nd.jitter, nd.bitfield = _a(o), _a(d), _a(aabb), _a(jitter), _a(bitfield)
+            nd.nears, nd.fars, nd.enc_in, nd.deltas, nd.sh_rows = _a(nears), _a(fars), _a(enc_in), _a(deltas), _a(sh)
+            nd.rays, nd.counter, nd.march_scratch = _a(rays), _a(counter), _a(scratch)
+            nd.levels, nd.base_resolution, nd.gridtype, nd.interp = L, int(H), int(gridtype), int(interp)
+            nd.align_corners, nd.table_dtype, nd.per_level_scale_log2 = int(bool(align_corners)), FOC_F16, float(S)
+            nd.embeddings, nd.offsets, nd.offsets_host = _a(emb16), _a(offsets), _gridencoder._host_offsets(offsets)
+            nd.planes, nd.grid_workspace, nd.grid_workspace_bytes = _a(planes), _a(gws), plan[0]
+            nd.sigma_input_dim, nd.sigma_hidden, nd.sigma_layers, nd.sigma_activation, nd.sigma_output_activation = (
+                int(sig_cfg[0]), int(sig_cfg[1]), int(sig_cfg[2]), int(sig_cfg[3]), 6)
+            nd.color_hidden, nd.color_layers, nd.color_activation, nd.c_width = 64, int(col_cfg[0]), int(col_cfg[1]), _C_WIDTH
+            nd.w_sigma, nd.w_color, nd.h, nd.c = _a(ws16), _a(wc16), _a(h), _a(c)
+            nd.T_thresh, nd.density_scale, nd.bg_scalar, nd.bg_ray = float(T_thresh), float(density_scale), float(bg_scalar), _a(bg_ray)
+            nd.weights_sum, nd.image_raw, nd.image, nd.depth = _a(ws), _a(image_raw), _a(image), _a(depth)
+            check(lib.foc_occ_train_forward(ctypes.byref(nd), st), "occ_train_forward")
+            # the count pass rode in the encoder's forward: the ticket the backward checks, as backend.grid_encode_forward_counted issues it
+            idx, pre = _gridencoder._pre_state(dev)
+            pre["ticket"] += 1
+            pre["key"] = (enc_in.data_ptr(), M, L, FOC_F16, gws.data_ptr())
+            ctx.save_for_backward(enc_in, emb16, ws16, wc16, offsets, planes, h, c, sh, deltas, rays, counter, ws, image_raw,
+                                  bg_ray if bg_ray is not None else torch.empty(0, device=dev))
+            ctx.nears_fars = nf
+            ctx.cfg = (M, n, float(T_thresh), float(density_scale), float(bg_scalar), bg_ray is not None, enc_cfg, sig_cfg, col_cfg)
+            ctx.ticket = (idx, pre["ticket"], pre["key"])
+            ctx.node, ctx.plan = nd, plan
+            ctx.mark_non_differentiable(depth)
+            ctx.set_materialize_grads(False)
+            return image, ws, depth
+        ctx.node = None
         check(lib.foc_march_rays_train_field(ptr(o), ptr(d), ptr(bitfield), float(bound), float(dt_gamma), int(max_steps), n, int(cascade), int(grid_size), cap,
                                              ptr(nears), ptr(fars), ptr(enc_in), ptr(sh), ptr(deltas), ptr(rays), ptr(counter), ptr(jitter), ptr(scratch),
                                              0 if budgeted else max(int(align), 1), ptr(aabb), float(min_near), st), "march_rays_train_field")
@@ -115,6 +187,22 @@ class _occ_train(Function):
             return g_emb, g_wsig.zero_(), g_wcol.zero_(), None, None, None, None, None, None, None, None
         g_image = g_image.contiguous().float() if g_image is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
         g_ws = g_ws.contiguous().float() if g_ws is not None else None
+        nd = getattr(ctx, "node", None)
+        if nd is not None:                                  # the whole backward as one library call (foc_occ_train_backward)
+            gws = _scratch.get("grid_bwd", ctx.plan[0], dev)
+            mws = _scratch.get("ffmlp_ws", ctx.plan[1], dev)
+            gblock = torch.empty(M * (_C_WIDTH + 1), dtype=torch.float16, device=dev)  # grad_c [M,4] | grad_h0 [M]: every row written by the kernel
+            grad_h = torch.empty_like(h)                    # its own block: 32-byte rows written with 16-byte stores, M need not be a multiple of 8
+            g_planes = torch.empty_like(planes)
+            nd.grad_image, nd.grad_ws = _a(g_image), _a(g_ws)
+            nd.grad_c, nd.grad_h0, nd.grad_h = gblock.data_ptr(), gblock.data_ptr() + 2 * M * _C_WIDTH, _a(grad_h)
+            nd.grad_planes, nd.grad_w_color, nd.grad_w_sigma, nd.grad_embeddings = _a(g_planes), _a(g_wcol), _a(g_wsig), _a(g_emb)
+            nd.mlp_workspace, nd.grid_workspace, nd.grid_workspace_bytes = _a(mws), _a(gws), ctx.plan[0]
+            nd.precounted = int(_gridencoder._precount_valid(ctx.ticket, enc_in, M, L, FOC_F16, gws))
+            check(lib.foc_occ_train_backward(ctypes.byref(nd), st), "occ_train_backward")
+            _gridencoder._invalidate_precount(dev)          # the header now belongs to this pass (and a used ticket is spent)
+            ctx.node = None
+            return g_emb, g_wsig, g_wcol, None, None, None, None, None, None, None, None
         gblock = torch.empty(M * (_C_WIDTH + 1), dtype=torch.float16, device=dev)      # grad_c [M,4] | grad_h0 [M]: every row written by the kernel
         grad_c, grad_h0 = gblock[: M * _C_WIDTH].view(M, _C_WIDTH), gblock[M * _C_WIDTH:]
         check(lib.foc_occ_tail_backward(ptr(g_image), ptr(g_ws), ptr(h), ptr(c), _C_WIDTH, ptr(deltas), ptr(rays), ptr(counter), ptr(ws), ptr(image_raw), M, n,

@@ -537,6 +537,51 @@ int foc_occ_tail_backward(const float *grad_image, const float *grad_ws, const v
                           const float *image_raw, uint32_t M, uint32_t N, float T_thresh, float density_scale,
                           const float *bg_ray, float bg_scalar, void *grad_c, void *grad_h0, void *stream);
 
+/* The whole occupancy-grid TRAINING node as ONE call each way (csrc/occtrain.hip): what legacy/nerf/renderer.py:256-322 (`run_cuda`, training
+ * branch, a fixed sample budget) + nerf/network_ff.py:51-75 do between the rays and the image, in the order
+ *   forward:  foc_march_rays_train_field -> foc_grid_encode_forward_counted -> foc_ffmlp_forward_planar -> foc_color_head_forward -> foc_occ_tail_forward
+ *   backward: foc_occ_tail_backward -> foc_color_head_backward -> foc_ffmlp_backward_planar -> foc_grid_encode_backward_binned[_counted]
+ * — the SAME entry points with the same arguments, launched from C instead of from the host language: nine library calls per step cost a
+ * Python caller ~0.25 ms of the ~0.8 ms a 4096-ray step takes on the GPU, and the step then depends on the host's speed. Every buffer is the
+ * caller's (device memory, sizes as the entry points above document them; `cap` = rows of the sample arrays = the sample budget M);
+ * the encoder must be one the binned backward serves (D = 3, C = 2, fp16 table: foc_grid_encode_backward_workspace_bytes != 0).
+ * `struct_bytes` = sizeof(FocOccTrainNode): a binding built against another layout is refused. Backward: `precounted` != 0 when the
+ * workspace header still holds the count pass of THIS node's forward (nothing else used `grid_workspace` in between). */
+typedef struct FocOccTrainNode {
+    uint32_t struct_bytes;
+    /* rays, occupancy grid, march (foc_march_rays_train_field) */
+    uint32_t n_rays, max_steps, cascade, grid_size, cap, pad_align;
+    float bound, dt_gamma, min_near;
+    const float *rays_o, *rays_d, *aabb, *jitter;
+    const uint8_t *bitfield;
+    float *nears, *fars, *enc_in, *deltas;
+    void *sh_rows;
+    int32_t *rays, *counter, *march_scratch;
+    /* hash-grid encoder, [L,M,2] planes */
+    uint32_t levels, base_resolution, gridtype, interp;
+    int32_t align_corners, table_dtype;
+    float per_level_scale_log2;
+    const void *embeddings;
+    const int32_t *offsets, *offsets_host;
+    void *planes, *grid_workspace;
+    uint64_t grid_workspace_bytes;
+    /* density network (FFMLP, planar input) and colour head */
+    uint32_t sigma_input_dim, sigma_hidden, sigma_layers, sigma_activation, sigma_output_activation;
+    uint32_t color_hidden, color_layers, color_activation, c_width;
+    const void *w_sigma, *w_color;
+    void *h, *c;
+    /* tail */
+    float T_thresh, density_scale, bg_scalar;
+    const float *bg_ray;
+    float *weights_sum, *image_raw, *image, *depth;
+    /* backward only */
+    int32_t precounted;
+    const float *grad_image, *grad_ws;
+    void *grad_c, *grad_h0, *grad_h, *grad_planes, *grad_w_color, *grad_w_sigma, *grad_embeddings, *mlp_workspace;
+} FocOccTrainNode;
+int foc_occ_train_forward(const FocOccTrainNode *node, void *stream);
+int foc_occ_train_backward(const FocOccTrainNode *node, void *stream);
+
 /* Extension (no reference binding; focnerf_amd/rayorder.py): perm [N] int64 = the order in which a staged render walks a view's rays —
  * tile_h x tile_w pixel tiles when rays_d [N,3] fp32 is a row-major H x W pixel grid (recognised from the directions: W >= 16, H >= 8),
  * else the identity. Found and built on the device, no host round trip. state16: 16 bytes of device scratch. */

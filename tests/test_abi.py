@@ -4,6 +4,7 @@ import os
 import re
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "focnerf.h")
 
 
 def _declared():
@@ -51,6 +52,42 @@ def test_argument_validation_needs_no_gpu():
     assert rc == 1 and b"input_dim" in lib.foc_last_error()
     rc = lib.foc_freq_encode_forward(one, 4, 3, 4, 26, one, None)
     assert rc == 1
+
+
+def test_occ_train_node_struct_matches_the_header_and_is_validated_on_the_host():
+    """include/focnerf.h `FocOccTrainNode` against its ctypes mirror (focnerf_amd/_lib.py): same field names in the same order, and the size
+    a C compiler gives the header's struct; a null node, a node of another size and an empty node are refused before any launch."""
+    import re
+    import subprocess
+    import tempfile
+    from focnerf_amd import _lib
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct FocOccTrainNode \{(.*?)\} FocOccTrainNode;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"[A-Za-z_0-9]+$", first.strip())[0])
+        names += [r.strip().lstrip("*").strip() for r in rest]
+    assert names == [f[0] for f in _lib.FocOccTrainNode._fields_]
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "%s"\nint main(void) { printf("%%zu", sizeof(FocOccTrainNode)); return 0; }\n' % HEADER)
+        subprocess.run(["gcc", "-o", os.path.join(tmp, "sz"), src], check=True)
+        assert int(subprocess.run([os.path.join(tmp, "sz")], capture_output=True, text=True, check=True).stdout) == ctypes.sizeof(_lib.FocOccTrainNode)
+    lib = _lib.lib
+    for fn in (lib.foc_occ_train_forward, lib.foc_occ_train_backward):
+        assert fn(None, None) == 1 and b"null node" in lib.foc_last_error()
+        node = _lib.FocOccTrainNode()
+        node.struct_bytes = ctypes.sizeof(_lib.FocOccTrainNode) - 8
+        assert fn(ctypes.byref(node), None) == 1 and b"bytes" in lib.foc_last_error()
+        node.struct_bytes = ctypes.sizeof(_lib.FocOccTrainNode)
+        assert fn(ctypes.byref(node), None) == 1 and b"empty node" in lib.foc_last_error()
+        node.cap, node.n_rays = 128, 4
+        assert fn(ctypes.byref(node), None) == 1 and b"workspace" in lib.foc_last_error()
 
 
 def test_device_selection_rule_of_the_entry_points():

@@ -78,6 +78,46 @@ def test_fused_training_path_equals_the_op_chain(case, monkeypatch):
         assert np.abs(a - b).max() <= 4e-3 * scale, f"{case}: grad {name} off by {np.abs(a - b).max() / scale:.2e} of its range"
 
 
+@pytest.mark.parametrize("case", ["budget", "budget_overflow", "per_ray_bg", "grey_bg_scaled"])
+def test_node_as_one_library_call_equals_the_call_by_call_node(case, monkeypatch):
+    """foc_occ_train_forward / _backward (include/focnerf.h FocOccTrainNode) sequence the entry points the node otherwise calls one by one
+    (FOC_OCC_NATIVE_NODE=0): the same kernels on the same buffers in the same order — image, depth, opacity AND the three gradients bit
+    for bit; and with a sample budget set it IS the path taken (one call each way)."""
+    from focnerf_amd._lib import lib
+    bound = 2
+    m = _model(bound, density_scale=2 if case == "grey_bg_scaled" else 1)
+    o, d = _rays(bound, 1500, 3)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        m.render(o, d, staged=False, dt_gamma=1 / 128, max_steps=1024, perturb=False, force_all_rays=True)          # fills step_counter
+    total = int(m.step_counter[(m.local_step - 1) % 16, 0])
+    m.mean_count = total // 2 if case == "budget_overflow" else total + 500
+    kw = dict(perturb=True, force_all_rays=False, bg_color={"per_ray_bg": torch.rand(1500, 3, device="cuda"), "grey_bg_scaled": 0.25}.get(case))
+    calls = {"forward": 0, "backward": 0}
+    for name in calls:
+        real = getattr(lib, "foc_occ_train_" + name)
+        monkeypatch.setattr(lib, "foc_occ_train_" + name, lambda *a, _r=real, _n=name: (calls.__setitem__(_n, calls[_n] + 1), _r(*a))[1])
+    monkeypatch.setenv("FOC_OCC_NATIVE_NODE", "0")
+    ref, g_ref = _step(m, o, d, True, monkeypatch, **kw)
+    assert calls == {"forward": 0, "backward": 0}
+    monkeypatch.setenv("FOC_OCC_NATIVE_NODE", "1")
+    got, g_got = _step(m, o, d, True, monkeypatch, **kw)
+    assert calls == {"forward": 1, "backward": 1}
+    for k in ("image", "depth", "weights_sum"):
+        a, b = to_np(ref[k]), to_np(got[k])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{case}: {k} differs, max {np.nanmax(np.abs(a - b))}"
+    assert to_np(got["weights_sum"]).max() > 0.5
+    for name, a, b in zip(("embeddings", "sigma_net", "color_net"), g_ref, g_got):
+        assert torch.equal(a, b), f"{case}: grad {name} differs by {float((a.double() - b.double()).abs().max())}"
+        assert float(a.abs().max()) > 0
+    # a second step reuses the workspaces and spends a fresh ticket: still the bits of the chain's second step
+    monkeypatch.setenv("FOC_OCC_NATIVE_NODE", "0")
+    ref2, g_ref2 = _step(m, o, d, True, monkeypatch, seed=8, **kw)
+    monkeypatch.setenv("FOC_OCC_NATIVE_NODE", "1")
+    got2, g_got2 = _step(m, o, d, True, monkeypatch, seed=8, **kw)
+    assert torch.equal(ref2["image"], got2["image"]) and all(torch.equal(a, b) for a, b in zip(g_ref2, g_got2))
+    assert not torch.equal(got["image"], got2["image"])
+
+
 def test_fused_training_step_is_deterministic(monkeypatch):
     """No atomics on the way: the march hands out slots by a scan, the weight gradients are summed in a fixed order, the table gradient
     in fixed point — two runs of the same step give the same bits."""
