@@ -96,6 +96,13 @@ out["ray_order"] = "8x8 pixel tiles" if tile_order is not None else "as given"
 out["compute_stream"] = ("side stream, first used %s RCCL's first collective" % side_mode) if side is not None else "default stream"
 out["dummy_streams_before_rccl"] = len(_dummies)
 reps = int(os.environ.get("REPS", "3"))
+only = os.environ.get("ONLY")                           # ONLY=overlap: nothing but the overlapped exchange (for a kernel trace, tools/rccl_overlap_from_trace.py)
+if only == "overlap":
+    with torch.no_grad(), half_cache_scope(), torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+        t, cs = timed(rccl, True)
+    print(f"overlapped exchange only: {1e3 * t:.2f} ms/view, checksum {cs}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0)
 for rep in range(reps):                                 # interleaved: the boxes drift by a percent or two over seconds
     with torch.no_grad(), half_cache_scope(), torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
         out[f"field_eval_only_s_{rep}"] = eval_only()
