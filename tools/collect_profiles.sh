@@ -23,6 +23,10 @@ for pair in occupancy_train:prof_occupancy.py render_fixed:time_render_fixed.py 
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$R/tools/$script" > "$OUT/$name.log" 2>&1
   cp "$(find "$OUT/$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${name}_kernel_stats.csv"
 done
+# HBM counters of the configs[2] training step (two separate --pmc passes, as for the bench)
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/occ_pmc_fetch" -- python3 "$R/tools/prof_occupancy.py" > "$OUT/occ_pmc_fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/occ_pmc_write" -- python3 "$R/tools/prof_occupancy.py" > "$OUT/occ_pmc_write.log" 2>&1
+python3 "$R/tools/summarize_profiles.py" --pmc-only "$OUT/occ_pmc_fetch" "$OUT/occ_pmc_write" "$OUT/${TAG}_occupancy_train_pmc_hbm.csv"
 # the fixed-step render once more with every chunk on ONE stream (with the default two streams the kernels of neighbouring chunks overlap
 # and rocprofv3's durations are those of kernels sharing the chip): the kernel stats and the HBM counters bench.py's roofline.render
 # refers to. The environment is exported here — nothing stands between `--` and python3.
@@ -36,4 +40,4 @@ python3 "$R/tools/summarize_profiles.py" --pmc-only "$OUT/render_pmc_fetch" "$OU
 unset FOC_RENDER_STREAMS VIEWS FIELDS
 # the raw traces (hundreds of MB) stay on the box: gpurun copies back at most 64 MiB of gpurun_out/
 rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/occupancy_train" "$OUT/render_fixed" "$OUT/render_occupancy" \
-       "$OUT/render_fixed_1s" "$OUT/render_pmc_fetch" "$OUT/render_pmc_write"
+       "$OUT/render_fixed_1s" "$OUT/render_pmc_fetch" "$OUT/render_pmc_write" "$OUT/occ_pmc_fetch" "$OUT/occ_pmc_write"
