@@ -90,6 +90,19 @@ def test_occ_train_node_struct_matches_the_header_and_is_validated_on_the_host()
         assert fn(ctypes.byref(node), None) == 1 and b"workspace" in lib.foc_last_error()
 
 
+def test_a_c_caller_links_the_library_and_gets_host_side_refusals(tmp_path):
+    """tests/c_abi_consumer.cpp, mode "cpu": a program that is not Python includes include/focnerf.h, links libfocnerf_hip.so and gets the ABI
+    version, refusals with messages, the option table — without a device (the device half runs in tests/test_gpu_edge_cases.py)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from util import build_c_abi_consumer
+    import oracle                                                    # noqa: F401 — builds oracle/_build/liboracle.so if it is missing
+    exe = build_c_abi_consumer(tmp_path)
+    r = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C_ABI_CONSUMER_OK cpu" in r.stdout, r.stdout + r.stderr
+
+
 def test_device_selection_rule_of_the_entry_points():
     """csrc/common.h FocDeviceGuard: a non-null stream decides; the NULL stream (torch's default stream on EVERY device) says nothing, then
     the first pointer argument's device does — a C caller with cuda:1 buffers on the default stream while cuda:0 is current; neither: the

@@ -182,3 +182,14 @@ def test_ops_follow_their_tensors_device():
         s1, c1 = m1(x.to("cuda:1"), d.to("cuda:1"))
     assert torch.cuda.current_device() == 0
     assert s1.device.index == 1 and torch.equal(s0.cpu(), s1.cpu()) and torch.equal(c0.cpu(), c1.cpu())
+
+
+def test_a_c_caller_with_hip_runtime_buffers_matches_the_oracle(tmp_path):
+    """tests/c_abi_consumer.cpp, mode "gpu": hipMalloc'ed buffers, raw pointers and sizes, the NULL stream — near_far_from_aabb (hits, misses,
+    origins inside the box, axis-parallel rays), morton3D and packbits against the C oracle linked into the same program, bit for bit; an error
+    in between leaves a message and the next call works. No torch and no Python inside that process."""
+    import subprocess
+    from util import build_c_abi_consumer
+    exe = build_c_abi_consumer(tmp_path)
+    r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ABI_CONSUMER_OK gpu" in r.stdout, r.stdout + r.stderr

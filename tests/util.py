@@ -59,3 +59,21 @@ def assert_bits_equal(got, ref, what=""):
         k = tuple(k)
         lines.append(f"  at {k}: got {got[k]!r} (0x{int(gb[k]):x})  want {ref[k]!r} (0x{int(rb[k]):x})")
     raise AssertionError("\n".join(lines))
+
+
+def build_c_abi_consumer(tmp_path):
+    """tests/c_abi_consumer.cpp -> an executable under tmp_path: a caller of include/focnerf.h written against the HIP runtime API only (plain g++,
+    no torch, no Python), linked with the library and with the C oracle it checks the results against. Returns the executable's path."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    exe = os.path.join(str(tmp_path), "c_abi_consumer")
+    libs = [os.path.join(repo, "focnerf_amd"), os.path.join(repo, "oracle", "_build"), os.path.join(rocm, "lib")]
+    cmd = ["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(repo, "include"),
+           os.path.join(repo, "tests", "c_abi_consumer.cpp"), "-o", exe, "-lfocnerf_hip", "-loracle", "-lamdhip64"]
+    for d in libs:
+        cmd += ["-L" + d, "-Wl,-rpath," + d]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
