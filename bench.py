@@ -745,18 +745,26 @@ def main():
     timer.enabled = True
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     alloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
-    t0 = time.perf_counter()
+    host_marks = [0.0] * (args.steps + 1)                  # when the host had enqueued step i (a spike in a step's GPU time with a host pause at the same
+    t0 = time.perf_counter()                                 # step is the host's: the region starts from an empty queue, the host's lead grows by ~0.6 ms per step)
+    host_marks[0] = t0
     step_marks[0].record()
     for i in range(args.steps):
         train_step(model, opt, scaler, *batches[(args.warmup + i) % len(batches)], fused=fused, sched=sched)
         step_marks[i + 1].record()
+        host_marks[i + 1] = time.perf_counter()
     barrier()
     el = max_over_ranks(time.perf_counter() - t0)
     timer.enabled = False
     ksum = timer.summary()
     count_share = timer.count_share_ms()
-    per_step = sorted(step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps))
+    raw_steps = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
+    host_steps = [1e3 * (host_marks[i + 1] - host_marks[i]) for i in range(args.steps)]
+    per_step = sorted(raw_steps)
     step_stats = {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1],
+                  "slowest_step": max(range(args.steps), key=lambda i: raw_steps[i]) if args.steps else None,
+                  "host_enqueue_ms": {"median": sorted(host_steps)[len(host_steps) // 2], "max": max(host_steps),
+                                      "max_at_step": max(range(args.steps), key=lambda i: host_steps[i])} if args.steps else None,
                   "device_allocs_in_timed_region": torch.cuda.memory_stats(device).get("num_device_alloc", 0) - alloc0,
                   "init_steps_before_warmup": init_steps}
 
