@@ -68,8 +68,10 @@ class HashGridEncode(AmpOp):
             planes = torch.empty(levels, n, chans, **like)
             encoded = torch.empty(n, levels * chans, **like)
             # a forward whose table will receive a gradient lets the backward's count pass ride in its launch (the kernels' own callers do
-            # the same, focnerf_amd/field.py): the backward then starts at its scatter — 0.10 ms of a 2 M-point call
-            if dy_dx is None and dim == 3 and chans == 2 and ctx.needs_input_grad[1] and n:
+            # the same, focnerf_amd/field.py): the backward then starts at its scatter — 0.10 ms of a 2 M-point call. `needs_input_grad`
+            # alone stays True under torch.no_grad() for an nn.Parameter table: an evaluation call must neither run the count pass, nor
+            # create the backward's scratch, nor take a precount ticket away from a pending training forward
+            if dy_dx is None and dim == 3 and chans == 2 and ctx.needs_input_grad[1] and torch.is_grad_enabled() and n:
                 ticket = _kernels.grid_encode_forward_counted(points, table, offsets, planes, *shape, *spec.tail())
             if ticket is None:
                 _kernels.grid_encode_forward(points, table, offsets, planes, *shape, dy_dx, *spec.tail())

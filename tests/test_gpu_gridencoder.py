@@ -472,6 +472,45 @@ def test_precounted_backward_and_stale_tickets(monkeypatch):
             assert (a.float() - b.float()).abs().max().item() <= 2e-3 * scale
 
 
+def test_no_grad_grid_encode_leaves_the_backward_state_alone():
+    """The public op under torch.no_grad() (evaluation through the drop-in path): `needs_input_grad` stays True for an nn.Parameter table there,
+    but the call must not run the backward's count pass — it neither takes a precount ticket (which would invalidate a pending training
+    forward's) nor touches the grid_bwd scratch; and a training forward's ticket survives an evaluation call made before its backward."""
+    from focnerf_amd import backend
+    from focnerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(5)
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).cuda().train()
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    xa = torch.rand(6000, 3, device="cuda") * 2 - 1
+    xe = torch.rand(9000, 3, device="cuda") * 2 - 1
+    _, st = backend._gridencoder._pre_state(xa.device)
+    calls = []
+    real = backend._gridencoder.grid_encode_forward_counted
+    backend._gridencoder.grid_encode_forward_counted = staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            ya = enc(xa, 1)                                   # training forward: counted, takes a ticket
+            before = dict(st)
+            scratch_before = {k: v[0].data_ptr() for k, v in backend._scratch._bufs.items()}
+            assert len(calls) == 1 and before["key"] is not None
+            with torch.no_grad():
+                ye = enc(xe, 1)                               # evaluation in between
+            assert len(calls) == 1, "a no_grad grid_encode ran the backward's count pass"
+            assert dict(st) == before, "a no_grad grid_encode changed the precount ticket"
+            assert {k: v[0].data_ptr() for k, v in backend._scratch._bufs.items()} == scratch_before
+        (ya.float() ** 2).sum().backward()
+        g_counted = enc.embeddings.grad.clone()
+    finally:
+        backend._gridencoder.grid_encode_forward_counted = staticmethod(real)
+    assert not ye.requires_grad and torch.isfinite(ye).all()
+    # the same gradient as a step without the evaluation call in between
+    enc.embeddings.grad = None
+    with torch.autocast("cuda", dtype=torch.float16):
+        yb = enc(xa, 1)
+    (yb.float() ** 2).sum().backward()
+    assert torch.equal(ya, yb) and torch.equal(g_counted, enc.embeddings.grad)
+
+
 @pytest.mark.parametrize("standalone", [False, True])
 @pytest.mark.parametrize("B,L", [(1, 16), (1000, 16), (70001, 16), (5000, 2), (3000, 5)])
 def test_counted_forward_and_counted_backward_match_the_plain_calls(B, L, standalone):
