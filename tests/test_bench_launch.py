@@ -28,6 +28,26 @@ def test_self_launch_two_ranks_prints_one_line_with_the_combined_leg():
     assert single["n_gpus"] == 1 and single["combined_render"]["bytes_sent_per_view_per_gpu"] == 0
 
 
+def test_self_launch_at_the_real_world_size_of_configs4():
+    """`bench.py --gpus 8 --dry-run-cpu`: the launch the driver's SCALE run makes at N = 8 — eight gloo ranks, one object each, the by-ray
+    exchange, the gather, ONE line from rank 0."""
+    r = _run(8)
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak"
+    leg = r["combined_render"]
+    assert "error" not in leg and leg["objects"] == 8 and leg["world_size"] == 8 and leg["value"] > 0
+    assert leg["bytes_sent_per_view_per_gpu"] > 0
+
+
+def test_a_rank_failing_before_the_first_collective_fails_an_eight_rank_launch():
+    """Rank 5 of 8 dies before the process group exists: the launcher tears the other seven down, the launch returns non-zero and NO result line is
+    printed (a line without a measured leg would read as a measurement)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FOC_BENCH_FAIL_RANK"] = "5"
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-1000:]
+
+
 def test_a_failing_rank_fails_the_launch():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["FOC_BENCH_FAIL_RANK"] = "1"

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 over gloo: the host / collective logic of the one-object-per-rank combine
+"""CPU, world_size 2, 4 and 8 over gloo: the host / collective logic of the one-object-per-rank combine
 (focnerf_amd/combine.py). The device kernels are replaced by CPU ops DEFINED HERE (backed by the
 oracle) and injected through the `ops` parameter — the product itself has no CPU path.
 
@@ -175,6 +175,10 @@ def _view_worker(rank, world, port, K, N, T, chunk, overlap, out_dir):
     (2, 4, 70, 33, False),       # two objects per rank (local pre-merge incl. a tie inside the run), odd chunk, no overlap
     (4, 4, 50, 16, True),        # world 4; last chunk of 2 rays: two ranks own nothing of it
     (4, 8, 45, 45, True),        # configs[4]-shaped: 8 objects on 4 ranks, a single ragged chunk
+    (8, 8, 43, 43, True),        # configs[4] at its real world size: 8 objects on 8 ranks, a ray count that 8 does not divide
+    (8, 8, 69, 32, True),        # ... and a last chunk of 5 rays: three of the eight ranks own no ray of it
+    (8, 8, 69, 32, False),       # the same without overlap
+    (8, 16, 21, 8, True),        # two objects per rank at world 8, a last chunk of 5
 ])
 def test_render_view_by_ray_exchange_equals_serial(tmp_path, world, K, N, chunk, overlap):
     T = 24
@@ -255,11 +259,11 @@ def _editable_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_configs4_editable_fixture_over_four_ranks(tmp_path):
-    """BASELINE configs[4] (8 objects, editable.py offset render) at world 4 on the reference's own numbers: the images the reference's
-    methods produced (tests/golden/make_golden.py editable_fixture) come out of the sharded path within the oracle-vs-torch summation
-    tolerance, on every rank, for both views and both backgrounds."""
-    world = 4
+@pytest.mark.parametrize("world", [4, 8])
+def test_configs4_editable_fixture_over_four_and_eight_ranks(tmp_path, world):
+    """BASELINE configs[4] (8 objects, editable.py offset render) at world 4 (two objects per rank) and at its REAL world size 8 (one object per
+    rank) on the reference's own numbers: the images the reference's methods produced (tests/golden/make_golden.py editable_fixture) come out of
+    the sharded path within the oracle-vs-torch summation tolerance, on every rank, for both views and both backgrounds."""
     mp.spawn(_editable_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     fx = np.load(os.path.join(GOLDEN, "editable.npz"))
     for r in range(world):

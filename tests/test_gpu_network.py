@@ -60,7 +60,7 @@ def test_network_matches_oracle_pipeline():
     assert (got == rgb_ref).mean() > 0.95, f"only {(got == rgb_ref).mean():.3f} of the colours are the oracle's bits"
 
 
-def literal_distance(B=131072, seed=1):
+def literal_distance(B=131072, seed=1, weight_scale=1.0):
     """Distance of the HIP network's (sigma, rgb) on the BASELINE field — hash grid L16 / C2 / 2^19 with a seed-`seed` U(-1, 1) table, sigma network
     32 -> 64 -> 64 -> 16, colour network 32 -> 64 -> 64 -> 64 -> 16 with FFMLP's seed-42 initialisation (ffmlp.py:141-144) — to the oracle chain in the
     REFERENCE-LITERAL numerics: the encoder's corner sum kept in half (gridencoder.cu:164,187; oracle grid acc_mode 0) and the MLPs' running sums
@@ -71,6 +71,9 @@ def literal_distance(B=131072, seed=1):
     from focnerf_amd.network import NeRFNetwork
     torch.manual_seed(0)
     m = NeRFNetwork(bound=1, cuda_ray=False).cuda().eval()
+    if weight_scale != 1.0:                               # a field with larger logits than the initialisation gives (a trained field's range)
+        m.sigma_net.weights.data.mul_(weight_scale ** (1 / 3))
+        m.color_net.weights.data.mul_(weight_scale ** (1 / 4))
     g = torch.Generator().manual_seed(seed)
     m.encoder.embeddings.data.copy_((torch.rand(m.encoder.embeddings.shape, generator=g) * 2 - 1).cuda())
     g2 = torch.Generator().manual_seed(seed + 1000)
@@ -84,7 +87,7 @@ def literal_distance(B=131072, seed=1):
     table = to_np(m.encoder.embeddings).astype(np.float16)
     sh = torch_cpu_nerf.sh_encode_deg4(d.cpu().float()).numpy().astype(np.float16)
     Ws, Wc = to_np(m.sigma_net.weights).astype(np.float16), to_np(m.color_net.weights).astype(np.float16)
-    out = {"samples": int(B)}
+    out = {"samples": int(B), "weight_scale": float(weight_scale)}
     for name, grid_acc, mlp_acc in (("literal", 0, 1), ("fp32acc", 1, 0)):
         enc = oracle.grid_encode_forward(to_np((x + 1) / 2), table, to_np(m.encoder.offsets), 3, 2, 16, S, 16, acc_mode=grid_acc)
         enc = np.ascontiguousarray(np.transpose(enc, (1, 0, 2)).reshape(B, 32))
@@ -98,7 +101,8 @@ def literal_distance(B=131072, seed=1):
         out[name] = {"rgb_abs_max": float(drgb.max()), "rgb_abs_p999": float(np.quantile(drgb, 0.999)), "rgb_abs_mean": float(drgb.mean()),
                      "sigma_rel_max": float(dsig.max()), "sigma_rel_p999": float(np.quantile(dsig, 0.999)), "sigma_rel_mean": float(dsig.mean()),
                      "rgb_identical_share": float((drgb == 0).mean()), "sigma_identical_share": float((dsig == 0).mean()),
-                     "sigma_range": [float(sig_ref.min()), float(sig_ref.max())]}
+                     "sigma_range": [float(sig_ref.min()), float(sig_ref.max())], "h0_abs_max": float(np.abs(h[:, 0].astype(np.float32)).max()),
+                     "rgb_logit_abs_max": float(np.abs(c.astype(np.float32)).max())}
     return out
 
 

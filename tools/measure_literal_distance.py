@@ -9,4 +9,5 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, os.path.join(R, "tests")]
 import test_gpu_network as t  # noqa: E402
 
-print(json.dumps(t.literal_distance(int(sys.argv[1]) if len(sys.argv) > 1 else 131072), indent=1))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+print(json.dumps([t.literal_distance(n), t.literal_distance(n // 4, weight_scale=16.0)], indent=1))
