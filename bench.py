@@ -131,6 +131,44 @@ def mlp_flops_per_row(input_dim, hidden, num_layers):
     return 2.0 * (input_dim * hidden + (num_layers - 1) * hidden * hidden + hidden * 16)
 
 
+def step_op_table():
+    """C-ABI entry points of the headline step -> (HIP kernels as rocprofv3 prints them, what bounds them, ALGORITHMIC bytes per sample
+    (SURVEY.md §8d / DESIGN.md §4), USEFUL flops per sample: the forward products once, the backward's dX and dW products — the re-evaluated
+    forward inside the fused backward is not counted)."""
+    fs, fc = mlp_flops_per_row(32, 64, 2), mlp_flops_per_row(32, 64, 3)
+    bwd_kernels = ["k_mlp_bwd_priv", "k_mlp_bwd_fused", "k_mlp_dw_reduce"]
+    return {
+        "foc_fixed_sample": (["k_fs_sample"], "hbm", 12.0, None),
+        "foc_near_far_from_aabb": (["k_near_far_from_aabb"], "hbm", 32.0 / NUM_STEPS, None),
+        "foc_grid_encode_forward_counted": (["k_grid_fwd_counted", "k_gbin_scans"], "hbm", 588.0, None),
+        "foc_grid_encode_forward": (["k_grid_fwd_lbc"], "hbm", 588.0, None),
+        "foc_ffmlp_forward_planar": (["k_mlp_fwd"], "mfma", 64.0 + 32.0, fs),
+        "foc_color_head_forward": (["k_mlp_fwd"], "mfma", 32.0 + 8.0, fc),
+        "foc_fixed_tail_forward": (["k_fs_tail_fwd"], "hbm", 40.0 + 12.0, None),
+        "foc_fixed_tail_backward": (["k_fs_tail_bwd"], "hbm", 28.0 + 34.0, None),
+        "foc_color_head_backward": (bwd_kernels, "mfma", 8.0 + 32.0 + 32.0, 2.0 * fc),
+        "foc_ffmlp_backward_planar": (bwd_kernels, "mfma", 32.0 + 64.0 + 64.0, 2.0 * fs),
+        "foc_grid_encode_backward_binned_counted": (["k_gbin_scatter", "k_gbin_reduce"], "hbm", 588.0, None),
+        "foc_grid_encode_backward_binned": (["k_gbin_count", "k_gbin_scans", "k_gbin_scatter", "k_gbin_reduce"], "hbm", 588.0, None),
+    }
+
+
+def pmc_mfma_utilisation(patterns):
+    """{kernel: matrix-pipe utilisation} of the kernels whose (mangled) name contains one of `patterns`, from the newest committed
+    profiles/*_bench_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... in its own pass), or None. A figure from a committed file, not from
+    this run: the file name travels with it."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_bench_pmc_mfma.csv")))
+    if not files:
+        return None
+    out = {}
+    for row in csv.DictReader(open(files[-1])):
+        if any(pat in row["kernel"] for pat in patterns):
+            out[row["kernel"][:64]] = float(row["mfma_pipe_utilisation"])
+    return {"source": os.path.basename(files[-1]), "by_kernel": out} if out else None
+
+
 class KernelTimer:
     """Event pairs around the C-ABI calls of focnerf_amd.backend, on torch's current stream (the stream the kernels launch on)."""
 
@@ -287,13 +325,18 @@ def render_roofline(model, view_rays, rkw, n_views=2):
     kern, bpu = RENDER_OPS[dom]
     achieved = bpu * units / (ks[dom][1] * 1e-3) / 1e9
     total = sum(v[0] * v[1] for v in ks.values())
-    return {"kernel": f"{dom} = {kern}", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic_bytes(dom, which="render_fixed", kernels=[kern]), "avg_launch_ms": ks[dom][1], "units_per_launch": units,
+    traffic = pmc_traffic_bytes(dom, which="render_fixed", kernels=[kern])
+    hbm_real = (traffic / (ks[dom][1] * 1e-3) / 1e9) if traffic else None
+    return {"kernel": f"{dom} = {kern}", "bound": "cache-request (L2 / Infinity-Cache gathers; HBM carries `hbm_real_frac`)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "hbm_real_GBps": hbm_real, "hbm_real_frac": (hbm_real / HBM_PEAK_GBS) if hbm_real else None,
+            "traffic": traffic, "avg_launch_ms": ks[dom][1], "units_per_launch": units,
             "algorithmic_bytes_per_unit": bpu, "share_of_render_kernel_time": ks[dom][0] * ks[dom][1] / total,
             "kernels_ms_per_chunk": {RENDER_OPS[k][0]: round(v[1], 4) for k, v in ks.items()}, "one_stream_s_per_view": one_stream_s,
             "note": "events on the launch stream around the C-ABI call, every chunk on one stream (FOC_RENDER_STREAMS=1); the rays/s figure is the "
-                    "default two-stream render. The hash tables (24 MB fp16) are cache resident: the 512 gathered bytes per sample are L2 / "
-                    "Infinity-Cache traffic, `traffic` (profiles/*_render_fixed_pmc_hbm.csv) is what reaches HBM"}
+                    "default two-stream render. `frac` prices the ALGORITHMIC 588 B per sample against the HBM peak as the contract asks, but the hash "
+                    "tables (24 MB fp16) are cache resident: the 512 gathered bytes per sample are L2 / Infinity-Cache requests, not HBM traffic. What "
+                    "reaches HBM is `traffic` (profiles/*_render_fixed_pmc_hbm.csv; the PMC run's piece size may differ from this run's: the real "
+                    "fraction is quoted per launch of that file's size when they agree) = `hbm_real_frac` of the peak"}
 
 
 def build_model(bound, device, cuda_ray=False, seed=0):
@@ -774,10 +817,10 @@ def main():
     # kernel-only step time (the optimizer is excluded or reported separately): a few more steps with an event pair around
     # EVERY C-ABI call of the library — what the step costs in this library's kernels, the rest being torch's own (fused Adam, GradScaler
     # unscale / inf check, fp16 <-> fp32 casts of parameters and gradients, fills, the loss)
+    ks_all, n_k = {}, 5
     try:
         from focnerf_amd import _lib
         names = [n for n, (_, a) in _lib.SIGNATURES.items() if a and a[-1] is _lib.c_vp and not n.endswith("_bytes")]
-        n_k = 5
         with LibTimer(names) as lt:
             m0 = torch.cuda.Event(enable_timing=True)
             m1 = torch.cuda.Event(enable_timing=True)
@@ -799,7 +842,7 @@ def main():
     # kernels of total duration / steps — no event pairs, no gaps between launches (the event-timed sum above moves by 10 % from run to run)
     prof = profile_kernel_ms_per_step()
     if prof is not None:
-        step_stats.update(prof)
+        step_stats["from_committed_profile"] = prof       # numbers parsed from a file of an EARLIER run of this command, not measured by this run
     result = {
         "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
@@ -815,32 +858,80 @@ def main():
                    "render_glue": "csrc/fixedstep.hip (fused density head + composite)" if fused else "torch ops of NeRFRenderer.run"},
     }
 
-    # ---- roofline of the dominant kernel of the timed region
-    if ksum:
-        shapes = {"ffmlp_forward": None, "ffmlp_backward": None}
-        dom = max(ksum, key=lambda k: ksum[k]["total_ms"])
-        r = ksum[dom]
-        units = r["avg_units"] or samples_per_step
-        if dom in ("grid_encode_forward", "grid_encode_forward_counted", "grid_encode_backward"):
-            bytes_per_unit = ALGO_BYTES["grid_encode_forward" if dom.startswith("grid_encode_forward") else dom]
-        elif dom in ("ffmlp_forward", "ffmlp_inference"):
-            bytes_per_unit = 0.5 * (mlp_bytes_per_row(32, 64, 2, True) + mlp_bytes_per_row(32, 64, 3, True))
-        else:
-            bytes_per_unit = 0.5 * (mlp_bytes_per_row(32, 64, 2, True, True) + mlp_bytes_per_row(32, 64, 3, True, True))
-        op_ms = r["avg_ms"]
-        note = ("timed with events on the launch stream around the C-ABI call (all kernels of the op); traffic = HBM bytes per "
-                "launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/*_pmc_hbm.csv")
-        if dom == "grid_encode_backward" and count_share is not None:
-            # the op's count pass + scans run inside the training forward launch (k_grid_fwd_counted): charge them to this op
-            op_ms += count_share["count_share_ms"]
-            note += (f"; avg_launch_ms = scatter + reduce ({r['avg_ms']:.4f} ms) + the op's count pass and scans, which ride in the forward launch "
+    # ---- roofline of the dominant op of the step. EVERY C-ABI entry point of the step is event-timed (ks_all: LibTimer over the five extra steps
+    # above, events on the launch stream around each call); the dominant one is chosen among all of them. For the ops the KernelTimer also timed
+    # INSIDE the timed region (the public grid / MLP ops) the timed region's own average is used.
+    if ks_all:
+        ops = step_op_table()
+        step_ms_now = 1000.0 * el / args.steps
+        per_step = {k: n * avg / n_k for k, (n, avg) in ks_all.items()}
+        share_ms = count_share["count_share_ms"] if count_share is not None else 0.0
+        ranked = dict(per_step)
+        if "foc_grid_encode_backward_binned_counted" in ranked and "foc_grid_encode_forward_counted" in ranked:
+            # the backward's count pass + scans ride in the training forward launch (k_grid_fwd_counted): they are the backward's
+            ranked["foc_grid_encode_backward_binned_counted"] += share_ms
+            ranked["foc_grid_encode_forward_counted"] = max(0.0, ranked["foc_grid_encode_forward_counted"] - share_ms)
+        timed_region = {"foc_grid_encode_backward_binned_counted": "grid_encode_backward", "foc_grid_encode_backward_binned": "grid_encode_backward",
+                        "foc_grid_encode_forward_counted": "grid_encode_forward_counted", "foc_grid_encode_forward": "grid_encode_forward"}
+
+        def entry(name):
+            kernels, bound, bpu, fpu = ops.get(name, ([name], "hbm", None, None))
+            launches, avg = ks_all[name]
+            src = "LibTimer, 5 steps after the timed region"
+            kt = ksum.get(timed_region.get(name, ""))
+            if kt is not None:
+                avg, src = kt["avg_ms"], "KernelTimer, inside the timed region"
+            e = {"kernels": kernels, "launches_per_step": launches / n_k, "avg_ms": round(avg, 4), "share_of_step": round(ranked.get(name, per_step[name]) / step_ms_now, 4),
+                 "bound": bound, "timed": src}
+            units = samples_per_step
+            if bpu is not None:
+                e["algorithmic_bytes_per_unit"] = bpu
+                e["achieved_GBps"] = round(bpu * units / (avg * 1e-3) / 1e9, 1)
+                e["hbm_frac"] = round(e["achieved_GBps"] / HBM_PEAK_GBS, 4)
+            if fpu is not None:
+                e["useful_flops_per_unit"] = fpu
+                e["achieved_TFLOPs"] = round(fpu * units / (avg * 1e-3) / 1e12, 1)
+                e["mfma_frac"] = round(e["achieved_TFLOPs"] / MFMA_F16_PEAK_TFLOPS, 4)
+            return e
+        result["kernels"] = {k: entry(k) for k in sorted(ks_all, key=lambda k: -ranked[k])}
+        dom = max(ranked, key=lambda k: ranked[k])
+        kernels, bound, bpu, fpu = ops.get(dom, ([dom], "hbm", None, None))
+        d = result["kernels"][dom]
+        op_ms = d["avg_ms"]
+        note = ("chosen among ALL C-ABI entry points of the step (`kernels`); timed with events on the launch stream around the C-ABI call (all kernels of "
+                "the op); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE), profiles/*_pmc_hbm.csv")
+        if dom == "foc_grid_encode_backward_binned_counted" and count_share is not None:
+            op_ms += share_ms
+            note += (f"; avg_launch_ms = scatter + reduce ({d['avg_ms']:.4f} ms) + the op's count pass and scans, which ride in the forward launch "
                      f"(counted forward {count_share['counted_forward_ms']:.4f} ms - plain forward {count_share['plain_forward_ms']:.4f} ms, timed after the run)")
-        achieved = bytes_per_unit * units / (op_ms * 1e-3) / 1e9
-        result["roofline"] = {"kernel": f"{dom} = {'+'.join(OP_KERNELS.get(dom, [dom]))}", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom), "avg_launch_ms": op_ms,
-                              "units_per_launch": units, "algorithmic_bytes_per_unit": bytes_per_unit, "note": note}
-        result["kernels"] = {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "share_of_step": round(v["total_ms"] / (1000.0 * el), 4)}
-                             for k, v in sorted(ksum.items(), key=lambda kv: -kv[1]["total_ms"])}
+        if bound == "mfma" and fpu is not None:
+            achieved = fpu * samples_per_step / (op_ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": f"{dom} = {'+'.join(kernels)}", "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(dom, kernels=kernels), "avg_launch_ms": op_ms,
+                                  "units_per_launch": samples_per_step, "useful_flops_per_unit": fpu, "note": note}
+        else:
+            bpu = bpu if bpu is not None else 588.0
+            achieved = bpu * samples_per_step / (op_ms * 1e-3) / 1e9
+            result["roofline"] = {"kernel": f"{dom} = {'+'.join(kernels)}", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom, kernels=kernels), "avg_launch_ms": op_ms,
+                                  "units_per_launch": samples_per_step, "algorithmic_bytes_per_unit": bpu, "note": note}
+        # the MFMA side of the step: both networks' backward and forward against the dense fp16 matrix peak, on USEFUL flops
+        mf = {}
+        for label, names in (("mlp_backward", ("foc_ffmlp_backward_planar", "foc_color_head_backward")), ("mlp_forward", ("foc_ffmlp_forward_planar", "foc_color_head_forward"))):
+            have = [n for n in names if n in ks_all]
+            if not have:
+                continue
+            ms = sum(ks_all[n][1] * ks_all[n][0] / n_k for n in have)
+            fl = sum(ops[n][3] for n in have) * samples_per_step
+            mf[label] = {"entry_points": {n: result["kernels"][n]["avg_ms"] for n in have}, "ms_per_step": round(ms, 4), "useful_flops_per_step": fl,
+                         "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1), "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS,
+                         "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
+        util = pmc_mfma_utilisation(["k_mlp_bwd", "k_mlp_fwd"])
+        if util is not None:
+            mf["mfma_pipe_utilisation_from_committed_profile"] = util
+        mf["note"] = ("useful flops = 2 x 36 864 per sample backward (dX and dW products; the forward the fused backward re-evaluates is NOT counted, so the "
+                      "matrix pipe's own busy share — the PMC figure — is about 1.5 x the useful fraction), 36 864 forward; sigma 32-64-64-16, colour 32-64-64-64-16")
+        result["roofline"]["mfma"] = mf
 
     from focnerf_amd import synthetic
     rays_o, rays_d = synthetic.get_rays(poses[:1], intr, VIEW, VIEW)
@@ -907,10 +998,11 @@ def main():
             # is enqueued in microseconds). No LR scheduler inside the graph (a host-side scalar); everything else is train_step().
             try:
                 from focnerf_amd.graph import GraphedStep
-                model.train()
-                opt_g = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+                import copy
+                model_g = copy.deepcopy(model).train()      # a copy: the render legs below (and their checksums) see the model as the timed steps left it
+                opt_g = torch.optim.Adam(model_g.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
                 sc_g = torch.amp.GradScaler("cuda")
-                g_head = GraphedStep(lambda o, d, t: train_step(model, opt_g, sc_g, o, d, t, fused=fused), batches[0])
+                g_head = GraphedStep(lambda o, d, t: train_step(model_g, opt_g, sc_g, o, d, t, fused=fused), batches[0])
                 for i in range(4):
                     g_head(*batches[i % len(batches)])
                 barrier()
@@ -923,7 +1015,7 @@ def main():
                                           "ms_per_step": 1000.0 * el_g / args.steps, "steps": args.steps,
                                           "note": "the headline step (forward, backward, GradScaler, fused Adam; a fresh batch copied in per step) captured once and "
                                                   "replayed as one HIP graph: the host-independent figure beside the eager `value`"}
-                del g_head, opt_g, sc_g
+                del g_head, opt_g, sc_g, model_g
             except Exception as e:
                 result["graph_replay"] = {"error": repr(e)}
             # ---- render: full 800x800 views through the same fixed-step path, staged in 4096-ray chunks (max_ray_batch, flags default)
@@ -957,9 +1049,9 @@ def main():
             # reference evaluates the colour network only where weights > 1e-10 (nerf/renderer.py:185-187), this path evaluates it densely and
             # masks in the composite — so the time of a view must not depend on the field, and `colour_mask_fraction` says how sparse the
             # reference's mask would be here (4096 rays of view 0, weights formed in torch from the returned densities)
+            saved_scale = model.density_scale
             try:
                 from focnerf_amd import raymarching
-                saved_scale = model.density_scale
                 model.density_scale = 1.0e4
                 with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                     model.render(rays_o, rays_d, return_fields=False, **rkw)
@@ -997,6 +1089,48 @@ def main():
             relf = max_over_ranks(time.perf_counter() - t0) / max(1, args.render_views)
             result["render_with_fields"] = {"metric": "render_rays_per_sec", "value": world * VIEW * VIEW / relf, "unit": "rays/s", "s_per_view": relf,
                                             "path": "same, plus densities [1,N,512] and rgbs [1,N,512,3] of the whole view (5.2 GB) as the reference's render() returns them"}
+
+            # ---- what an UNCHANGED FOCNeRF checkout gets for a RENDER: one 800 x 800 view through the public ops only, in the sequence of the
+            # reference's run() (nerf/renderer.py:145-221 with nerf/network_ff.py:51-134: near_far_from_aabb -> torch linspace / clamp -> grid_encode ->
+            # FFMLP -> trunc_exp -> cumprod weights -> SH + cat / pad + FFMLP on the samples whose weight passes 1e-10 -> sigmoid -> torch composite),
+            # every fusion of this library's own callers off, as `dropin_ops_path` does for training
+            if fused and "dropin_ops_path" in result:
+                switches = ("FOC_FUSED_FIELD", "FOC_FUSED_HEAD", "FOC_FUSED_TAIL", "FOC_FUSED_INFER", "FOC_FUSED_OCC")
+                saved = {k: os.environ.get(k) for k in switches}
+                try:
+                    for k in switches:
+                        os.environ[k] = "0"
+                    rkd = dict(staged=True, max_ray_batch=4096, num_steps=NUM_STEPS, upsample_steps=0, perturb=False, fused=False)
+                    nv = 2
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                        model.render(*view_rays[0], **rkd)
+                        barrier()
+                        timer.records.clear()
+                        timer.enabled = True
+                        t0 = time.perf_counter()
+                        for i in range(nv):
+                            model.render(*view_rays[i % len(view_rays)], **rkd)
+                        barrier()
+                        eldr = max_over_ranks(time.perf_counter() - t0)
+                        timer.enabled = False
+                    kdr = timer.summary()
+                    result["dropin_ops_path"]["render"] = {
+                        "metric": "render_rays_per_sec", "value": world * VIEW * VIEW * nv / eldr, "unit": "rays/s", "s_per_view": eldr / nv, "views": nv,
+                        "vs_render": (world * VIEW * VIEW * nv / eldr) / result["render"]["value"],
+                        "path": "800 x 800 view through the public ops only (near_far_from_aabb, grid_encode, ffmlp x2, trunc_exp, SH encoder) in the sequence of "
+                                "the reference's run(), 4096-ray chunks, torch glue between the ops, all fusions off",
+                        "op_share_of_view": {k: {"launches_per_view": v["launches"] / nv, "avg_ms": round(v["avg_ms"], 4), "share": round(v["total_ms"] / (1000.0 * eldr), 4)}
+                                             for k, v in sorted(kdr.items(), key=lambda kv: -kv[1]["total_ms"])},
+                        "torch_glue_share": round(max(0.0, 1.0 - sum(v["total_ms"] for v in kdr.values()) / (1000.0 * eldr)), 4)}
+                except Exception as e:
+                    result["dropin_ops_path"]["render"] = {"error": repr(e)}
+                finally:
+                    timer.enabled = False
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
 
             # ---- the same two measurements on FOC's object-conditioned network (network_tcnn.py topology, 48-wide colour input)
             progress("FOC object-conditioned network legs")
@@ -1063,8 +1197,9 @@ def main():
                                                 "Adam; FOC_FUSED_OCC=0 is the chain of separate ops (march_rays_train, grid_encode, FFMLP x2, composite_rays_train)"}
             po = profile_occupancy_kernel_us_per_step()
             if po is not None:
-                result["occupancy_path"].update(po)
+                result["occupancy_path"]["from_committed_profile"] = po   # parsed from a file of an earlier run, not measured by this run
             # the same step as the chain of separate public ops (what round 3 measured as `occupancy_path`)
+            saved_occ = os.environ.get("FOC_FUSED_OCC")
             try:
                 os.environ["FOC_FUSED_OCC"] = "0"
                 for i in range(4):
@@ -1080,7 +1215,10 @@ def main():
             except Exception as e:
                 result["occupancy_path"]["op_chain"] = {"error": repr(e)}
             finally:
-                os.environ.pop("FOC_FUSED_OCC", None)
+                if saved_occ is None:
+                    os.environ.pop("FOC_FUSED_OCC", None)
+                else:
+                    os.environ["FOC_FUSED_OCC"] = saved_occ
 
             # replayed as one HIP graph (focnerf_amd.graph.GraphedStep, static shapes thanks to the sample budget): what the step costs with no
             # host in the loop (round 3's chain of ops needed 1.2 ms of Python per step for 1.05 ms of GPU work; the fused node 0.75 for 0.8)

@@ -193,9 +193,13 @@ __global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restric
 // ---------------------------------------------------------------- options (common.h FocOpt)
 #include <stdlib.h>
 #include <string.h>
-struct FocOptionRow { const char *name; int value; };
+#include <atomic>
+#include <mutex>
+// values are atomics and the table is filled from the environment exactly once (std::call_once): a second thread entering foc_opt() while the
+// first one initialises waits for it instead of reading defaults; foc_set_option from one thread is seen by launches issued afterwards
+struct FocOptionRow { const char *name; std::atomic<int> value; };
 static FocOptionRow foc_option_table[FOC_OPT_COUNT] = {
-    {"FOC_MLP_BWD_FUSED", 1}, {"FOC_GB_MERGE_MAX_RES", 480}, {"FOC_GB_FACTORED", 1}, {"FOC_GB_TAIL_SPLIT", 16}, {"FOC_GRID_FUSE_SMALL", 1},
+    {"FOC_MLP_BWD_FUSED", 1}, {"FOC_MLP_BWD_PRIV", 0}, {"FOC_GB_MERGE_MAX_RES", 480}, {"FOC_GB_FACTORED", 1}, {"FOC_GB_TAIL_SPLIT", 16}, {"FOC_GRID_FUSE_SMALL", 1},
     {"FOC_GRID_PAIRS", 1}, {"FOC_GRID_FAST", 1}, {"FOC_MARCH_SERIAL", -1}, {"FOC_MARCH_RAYS_ROW_MAX", 131072}, {"FOC_OCC_MARCH_FORM", -1},
     {"FOC_OCC_SAMPLE_MAJOR", 1}, {"FOC_OCC_FIELD_PIECE", 1 << 23},
 };
@@ -209,22 +213,22 @@ static int foc_option_parse(int which, const char *text) {
     return atoi(text);
 }
 static void foc_options_init() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    for (int i = 0; i < FOC_OPT_COUNT; i++) {               // the ONE place the library reads its environment
-        const char *e = getenv(foc_option_table[i].name);
-        if (e && e[0]) foc_option_table[i].value = foc_option_parse(i, e);
-    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < FOC_OPT_COUNT; i++) {           // the ONE place the library reads its environment
+            const char *e = getenv(foc_option_table[i].name);
+            if (e && e[0]) foc_option_table[i].value.store(foc_option_parse(i, e), std::memory_order_relaxed);
+        }
+    });
 }
-int foc_opt(FocOpt which) { foc_options_init(); return foc_option_table[which].value; }
+int foc_opt(FocOpt which) { foc_options_init(); return foc_option_table[which].value.load(std::memory_order_relaxed); }
 
 extern "C" {
 
 int foc_set_option(const char *name, int value) {
     foc_options_init();
     for (int i = 0; i < FOC_OPT_COUNT; i++)
-        if (name && strcmp(name, foc_option_table[i].name) == 0) { foc_option_table[i].value = value; return FOC_OK; }
+        if (name && strcmp(name, foc_option_table[i].name) == 0) { foc_option_table[i].value.store(value, std::memory_order_relaxed); return FOC_OK; }
     foc_set_error("set_option: unknown option '%s'", name ? name : "(null)");
     return FOC_E_INVALID;
 }
@@ -232,7 +236,7 @@ int foc_set_option(const char *name, int value) {
 int foc_get_option(const char *name, int *value) {
     foc_options_init();
     for (int i = 0; i < FOC_OPT_COUNT; i++)
-        if (name && value && strcmp(name, foc_option_table[i].name) == 0) { *value = foc_option_table[i].value; return FOC_OK; }
+        if (name && value && strcmp(name, foc_option_table[i].name) == 0) { *value = foc_option_table[i].value.load(std::memory_order_relaxed); return FOC_OK; }
     foc_set_error("get_option: unknown option '%s'", name ? name : "(null)");
     return FOC_E_INVALID;
 }

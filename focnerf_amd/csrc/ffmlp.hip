@@ -26,278 +26,7 @@
 #include "activations.h"
 #include <stdlib.h>
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef short s4 __attribute__((__vector_size__(4 * sizeof(short))));
-typedef __attribute__((address_space(3))) s4 lds_s4;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-#define MLP_BLOCK 256
-#define MLP_WAVES 4
-// k_mlp_bwd_fused hands its weight-gradient tiles over in per-workgroup slots: [stage][wave][16 registers][64 lanes] fp32
-#define MLP_DW_SLOT_STAGE 4096u        // floats per stage and slot (4 wave tiles of 32 x 32)
-#define MLP_DW_MAX_SLOTS 1024u         // cap on the workgroups of a launch (2 per CU)
-#ifndef FOC_MLP_SETPRIO
-#define FOC_MLP_SETPRIO 1              // issue priority of the MFMA sections of k_mlp_bwd_fused (0 = none: A/B builds, tools/build_variant.sh)
-#endif
-
-// neuron (row) index inside a 32-row accumulator tile held in register `reg` by lane-half `h`
-// (C/D map of v_mfma_f32_32x32x*: row = (reg&3) + 8*(reg>>2) + 4*h)
-__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-// k index carried by element j of lane-half h when an accumulator tile is reused as a B operand
-__device__ __forceinline__ int chain_k(int kc, int h, int j) { return 16 * kc + 8 * (j >> 2) + 4 * h + (j & 3); }
-
-__device__ __forceinline__ f16v mfma16(const h8 a, const h8 b, const f16v c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ h8 ld_frag(const _Float16 *lds, uint32_t frag, uint32_t lane) {
-    return *reinterpret_cast<const h8 *>(lds + (size_t)frag * 512 + lane * 8);
-}
-
-// Build the B fragment of k-chunk (2*mt_prev + s) from accumulator tile `acc` (optionally ReLU'd).
-template <bool RELU>
-__device__ __forceinline__ h8 acc_to_frag(const f16v &acc, int s) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    h8 r;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        h2 p = {(_Float16)acc[8 * s + j], (_Float16)acc[8 * s + j + 1]};       // one v_cvt_pk_f16_f32 (round to nearest even)
-        if (RELU) p = __builtin_elementwise_max(p, h2{(_Float16)0, (_Float16)0});  // one v_pk_max_f16 for the pair: max(x, 0), NaN -> 0 like `x > 0 ? x : 0`
-        r[j] = p[0]; r[j + 1] = p[1];
-    }
-    return r;
-}
-
-// The same with any of the reference's hidden activations (activations.h): the sum rounded to half, then the function on it.
-__device__ __forceinline__ h8 acc_to_frag_act(const f16v &acc, int s, int act) {
-    h8 r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = foc_act_forward((_Float16)acc[8 * s + j], act);
-    return r;
-}
-
-// ReLU gate on a chained fragment: d where a > 0, else +0. `a` is a post-ReLU activation (never negative, never -0), so "a > 0" is
-// "its 16 bits are not zero": min(bits, 1) is a 0/1 factor per half and a packed 16-bit integer multiply applies it to d's bits —
-// 2 packed instructions per 2 values instead of a compare and a select per value.
-__device__ __forceinline__ h8 relu_gate(const h8 d, const h8 a) {
-    const u32x4 db = __builtin_bit_cast(u32x4, d), ab = __builtin_bit_cast(u32x4, a);
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t m, o;
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(ab[i]), "v"(0x00010001u));
-        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(db[i]), "v"(m));
-        r[i] = o;
-    }
-    return __builtin_bit_cast(h8, r);
-}
-
-// Planar network inputs: [in_dim/2][B] dwords (half2), i.e. the hash-grid encoder's native [L, B, C=2] output (gridencoder.cu:218)
-// read without the permute to [B, L*C]. Element (row, 16kc + 8h + 2j + {0,1}) lives in plane 8kc + 4h + j; for one j the 32 lanes
-// of a lane-half read 128 contiguous bytes.
-__device__ __forceinline__ h8 ld_planar8(const _Float16 *__restrict__ base, uint64_t B, uint64_t row, uint32_t kc, int h) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(base) + (uint64_t)(8 * kc + 4 * h) * B + row;
-    const u32x4 v = {p[0], p[B], p[2 * B], p[3 * B]};
-    return __builtin_bit_cast(h8, v);
-}
-
-// Colour-network inputs taken from where they already are (input mode 2, in_dim = 32): the row [SH16(ray) | h[1:16] | 0] the
-// reference concatenates per sample (network_ff.py:104-108) is never materialised. k-chunk 0 = the ray's 16 SH values (one 32-byte
-// row per ray, shared by its samples); k-chunk 1 = columns 1..16 of the sigma network's output row h [B,16], i.e. the row shifted by
-// one half with a zero shifted in at the end — every value sits at the k position it has in the concatenated row, so the
-// products and their summation order are those of the materialised form.
-struct MlpHead {
-    const _Float16 *ray_sh;        // [B / samples_per_ray, 16]
-    const _Float16 *grad_h0;       // backward: [B], gradient of h[:,0] (the density path), merged into grad_h column 0
-    uint32_t samples_per_ray;
-    uint32_t out_width;            // 16: [B,16] outputs / output gradients; 4: only columns 0..3 exist in memory ([B,4]: rgb logits + 1 pad)
-    // FOC's object-conditioned colour network (nerf/network_tcnn.py:611-640): the input row is [SH16 | h[1:16] | obj 16 | 0] = 48 wide, and
-    // the encoded object feature `obj` [16] is ONE vector for every sample of the launch. W0[:, 31:47] . obj is therefore a constant per
-    // neuron: it enters as the initial value of the layer-0 accumulators (obj_bias in LDS) and the k-chunks stay the two of the 32-wide
-    // form. Backward: column 31 of the layer-0 input tile is set to 1, so the weight-gradient MFMAs deliver the column sum of delta_0 in
-    // dW0[:, 31]; dW0[:, 31:47] = colsum (x) obj and grad_obj = W0[:, 31:47]^T colsum follow in the finalize kernel. W0 rows are 48 wide.
-    const _Float16 *obj;           // [16] or null
-};
-#define HEAD_OBJ_LD 48u
-__device__ __forceinline__ uint32_t head_ld0(const MlpHead &hd) { return hd.obj ? HEAD_OBJ_LD : 32u; }
-
-// obj_bias[mt][h][reg] (fp32, accumulator-register order of acc_row) = sum_j W0[n][31 + j] * obj[j], n = 32 mt + acc_row(reg, h):
-// 64 threads, sequential fmaf in j order. `W0` has HEAD_OBJ_LD-wide rows.
-__device__ __forceinline__ void stage_obj_bias(const _Float16 *__restrict__ W0, const _Float16 *__restrict__ obj, float *bias, uint32_t hidden) {
-    if (threadIdx.x < hidden) {
-        const uint32_t n = threadIdx.x, r = n & 31u, mt = n >> 5;
-        const uint32_t h = (r >> 2) & 1u, reg = (r & 3u) + 4u * (r >> 3);
-        float a = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; j++) a = fmaf((float)W0[(size_t)n * HEAD_OBJ_LD + 31 + j], (float)obj[j], a);
-        bias[(mt * 2 + h) * 16 + reg] = a;
-    }
-}
-__device__ __forceinline__ f16v ld_obj_bias(const float *bias, int mt, int h) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 *p = reinterpret_cast<const f4 *>(bias + (mt * 2 + h) * 16);
-    const f4 a = p[0], b = p[1], c = p[2], d = p[3];
-    return f16v{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-}
-// the loads and the shift are separate so that a prefetching caller can keep the raw dwords in flight
-__device__ __forceinline__ void ld_head_raw(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(hrows + row * 16) + 4 * h;
-    v = *reinterpret_cast<const u32x4 *>(p);
-    nxt = h == 0 ? p[4] : 0u;
-}
-// prefetching form: the dword after the lane's 16 bytes is loaded by EVERY lane (upper lane-half: a dword of its own 16 bytes, dropped by
-// the caller when it shifts) so that the load sits in no exec-masked branch
-__device__ __forceinline__ void ld_head_raw_all(const _Float16 *__restrict__ hrows, uint64_t row, int h, u32x4 &v, uint32_t &nxt) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(hrows + row * 16) + 4 * h;
-    v = *reinterpret_cast<const u32x4 *>(p);
-    nxt = p[h == 0 ? 4 : 3];
-}
-__device__ __forceinline__ h8 head_shift(const u32x4 v, uint32_t nxt) {
-    const u32x4 r = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16), __builtin_amdgcn_alignbit(v.w, v.z, 16),
-                     __builtin_amdgcn_alignbit(nxt, v.w, 16)};
-    return __builtin_bit_cast(h8, r);
-}
-__device__ __forceinline__ h8 ld_head8(const _Float16 *__restrict__ hrows, const MlpHead &hd, uint64_t row, uint32_t kc, int h) {
-    if (kc == 0) return *reinterpret_cast<const h8 *>(hd.ray_sh + (uint64_t)((uint32_t)row / hd.samples_per_ray) * 16 + 8 * h);
-    u32x4 v; uint32_t nxt;
-    ld_head_raw_all(hrows, row, h, v, nxt);
-    return head_shift(v, h == 0 ? nxt : 0u);
-}
-
-// ---------------------------------------------------------------- weight staging
-// Forward image. Fragment f holds, for lane (r = lane&31, h = lane>>5), the 8 halfs
-//   layer 0      : W0[32*mt + r][16*kc + 8*h + j]                       (natural k: B comes from global inputs)
-//   hidden l>=1  : Wl[32*mt + r][chain_k(kc, h, j)]
-//   output layer : Wout[r][chain_k(kc, h, j)]  for r < 16, else 0
-// Fragment order: layer0 [mt][kc0] | hidden layers [l][mt][kc] | out [kc].
-// ld0 = 0: W0 rows are in_dim wide and all in_dim / 16 k-chunks are staged; ld0 > in_dim (head with an object feature): rows are ld0 wide,
-// the first in_dim / 16 chunks are staged
-template <int HIDDEN>
-__device__ void stage_weights_fwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_out = true, uint32_t ld0 = 0) {
-    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
-    const uint32_t KS0 = in_dim / 16;
-    if (!ld0) ld0 = in_dim;
-    const uint32_t n0 = MT * KS0, nh = (num_layers - 1) * MT * KC, total = n0 + nh + (with_out ? KC : 0);
-    const _Float16 *Wh = W + (size_t)HIDDEN * ld0;
-    const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
-    for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
-        const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-        h8 v;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (_Float16)0;
-        if (f < n0) {
-            const uint32_t mt = f / KS0, kc = f % KS0, row = 32 * mt + r;
-            if (row < HIDDEN) v = *reinterpret_cast<const h8 *>(W + (size_t)row * ld0 + 16 * kc + 8 * h);
-        } else if (f < n0 + nh) {
-            const uint32_t g = f - n0, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, row = 32 * mt + r;
-            if (row < HIDDEN) {
-                const _Float16 *p = Wh + (size_t)l * HIDDEN * HIDDEN + (size_t)row * HIDDEN + 16 * kc + 4 * h;
-                const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-            }
-        } else {
-            const uint32_t kc = f - n0 - nh;
-            if (r < 16) {
-                const _Float16 *p = Wo + (size_t)r * HIDDEN + 16 * kc + 4 * h;
-                const h4 lo = *reinterpret_cast<const h4 *>(p), hi = *reinterpret_cast<const h4 *>(p + 8);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[j] = lo[j]; v[4 + j] = hi[j]; }
-            }
-        }
-        *reinterpret_cast<h8 *>(lds + (size_t)f * 512 + lane * 8) = v;
-    }
-}
-
-// Backward image (transposed weights: rows = INPUT neuron i of the layer, k = OUTPUT neuron o).
-//   out layer   [mt]        : Wout[8*h + j][32*mt + r]                (k = o natural, K = 16; B = grad from global)
-//   hidden l    [l][mt][kc] : Wl[chain_k(kc,h,j)][32*mt + r]          (l = 0 .. num_layers-2, matrix l maps fwd[l] -> fwd[l+1])
-//   dX          [mt0][kc]   : W0[chain_k(kc,h,j)][32*mt0 + r]  (i < in_dim, else 0)
-// Fragment order: out [mt] | hidden [l][mt][kc] | dX [mt0][kc].
-template <int HIDDEN>
-__device__ void stage_weights_bwd(const _Float16 *__restrict__ W, _Float16 *lds, uint32_t in_dim, uint32_t num_layers, bool with_dx, bool head = false,
-                                  uint32_t ld0 = 0) {
-    constexpr int MT = (HIDDEN + 31) / 32, KC = HIDDEN / 16;
-    const uint32_t MT0 = (in_dim + 31) / 32;
-    if (!ld0) ld0 = in_dim;
-    const uint32_t no = MT, nh = (num_layers - 1) * MT * KC, nx = with_dx ? MT0 * KC : 0, total = no + nh + nx;
-    const _Float16 *Wh = W + (size_t)HIDDEN * ld0;
-    const _Float16 *Wo = Wh + (size_t)(num_layers - 1) * HIDDEN * HIDDEN;
-    for (uint32_t idx = threadIdx.x; idx < total * 64; idx += MLP_BLOCK) {
-        const uint32_t f = idx >> 6, lane = idx & 63, r = lane & 31, h = lane >> 5;
-        h8 v;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (_Float16)0;
-        if (f < no) {
-            const uint32_t i = 32 * f + r;
-            if (i < HIDDEN) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = Wo[(size_t)(8 * h + j) * HIDDEN + i];
-            }
-        } else if (f < no + nh) {
-            const uint32_t g = f - no, l = g / (MT * KC), mt = (g / KC) % MT, kc = g % KC, i = 32 * mt + r;
-            if (i < HIDDEN) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = Wh[(size_t)l * HIDDEN * HIDDEN + (size_t)chain_k(kc, h, j) * HIDDEN + i];
-            }
-        } else {
-            const uint32_t g = f - no - nh, mt0 = g / KC, kc = g % KC, i = 32 * mt0 + r;
-            if (head) {
-                // input mode 2: result row 16 + k is the gradient of h column k = input column 15 + k (k = 1..15); rows 0..16 are not used
-                if (i >= 17 && i < 32) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * ld0 + (i - 1)];
-                }
-            } else if (i < in_dim) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = W[(size_t)chain_k(kc, h, j) * ld0 + i];
-            }
-        }
-        *reinterpret_cast<h8 *>(lds + (size_t)f * 512 + lane * 8) = v;
-    }
-}
-
-// Store one accumulator tile (32 neurons x 32 samples) as fp16 into a row-major [B, ld] buffer:
-// lane (c, h) owns sample `row0 + c` and, per register quad q, the 4 consecutive neurons
-// col0 + 8q + 4h .. +3  -> one 8-byte store per quad.
-template <bool RELU>
-__device__ __forceinline__ void store_tile(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint64_t nrows, uint32_t col0, uint32_t ncols,
-                                           const f16v &acc, int h) {
-    if (row >= nrows) return;          // ragged last tile: rows past B are computed on clamped inputs and dropped
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t col = col0 + 8 * q + 4 * h;
-        if (col < ncols) {
-            h4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                _Float16 x = (_Float16)acc[4 * q + e];
-                if (RELU) x = x > (_Float16)0 ? x : (_Float16)0;
-                v[e] = x;
-            }
-            *reinterpret_cast<h4 *>(dst + row * ld + col) = v;
-        }
-    }
-}
-
-// store_tile with a general activation on the half-rounded sums
-__device__ __forceinline__ void store_tile_act(_Float16 *__restrict__ dst, uint32_t ld, uint64_t row, uint64_t nrows, uint32_t col0, uint32_t ncols,
-                                               const f16v &acc, int h, int act) {
-    if (row >= nrows) return;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t col = col0 + 8 * q + 4 * h;
-        if (col < ncols) {
-            h4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = foc_act_forward((_Float16)acc[4 * q + e], act);
-            *reinterpret_cast<h4 *>(dst + row * ld + col) = v;
-        }
-    }
-}
+#include "mlp_common.h"
 
 // ---------------------------------------------------------------- M1: fused forward / inference
 // GEN: a hidden activation other than ReLU / None (exponential, sine, sigmoid, squareplus, softplus — ffmlp/src/utils.h:424-470; no FOC
@@ -583,13 +312,15 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_bwd(const _Float16 *__restric
 // 32x32 output tiles and reads its MFMA operands transposed out of LDS; partial sums go to the fp32
 // workspace with float atomics shaped as whole 128-byte row segments.
 #define DW_CHUNK 64
-template <int HIDDEN>
+// AW: widest layer input the LDS tile holds — 128 (hidden <= 128, inputs up to 128), 256 (hidden 256, or the reference's dynamic input layer with
+// up to 256 inputs at a narrower hidden width, ffmlp.cu:151-239: any 16 m that fits shared memory)
+template <int HIDDEN, int AW = (HIDDEN > 128 ? HIDDEN : 128)>
 __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                       const _Float16 *__restrict__ fwd_buf, const _Float16 *__restrict__ bwd_buf,
                                                       float *__restrict__ ws, uint32_t B, uint32_t in_dim, uint32_t num_layers) {
     constexpr int LDP = 8;   // row padding (halfs) to spread the strided 2-byte reads over banks
     __shared__ __attribute__((aligned(16))) _Float16 sD[DW_CHUNK][(HIDDEN < 32 ? 32 : HIDDEN) + LDP];   // >= 32 columns: transposed reads span a whole 32-row tile
-    __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][(HIDDEN > 128 ? HIDDEN : 128) + LDP];
+    __shared__ __attribute__((aligned(16))) _Float16 sA[DW_CHUNK][AW + LDP];
 
     const uint32_t j = blockIdx.y;
     const _Float16 *Dp; const _Float16 *Ap; uint32_t OUT, IN; uint64_t ws_off;
@@ -601,7 +332,9 @@ __global__ void __launch_bounds__(MLP_BLOCK) k_mlp_dw(const _Float16 *__restrict
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const uint32_t MTo = (OUT + 31) / 32, NTi = (IN + 31) / 32, n_out_tiles = MTo * NTi;
-    // up to 4 tiles per wave and workgroup: 16 tiles cover OUT, IN <= 128; hidden 256 (64 tiles) deals them over blockIdx.z
+    // up to 4 tiles per wave and workgroup: 16 tiles cover OUT, IN <= 128; hidden 256 (64 tiles) and wide input layers (up to 32) deal them
+    // over blockIdx.z — a z slice with no tile of this layer has nothing to stage
+    if (16 * blockIdx.z >= n_out_tiles) return;
     f16v acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -734,6 +467,16 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
     _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
+    // Bank swizzle of the tiles (re-evaluating form): the chained-layout writes below are 32 rows x 8 bytes at a row stride of 20 / 28 / 36 dwords, and
+    // 16 such strides are a multiple of the 64 banks — rows r and r + 16 met in one bank (SQ_LDS_BANK_CONFLICT 26 % of the LDS cycles, round 4). A
+    // row's 8-byte granule g therefore lives at g ^ ((row >> 4) & 1): the writers flip their lane-half term, the transposed readers (whose four rows
+    // of a k step share row >> 4) flip bit 0 of their column group. The 16-wide output-gradient tile of stage 0 (16-byte rows) stays as it is.
+#ifdef FOC_TIMING_NO_SWZ
+    constexpr bool SWZ = false;                          // A/B build (tools/build_variant.sh)
+#else
+    constexpr bool SWZ = RECOMP;
+#endif
+    const int swc = SWZ ? ((c >> 4) & 1) : 0, hs = h ^ swc;
 
     f16v dwacc[NL + 1];
 #pragma unroll
@@ -920,7 +663,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                             if (col < HIDDEN) {
                                 const h8 f = bf[(2 * mt + (q >> 1)) < KC ? (2 * mt + (q >> 1)) : 0][nb];
                                 const h4 v = (q & 1) ? h4{f[4], f[5], f[6], f[7]} : h4{f[0], f[1], f[2], f[3]};
-                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + col) = v;
+#ifndef FOC_TIMING_NO_TILES
+                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + 32 * mt + 8 * q + 4 * hs) = v;
+#endif
                             }
                         }
                         if (bwd_buf) store_tile<false>(bwd_buf + (uint64_t)(s - 1) * B * HIDDEN, HIDDEN, row0 + nb * 32 + c, B, 32 * mt, HIDDEN, acc[mt][nb], h);
@@ -958,9 +703,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
                             const h8 v = fa[NL - 1 - s][kc][nb];
-                            _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 4 * h;
+                            _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 4 * hs;
+#ifndef FOC_TIMING_NO_TILES
                             *reinterpret_cast<h4 *>(dst) = h4{v[0], v[1], v[2], v[3]};
                             *reinterpret_cast<h4 *>(dst + 8) = h4{v[4], v[5], v[6], v[7]};
+#endif
                         }
                 } else {
 #pragma unroll
@@ -971,7 +718,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                                 h8 v = x_cur[kc][nb];
                                 // object feature: column 31 of the input tile (a zero of the shifted h row) becomes 1, so that dW0[:, 31] = sum_b delta_0
                                 if constexpr (HEAD) { if (kc == 1 && has_obj && h == 1) v[7] = (_Float16)1.0f; }
-                                *reinterpret_cast<h8 *>(myA + (nb * 32 + c) * WA + 16 * kc + 8 * h) = v;
+                                _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 8 * h;      // the row's two granules, swapped for rows 16..31
+                                *reinterpret_cast<h4 *>(dst + 4 * swc) = h4{v[0], v[1], v[2], v[3]};
+                                *reinterpret_cast<h4 *>(dst + 4 * (1 - swc)) = h4{v[4], v[5], v[6], v[7]};
                             }
                 }
             } else {
@@ -983,7 +732,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                     *reinterpret_cast<h8 *>(myA + rr * WA + cc) = v;
                 }
             }
+#ifndef FOC_TIMING_NO_BARRIER
             foc_lds_barrier();     // LDS tiles only: the next group's prefetched rows stay in flight, grad_inputs stores are not waited for
+#endif
             // ---- input gradients (last stage) BEFORE this stage's weight-gradient MFMAs: they need the delta fragments in registers only, and the
             // stores then have the whole dW section to be acknowledged — the wait for the prefetched rows at the top of the next group is a
             // vmcnt(0) (stores behind per-lane guards cannot be counted), which used to sit right behind these stores
@@ -1038,6 +789,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                 // every wave owns an accumulator for every stage anyway, and the flush adds them up
                 const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi;
                 const uint32_t ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+#ifdef FOC_TIMING_NO_DW
+                if (B == 0xFFFFFFFFu)                      // timing build: the weight-gradient section never runs
+#endif
                 if (wave < ntile * ksplit) {
                     // The MFMA sections (weight gradients, then the delta chain) run at raised issue priority: the other wave on this SIMD belongs to
                     // the other workgroup and is somewhere else in its group — when both can issue, the one feeding the matrix pipe goes first and
@@ -1061,10 +815,11 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                             // (stride 36 dwords: bank offsets 0, 36, 8, 44) overlapped pairwise: a 2-way conflict on half of these reads, the
                             // bulk of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE, LDS 48 % busy).
                             const int k0 = 16 * ks + 4 * q + h;
-                            const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * p));
-                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 2) * WD + 32 * mt + cg + 4 * p));
-                            const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * p));
-                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 2) * WA + 32 * nt + cg + 4 * p));
+                            const int pa = SWZ ? (p ^ (ks & 1)) : p, pd = (SWZ && s > 0) ? pa : p;      // swizzled column group (all four rows share row >> 4 = ks)
+                            const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * pd));
+                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 2) * WD + 32 * mt + cg + 4 * pd));
+                            const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * pa));
+                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 2) * WA + 32 * nt + cg + 4 * pa));
                             const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
                             const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
                             u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
@@ -1124,7 +879,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                         }
             }
             __builtin_amdgcn_s_setprio(0);
+#ifndef FOC_TIMING_NO_BARRIER
             foc_lds_barrier();     // every wave is done reading sD / sA of this stage
+#endif
         }
     }
     // ---- flush the weight-gradient tiles: every workgroup writes ITS partial tiles to a slot of its own with plain coalesced stores
@@ -1151,12 +908,13 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 // partial sums meet in LDS and are added in wave order: the result does not depend on timing (the atomic flush's did).
 template <int HIDDEN>
 __global__ void __launch_bounds__(1024) k_mlp_dw_reduce(const float *__restrict__ slots, uint32_t n_slots, uint32_t NL, uint32_t in_dim, uint32_t ld0,
-                                                        _Float16 *__restrict__ gw, float *__restrict__ wsb) {
+                                                        _Float16 *__restrict__ gw, float *__restrict__ wsb, uint32_t nosplit) {
     __shared__ float part[16][64];
     const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x / 64, w = (blockIdx.x / 16) % 4, reg = blockIdx.x % 16;       // stage, wave tile, accumulator register
     const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN, IN = s < NL ? (uint32_t)HIDDEN : in_dim;
-    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4) ? 2u : 1u;
+    // nosplit: slots of k_mlp_bwd_priv — one tile per (mt, nt), no second batch half
+    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4 && !nosplit) ? 2u : 1u;
     if (w >= ntile) return;                               // the second batch half of a tile (w >= ntile) is added by the tile's workgroup
     const uint32_t mt = w / NTi, nt = w % NTi, h = lane >> 5;
     const uint32_t o = 32 * mt + (uint32_t)acc_row((int)reg, (int)h), i = 32 * nt + (lane & 31);
@@ -1494,6 +1252,9 @@ static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
 // hidden_dim 256 (ffmlp_wide.hip): layer-by-layer kernels with one matrix resident in LDS
 int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act, void *buffer,
                      void *outputs, hipStream_t st);
+// wave-private weight-gradient tiles (ffmlp_bwd_priv.hip)
+int mlp_bwd_priv_launch(int num_layers, int imode, int nb, const void *grad, const void *inputs, const void *weights, uint32_t B, void *grad_inputs,
+                        float *slots, uint32_t max_grid, const MlpHead *head, hipStream_t st, uint32_t *grid_out);
 int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act,
                                   void *bwd_buf, void *grad_inputs, hipStream_t st);
 
@@ -1501,8 +1262,9 @@ static int mlp_check(const char *who, uint32_t B, uint32_t input_dim, uint32_t o
                      uint32_t activation, uint32_t output_activation) {
     FOC_REQUIRE(hidden_dim == 16 || hidden_dim == 32 || hidden_dim == 64 || hidden_dim == 128 || hidden_dim == 256, FOC_E_INVALID,
                 "%s: hidden_dim should in [16, 32, 64, 128, 256] (got %u)", who, hidden_dim);                 // ffmlp.cu:658
-    FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= (hidden_dim == 256 ? 256u : 128u), FOC_E_INVALID,
-                "%s: input_dim must be a multiple of 16 up to %u (got %u)", who, hidden_dim == 256 ? 256u : 128u, input_dim);
+    // ffmlp.cu:151-239: the reference's input layer takes any 16 m that fits shared memory; here up to 256 (the weight images must fit the 160 KiB LDS:
+    // checked per launch)
+    FOC_REQUIRE(input_dim > 0 && input_dim % 16 == 0 && input_dim <= 256u, FOC_E_INVALID, "%s: input_dim must be a multiple of 16 up to 256 (got %u)", who, input_dim);
     FOC_REQUIRE(output_dim <= 16, FOC_E_INVALID, "%s: output_dim must be <= 16 (got %u)", who, output_dim);
     FOC_REQUIRE(num_layers >= 2 && num_layers <= 16, FOC_E_INVALID, "%s: num_layers must be in [2,16] (got %u)", who, num_layers);
     FOC_REQUIRE(activation <= 6, FOC_E_INVALID, "%s: hidden activation must be one of relu(0) exponential(1) sine(2) sigmoid(3) squareplus(4) softplus(5) none(6) (got %u)", who, activation);
@@ -1581,6 +1343,11 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     const bool has_obj = head && head->obj;
     const size_t lds = lds_w + (size_t)4 * RW * (WD + WA) * sizeof(_Float16) + (recomp ? (size_t)(MT * (in_dim / 16) + (NL - 1) * MT * KC) * 1024 : 0) + (has_obj ? 256 : 0);
     FOC_REQUIRE(lds <= 160 * 1024, FOC_E_INVALID, "ffmlp_backward: fused kernel needs %zu B of LDS", lds);
+#ifdef FOC_TIMING_ONE_WG
+    const size_t lds_launch = lds < 84 * 1024 ? 84 * 1024 : lds;      // timing build: one workgroup (one wave per SIMD) per CU
+#else
+    const size_t lds_launch = lds;
+#endif
     // the re-evaluating forms exist twice: ReLU as a compile-time fact (what every NeRF network uses) and with the runtime flag
     auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
                                  : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, false>))
@@ -1590,19 +1357,30 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
                                                : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>);
     }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds_launch > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
     const uint32_t n_w = HIDDEN * ((has_obj ? HEAD_OBJ_LD : in_dim) + HIDDEN * (NL - 1) + 16);
     uint32_t grid = foc_div_up(B, 4 * RW);
     const uint32_t cap = min(mlp_num_cus() * 2, MLP_DW_MAX_SLOTS);
     if (grid > cap) grid = cap;
     // workspace: [fp32 blob image (object-conditioned head only)] [one slot of (NL + 1) x 4096 floats per workgroup] — no zero fill, no atomics
     float *slots = ws + mlp_dw_blob_floats(has_obj ? HEAD_OBJ_LD : in_dim, HIDDEN, NL);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, slots, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
-                       head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
-    FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
+    // the shapes of the NeRF networks (hidden 64, 32 inputs, 2 or 3 hidden layers, ReLU, re-evaluated activations, no stored gradients) take the
+    // form with wave-private weight-gradient tiles (ffmlp_bwd_priv.hip): one workgroup per CU, no barrier in the batch loop
+    const int priv = foc_opt(FOC_OPT_MLP_BWD_PRIV);
+    uint32_t nosplit = 0;
+    if (HIDDEN == 64 && NL <= 3 && in_dim == 32 && recomp && relu && !bwd_buf && priv > 0) {
+        const int imode = head ? (head->out_width == 4u ? 3 : 2) : (planar ? 1 : 0);
+        const int rc = mlp_bwd_priv_launch(NL, imode, priv >= 2 ? 2 : 1, grad, inputs, weights, B, grad_inputs, slots, min(mlp_num_cus(), MLP_DW_MAX_SLOTS), head, st, &grid);
+        if (rc) return rc;
+        nosplit = 1;
+    } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds_launch, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
+                           (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, slots, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
+                           head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
+        FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
+    }
     hipLaunchKernelGGL((k_mlp_dw_reduce<HIDDEN>), dim3((NL + 1) * 64), dim3(1024), 0, st, (const float *)slots, grid, (uint32_t)NL, in_dim,
-                       has_obj ? (uint32_t)HEAD_OBJ_LD : in_dim, (_Float16 *)grad_weights, has_obj ? ws : (float *)nullptr);
+                       has_obj ? (uint32_t)HEAD_OBJ_LD : in_dim, (_Float16 *)grad_weights, has_obj ? ws : (float *)nullptr, nosplit);
     FOC_CHECK_LAUNCH("ffmlp_backward(reduce)");
     if (has_obj) {
         hipLaunchKernelGGL(k_mlp_dw_finalize_obj, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w, (uint32_t)HIDDEN,
@@ -1620,11 +1398,14 @@ static int mlp_dw_launch(const void *grad, const void *inputs, const void *fwd_b
     if (foc_zero_async(ws, (size_t)n_w * sizeof(float), st) != hipSuccess) { foc_set_error("ffmlp_backward: memset of workspace failed"); return FOC_E_LAUNCH; }
     uint32_t gx = foc_div_up(B, DW_CHUNK);
     const int wgs_per_cu = 8;                    // split-K workgroups per CU over all layers
-    constexpr uint32_t GZ = HIDDEN > 128 ? (uint32_t)((HIDDEN / 32) * (HIDDEN / 32) + 15) / 16 : 1u;      // 16 output tiles per workgroup
+    // 16 output tiles per workgroup: hidden x hidden, or hidden x in_dim for an input layer wider than the hidden layers
+    const uint32_t tiles = ((HIDDEN + 31) / 32) * ((max((uint32_t)HIDDEN, in_dim) + 31) / 32), GZ = (tiles + 15) / 16;
     const uint32_t capx = foc_div_up(mlp_num_cus() * (uint32_t)wgs_per_cu, (num_layers + 1) * GZ);
     if (gx > capx) gx = capx;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_mlp_dw<HIDDEN>), dim3(gx, num_layers + 1, GZ), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
+    auto kern = k_mlp_dw<HIDDEN>;
+    if constexpr (HIDDEN <= 128) { if (in_dim > 128) kern = k_mlp_dw<HIDDEN, 256>; }
+    hipLaunchKernelGGL(kern, dim3(gx, num_layers + 1, GZ), dim3(MLP_BLOCK), 0, st, (const _Float16 *)grad, (const _Float16 *)inputs,
                        (const _Float16 *)fwd_buf, (const _Float16 *)bwd_buf, ws, B, in_dim, num_layers);
     FOC_CHECK_LAUNCH("ffmlp_backward(weights)");
     hipLaunchKernelGGL(k_mlp_dw_finalize, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w);

@@ -43,7 +43,8 @@ def _run_forward(x, W, I, Hd, nl, act, train):
 
 
 SHAPES = [(32, 64, 2), (32, 64, 3), (16, 16, 2), (48, 32, 4), (64, 128, 2), (128, 128, 3), (16, 64, 5),
-          (32, 256, 2), (256, 256, 3), (48, 256, 4)]          # hidden 256 (ffmlp.cu:652-658): csrc/ffmlp_wide.hip
+          (32, 256, 2), (256, 256, 3), (48, 256, 4),          # hidden 256 (ffmlp.cu:652-658): csrc/ffmlp_wide.hip
+          (192, 64, 2), (256, 128, 2), (144, 32, 3)]          # input layers wider than 128 at hidden <= 128 (the reference's dynamic input layer, ffmlp.cu:151-239)
 
 
 @pytest.mark.parametrize("I,Hd,nl", SHAPES)
@@ -115,7 +116,7 @@ def test_backward_exact_on_integer_data(I, Hd, nl, act):
     assert torch.equal(gw, gw2)
 
 
-@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (64, 128, 2), (32, 256, 3)])
+@pytest.mark.parametrize("I,Hd,nl", [(32, 64, 2), (32, 64, 3), (48, 32, 4), (64, 128, 2), (32, 256, 3), (192, 64, 2), (256, 128, 2)])
 def test_backward_random(I, Hd, nl):
     be = _be()
     rng = np.random.default_rng(99 + I + Hd + nl)
@@ -306,6 +307,36 @@ def test_hidden_256_module_trains_and_infers():
     xh, w = x.detach().half(), net.weights.detach().half()
     with pytest.raises(RuntimeError, match="inference_buffer"):
         be.ffmlp_inference(xh, w, 333, 32, 16, 256, 2, 0, 6, None, torch.empty(333, 16, dtype=torch.float16, device="cuda"))
+
+
+@pytest.mark.parametrize("I,Hd", [(192, 64), (256, 128)])
+def test_wide_input_module_trains_and_infers(I, Hd):
+    """FFMLP with an input layer wider than 128 at hidden <= 128 (ffmlp.cu:151-239 takes any 16 m that fits shared memory; mlp_check refused it until
+    round 5): forward against the oracle, autograd through the stored-activation backward (split-K weight gradients over 24 / 32 input tiles),
+    inference equal to the training forward, ragged batch; 272 inputs are still refused with the library's message."""
+    from focnerf_amd.ffmlp import FFMLP
+    net = FFMLP(I, 3, Hd, 2).cuda()
+    x = torch.randn(777, I, device="cuda", requires_grad=True)
+    net.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(x)
+    ref = oracle.ffmlp_forward(to_np(x.detach().half()), to_np(net.weights.detach().half()), I, Hd, 2, 0, training=False)
+    assert_half_close(to_np(y), ref[:, :3], ulps=8, atol=4e-3, what="wide-input module forward")
+    y.float().pow(2).sum().backward()
+    assert torch.isfinite(net.weights.grad).all() and net.weights.grad.abs().sum() > 0 and x.grad.shape == (777, I) and torch.isfinite(x.grad).all()
+    # the weight gradient of the input layer against the float64 outer-product sum of the oracle's deltas
+    gw_r, gi_r, _ = oracle.ffmlp_backward((2 * ref.astype(np.float32) * (np.arange(16) < 3)).astype(np.float16), to_np(x.detach().half()),
+                                          to_np(net.weights.detach().half()), oracle.ffmlp_forward(to_np(x.detach().half()), to_np(net.weights.detach().half()), I, Hd, 2, 0)[1],
+                                          I, Hd, 2, 0, True)
+    scale = float(np.abs(gw_r.astype(np.float32)).max())
+    assert np.abs(to_np(net.weights.grad).astype(np.float32) - gw_r.astype(np.float32)).max() <= 2e-2 * scale
+    net.eval()
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        assert torch.equal(net(x), y.detach())
+    be = _be()
+    with pytest.raises(RuntimeError, match="up to 256"):
+        be.ffmlp_inference(torch.zeros(128, 272, dtype=torch.float16, device="cuda"), torch.zeros(Hd * (272 + Hd + 16), dtype=torch.float16, device="cuda"),
+                           128, 272, 16, Hd, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.float16, device="cuda"))
 
 
 ACT_NAMES = {1: "exponential", 2: "sine", 3: "sigmoid", 4: "squareplus", 5: "softplus"}

@@ -107,7 +107,8 @@ def literal_distance(B=131072, seed=1, weight_scale=1.0):
 
 
 # measured on MI355X (tools/measure_literal_distance.py, 131 072 samples) with a margin of ~1.5x on top
-LITERAL_BOUNDS = {"rgb_abs_max": None, "rgb_abs_p999": None, "sigma_rel_max": None, "sigma_rel_p999": None}
+# scale 1: rgb max / p99.9 4.88e-4 / 4.88e-4 (one fp16 ulp in [0.5, 1)), sigma max / p99.9 4.89e-4 / 3.66e-4 (gpurun_out/r5a_literal.json)
+LITERAL_BOUNDS = {"rgb_abs_max": 9.8e-4, "rgb_abs_p999": 7.4e-4, "sigma_rel_max": 7.5e-4, "sigma_rel_p999": 5.5e-4}
 
 
 def test_end_to_end_distance_to_reference_literal_numerics():
@@ -123,7 +124,7 @@ def test_end_to_end_distance_to_reference_literal_numerics():
         assert lit[k] > 0.05 * bound, f"{k}: {lit[k]:.3e} — the bound {bound:.1e} is stale (more than 20x too wide), re-measure"
     # this library's own numerics model: identical bits nearly everywhere, the rest one fp16 rounding of a logit away
     assert own["rgb_identical_share"] > 0.95 and own["rgb_abs_max"] <= 2 * 4.9e-4 + 1e-6
-    assert own["sigma_rel_p999"] <= 2.0 ** -9
+    assert own["sigma_rel_p999"] <= 1.5e-4
 
 
 def test_cuda_ray_training_reduces_loss():
