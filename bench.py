@@ -136,7 +136,7 @@ def step_op_table():
     (SURVEY.md §8d / DESIGN.md §4), USEFUL flops per sample: the forward products once, the backward's dX and dW products — the re-evaluated
     forward inside the fused backward is not counted)."""
     fs, fc = mlp_flops_per_row(32, 64, 2), mlp_flops_per_row(32, 64, 3)
-    bwd_kernels = ["k_mlp_bwd_priv", "k_mlp_bwd_fused", "k_mlp_dw_reduce"]
+    bwd_kernels = ["k_mlp_bwd_fused", "k_mlp_dw_reduce"]
     return {
         "foc_fixed_sample": (["k_fs_sample"], "hbm", 12.0, None),
         "foc_near_far_from_aabb": (["k_near_far_from_aabb"], "hbm", 32.0 / NUM_STEPS, None),

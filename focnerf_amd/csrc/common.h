@@ -17,7 +17,6 @@ void foc_set_error(const char *fmt, ...);
 // foc_set_option (tests, A/B runs) — no getenv on any call path.
 enum FocOpt {
     FOC_OPT_MLP_BWD_FUSED,        // 1: single-pass fused MLP backward where it applies; 0: the two-kernel form (stored activations)
-    FOC_OPT_MLP_BWD_PRIV,         // fused MLP backward with wave-private weight-gradient tiles (ffmlp_bwd_priv.hip): 0 off, 1 / 2 = 32 / 64 rows per wave and step
     FOC_OPT_GB_MERGE_MAX_RES,     // binned grid backward: levels up to this resolution merge runs of equal cells (default 480)
     FOC_OPT_GB_FACTORED,          // 1: 8-byte factored records on the unmerged hashed levels; 0: 12-byte two-corner records everywhere
     FOC_OPT_GB_TAIL_SPLIT,        // scatter: most workgroups a tile of the last partial round is dealt out to (16; 1 = whole tiles only)

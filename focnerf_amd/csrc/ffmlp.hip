@@ -467,16 +467,6 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     const uint32_t MT0 = (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
     _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
-    // Bank swizzle of the tiles (re-evaluating form): the chained-layout writes below are 32 rows x 8 bytes at a row stride of 20 / 28 / 36 dwords, and
-    // 16 such strides are a multiple of the 64 banks — rows r and r + 16 met in one bank (SQ_LDS_BANK_CONFLICT 26 % of the LDS cycles, round 4). A
-    // row's 8-byte granule g therefore lives at g ^ ((row >> 4) & 1): the writers flip their lane-half term, the transposed readers (whose four rows
-    // of a k step share row >> 4) flip bit 0 of their column group. The 16-wide output-gradient tile of stage 0 (16-byte rows) stays as it is.
-#ifdef FOC_TIMING_NO_SWZ
-    constexpr bool SWZ = false;                          // A/B build (tools/build_variant.sh)
-#else
-    constexpr bool SWZ = RECOMP;
-#endif
-    const int swc = SWZ ? ((c >> 4) & 1) : 0, hs = h ^ swc;
 
     f16v dwacc[NL + 1];
 #pragma unroll
@@ -664,7 +654,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                                 const h8 f = bf[(2 * mt + (q >> 1)) < KC ? (2 * mt + (q >> 1)) : 0][nb];
                                 const h4 v = (q & 1) ? h4{f[4], f[5], f[6], f[7]} : h4{f[0], f[1], f[2], f[3]};
 #ifndef FOC_TIMING_NO_TILES
-                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + 32 * mt + 8 * q + 4 * hs) = v;
+                                *reinterpret_cast<h4 *>(myD + (nb * 32 + c) * WD + col) = v;
 #endif
                             }
                         }
@@ -703,7 +693,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
                         for (int nb = 0; nb < NB; nb++) {
                             const h8 v = fa[NL - 1 - s][kc][nb];
-                            _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 4 * hs;
+                            _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 4 * h;
 #ifndef FOC_TIMING_NO_TILES
                             *reinterpret_cast<h4 *>(dst) = h4{v[0], v[1], v[2], v[3]};
                             *reinterpret_cast<h4 *>(dst + 8) = h4{v[4], v[5], v[6], v[7]};
@@ -718,9 +708,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                                 h8 v = x_cur[kc][nb];
                                 // object feature: column 31 of the input tile (a zero of the shifted h row) becomes 1, so that dW0[:, 31] = sum_b delta_0
                                 if constexpr (HEAD) { if (kc == 1 && has_obj && h == 1) v[7] = (_Float16)1.0f; }
-                                _Float16 *dst = myA + (nb * 32 + c) * WA + 16 * kc + 8 * h;      // the row's two granules, swapped for rows 16..31
-                                *reinterpret_cast<h4 *>(dst + 4 * swc) = h4{v[0], v[1], v[2], v[3]};
-                                *reinterpret_cast<h4 *>(dst + 4 * (1 - swc)) = h4{v[4], v[5], v[6], v[7]};
+                                *reinterpret_cast<h8 *>(myA + (nb * 32 + c) * WA + 16 * kc + 8 * h) = v;
                             }
                 }
             } else {
@@ -815,11 +803,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
                             // (stride 36 dwords: bank offsets 0, 36, 8, 44) overlapped pairwise: a 2-way conflict on half of these reads, the
                             // bulk of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE, LDS 48 % busy).
                             const int k0 = 16 * ks + 4 * q + h;
-                            const int pa = SWZ ? (p ^ (ks & 1)) : p, pd = (SWZ && s > 0) ? pa : p;      // swizzled column group (all four rows share row >> 4 = ks)
-                            const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * pd));
-                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 2) * WD + 32 * mt + cg + 4 * pd));
-                            const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * pa));
-                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 2) * WA + 32 * nt + cg + 4 * pa));
+                            const s4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + k0 * WD + 32 * mt + cg + 4 * p));
+                            const s4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tD + (k0 + 2) * WD + 32 * mt + cg + 4 * p));
+                            const s4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + k0 * WA + 32 * nt + cg + 4 * p));
+                            const s4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4 *)(tA + (k0 + 2) * WA + 32 * nt + cg + 4 * p));
                             const u32x2 A0 = __builtin_bit_cast(u32x2, a0), A1 = __builtin_bit_cast(u32x2, a1);
                             const u32x2 B0 = __builtin_bit_cast(u32x2, b0), B1 = __builtin_bit_cast(u32x2, b1);
                             u32x4 av = {A0.x, A0.y, A1.x, A1.y}, bv = {B0.x, B0.y, B1.x, B1.y};
@@ -908,13 +895,12 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 // partial sums meet in LDS and are added in wave order: the result does not depend on timing (the atomic flush's did).
 template <int HIDDEN>
 __global__ void __launch_bounds__(1024) k_mlp_dw_reduce(const float *__restrict__ slots, uint32_t n_slots, uint32_t NL, uint32_t in_dim, uint32_t ld0,
-                                                        _Float16 *__restrict__ gw, float *__restrict__ wsb, uint32_t nosplit) {
+                                                        _Float16 *__restrict__ gw, float *__restrict__ wsb) {
     __shared__ float part[16][64];
     const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x / 64, w = (blockIdx.x / 16) % 4, reg = blockIdx.x % 16;       // stage, wave tile, accumulator register
     const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN, IN = s < NL ? (uint32_t)HIDDEN : in_dim;
-    // nosplit: slots of k_mlp_bwd_priv — one tile per (mt, nt), no second batch half
-    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4 && !nosplit) ? 2u : 1u;
+    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4) ? 2u : 1u;
     if (w >= ntile) return;                               // the second batch half of a tile (w >= ntile) is added by the tile's workgroup
     const uint32_t mt = w / NTi, nt = w % NTi, h = lane >> 5;
     const uint32_t o = 32 * mt + (uint32_t)acc_row((int)reg, (int)h), i = 32 * nt + (lane & 31);
@@ -1252,9 +1238,6 @@ static uint32_t mlp_resident_blocks(const void *kern, size_t lds) {
 // hidden_dim 256 (ffmlp_wide.hip): layer-by-layer kernels with one matrix resident in LDS
 int mlp_wide_forward(bool train, const void *inputs, const void *weights, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act, void *buffer,
                      void *outputs, hipStream_t st);
-// wave-private weight-gradient tiles (ffmlp_bwd_priv.hip)
-int mlp_bwd_priv_launch(int num_layers, int imode, int nb, const void *grad, const void *inputs, const void *weights, uint32_t B, void *grad_inputs,
-                        float *slots, uint32_t max_grid, const MlpHead *head, hipStream_t st, uint32_t *grid_out);
 int mlp_wide_backward_activations(const void *grad, const void *weights, const void *fwd_buf, uint32_t B, uint32_t in_dim, uint32_t hidden, uint32_t num_layers, int act,
                                   void *bwd_buf, void *grad_inputs, hipStream_t st);
 
@@ -1364,23 +1347,12 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     if (grid > cap) grid = cap;
     // workspace: [fp32 blob image (object-conditioned head only)] [one slot of (NL + 1) x 4096 floats per workgroup] — no zero fill, no atomics
     float *slots = ws + mlp_dw_blob_floats(has_obj ? HEAD_OBJ_LD : in_dim, HIDDEN, NL);
-    // the shapes of the NeRF networks (hidden 64, 32 inputs, 2 or 3 hidden layers, ReLU, re-evaluated activations, no stored gradients) take the
-    // form with wave-private weight-gradient tiles (ffmlp_bwd_priv.hip): one workgroup per CU, no barrier in the batch loop
-    const int priv = foc_opt(FOC_OPT_MLP_BWD_PRIV);
-    uint32_t nosplit = 0;
-    if (HIDDEN == 64 && NL <= 3 && in_dim == 32 && recomp && relu && !bwd_buf && priv > 0) {
-        const int imode = head ? (head->out_width == 4u ? 3 : 2) : (planar ? 1 : 0);
-        const int rc = mlp_bwd_priv_launch(NL, imode, priv >= 2 ? 2 : 1, grad, inputs, weights, B, grad_inputs, slots, min(mlp_num_cus(), MLP_DW_MAX_SLOTS), head, st, &grid);
-        if (rc) return rc;
-        nosplit = 1;
-    } else {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds_launch, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
-                           (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, slots, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
-                           head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
-        FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
-    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MLP_BLOCK), lds_launch, st, (const _Float16 *)grad, (const _Float16 *)inputs, (const _Float16 *)weights,
+                       (const _Float16 *)fwd_buf, (_Float16 *)bwd_buf, (_Float16 *)grad_inputs, slots, B, in_dim, relu, (uint32_t)(lds_w / sizeof(_Float16)),
+                       head ? *head : MlpHead{nullptr, nullptr, 1u, 16u, nullptr});
+    FOC_CHECK_LAUNCH("ffmlp_backward(fused)");
     hipLaunchKernelGGL((k_mlp_dw_reduce<HIDDEN>), dim3((NL + 1) * 64), dim3(1024), 0, st, (const float *)slots, grid, (uint32_t)NL, in_dim,
-                       has_obj ? (uint32_t)HEAD_OBJ_LD : in_dim, (_Float16 *)grad_weights, has_obj ? ws : (float *)nullptr, nosplit);
+                       has_obj ? (uint32_t)HEAD_OBJ_LD : in_dim, (_Float16 *)grad_weights, has_obj ? ws : (float *)nullptr);
     FOC_CHECK_LAUNCH("ffmlp_backward(reduce)");
     if (has_obj) {
         hipLaunchKernelGGL(k_mlp_dw_finalize_obj, dim3(foc_grid_1d(n_w, 256)), dim3(256), 0, st, ws, (_Float16 *)grad_weights, n_w, (uint32_t)HIDDEN,

@@ -598,7 +598,8 @@ __global__ void __launch_bounds__(256) k_vt_perm(uint32_t N, uint32_t th, uint32
         uint32_t src = p;
         if (grid) {
             // tile rows hold W * th rays each (the last one fewer rows), a tile rows_here * tw rays (the last one of a tile row fewer columns)
-            const uint32_t ty = p / (W * th), rem = p - ty * W * th;
+            const uint64_t wt = (uint64_t)W * th;            // 64 bits: a very wide view times a tall tile passes 2^32
+            const uint32_t ty = (uint32_t)(p / wt), rem = (uint32_t)(p - ty * wt);
             const uint32_t rows_here = min(th, H - ty * th);
             const uint32_t tx = min(rem / (rows_here * tw), (W - 1u) / tw), r2 = rem - tx * rows_here * tw;
             const uint32_t cols_here = min(tw, W - tx * tw);

@@ -1,4 +1,4 @@
-// mlp_common.h — shared device helpers of the fused MLP kernels (ffmlp.hip, ffmlp_bwd_priv.hip): MFMA fragment layouts, the
+// mlp_common.h — shared device helpers of the fused MLP kernels (ffmlp.hip; a second translation unit, ffmlp_bwd_priv.hip, lived beside it in round 5: NOTEBOOK.md): MFMA fragment layouts, the
 // chained-operand k permutation, weight staging into LDS, colour-head input modes. Semantics: ffmlp/src/ffmlp.cu of the reference
 // (see ffmlp.hip for the design notes).
 #pragma once

@@ -60,10 +60,14 @@ def view_tiling(rays_d):
     """int64 [N] order in which the staged render walks the view's rays: 8 x 8 pixel tiles if `rays_d` is a row-major pixel grid, else the
     identity — found and built ON THE DEVICE (csrc/fixedstep.hip, foc_view_tile_order): the caller's thread never waits for the GPU, so
     the chunks of the next view are enqueued while the previous view is still being rendered. None: not applicable (FOC_RAY_TILES=0, fewer
-    than 4096 rays, not on the GPU)."""
+    than 4096 rays, not on the GPU). A ray set of >= 4096 rays that is NO pixel grid gets the identity as a tensor (the decision lives on the
+    device): its caller gathers the rays and scatters the results through it — 2 x 24 B per ray of extra traffic for random-ray evaluation,
+    the price of not waiting for the GPU once per view; FOC_RAY_TILES=0 skips both."""
     shape = os.environ.get("FOC_RAY_TILES", "8x8")
     if shape in ("0", "", "off") or not rays_d.is_cuda or rays_d.dim() != 2 or rays_d.shape[0] < 4096:
         return None
+    if rays_d.shape[1] != 3:
+        raise ValueError(f"view_tiling: rays_d must be [N, 3] (got {tuple(rays_d.shape)})")
     try:
         th, tw = (int(v) for v in shape.lower().split("x"))
     except ValueError:

@@ -35,8 +35,12 @@ extern "C" {
 #define FOC_F32 0
 #define FOC_F16 1
 
-/* ABI version of this header; bump on any signature change. */
-#define FOC_ABI_VERSION 1
+/* ABI version of this header; bump on any change of a signature OR of a buffer contract.
+ *   2 (round 5): the workspace of foc_ffmlp_backward / _backward_planar / foc_color_head_backward is
+ *     [fp32 image of the weight blob | one slot of partial weight-gradient tiles per workgroup of the launch], written without a zero fill and
+ *     tens of MB large — a buffer sized by version 1's blob formula (input_dim, hidden_dim, num_layers -> ~50 KB) is too small: size it with
+ *     foc_ffmlp_backward_workspace_bytes(); input_dim up to 256 at every hidden width. */
+#define FOC_ABI_VERSION 2
 int         foc_abi_version(void);
 /* Thread-local message of the last non-zero return on this thread ("" if none). */
 const char *foc_last_error(void);
@@ -356,9 +360,12 @@ int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uin
  *       backward_buffer [num_layers,B,hidden], grad_inputs [B,input_dim], grad_weights (blob))
  * forward_buffer NULL: see foc_ffmlp_forward. backward_buffer may be NULL for the same shapes (the
  * activation gradients then never leave the chip); other shapes need both (FOC_E_INVALID otherwise).
- * workspace: device fp32, foc_ffmlp_backward_workspace_bytes() bytes, caller-owned; holds
- * the fp32 split-K partial sums of the weight gradients (the reference's CUTLASS split-K
- * workspace, cutlass_matmul.h:335-363, is a process-global map instead). */
+ * workspace: device memory, foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers) bytes, caller-owned, needs NO zero fill:
+ * [fp32 image of the weight blob: the split-K sums of the two-kernel form, the object-conditioned head's finalize] followed, for the shapes
+ * the single-pass kernel serves (hidden_dim <= 64, input_dim <= 64, 2..4 layers), by up to 1024 per-workgroup slots of
+ * (num_layers + 1) x 4096 fp32 partial weight-gradient tiles that a second kernel sums in a fixed order (33 - 80 MB; the reference's CUTLASS
+ * split-K workspace, cutlass_matmul.h:335-363, is a process-global map instead). Every caller queries the size; for the colour head with
+ * an object feature ask for input_dim 48 (the slots start behind a 48-wide blob image). */
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights,
                        const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,

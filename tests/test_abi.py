@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_arch():
     from focnerf_amd import _lib
-    assert _lib.lib.foc_abi_version() == 1
+    assert _lib.lib.foc_abi_version() == 2
     assert _lib.lib.foc_arch() == b"gfx950"
     assert isinstance(_lib.lib.foc_last_error(), bytes)           # (empty in a fresh process; other tests of a session may have left theirs)
 

@@ -3,7 +3,6 @@
 # the two backward calls of the headline step in isolation (tools/time_mlp_bwd.py).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
-export FOC_MLP_BWD_PRIV=0
 for rep in 1 2 3; do
   python3 tools/time_mlp_bwd.py 2>/dev/null
   for lib in _ab/lib_t_*.so; do

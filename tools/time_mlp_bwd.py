@@ -43,7 +43,7 @@ def main():
     def colour():
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w_c), M, 64, 3, 0, ptr(gh), ptr(gw_c), ptr(ws_c), 4, None, None, st),
               "colour bwd")
-    out = {"rows": M, "lib": os.path.basename(os.environ.get("FOCNERF_LIB_PATH", "libfocnerf_hip.so")), "priv": os.environ.get("FOC_MLP_BWD_PRIV")}
+    out = {"rows": M, "lib": os.path.basename(os.environ.get("FOCNERF_LIB_PATH", "libfocnerf_hip.so"))}
     for name, fn in (("sigma", sigma), ("colour", colour)):
         for _ in range(5):
             fn()
