@@ -820,7 +820,7 @@ def main():
     ks_all, n_k = {}, 5
     try:
         from focnerf_amd import _lib
-        names = [n for n, (_, a) in _lib.SIGNATURES.items() if a and a[-1] is _lib.c_vp and not n.endswith("_bytes")]
+        names = [n for n, (_, a) in _lib.SIGNATURES.items() if a and a[-1] is _lib.c_vp and not n.endswith("_bytes") and not n.endswith("_option")]
         with LibTimer(names) as lt:
             m0 = torch.cuda.Event(enable_timing=True)
             m1 = torch.cuda.Event(enable_timing=True)
@@ -998,8 +998,8 @@ def main():
             # is enqueued in microseconds). No LR scheduler inside the graph (a host-side scalar); everything else is train_step().
             try:
                 from focnerf_amd.graph import GraphedStep
-                import copy
-                model_g = copy.deepcopy(model).train()      # a copy: the render legs below (and their checksums) see the model as the timed steps left it
+                model_g = build_model(bound, device, cuda_ray=False, seed=rank).train()      # a copy of the trained model: the render legs below (and their
+                model_g.load_state_dict(model.state_dict())                                    # checksums) see `model` as the timed steps left it
                 opt_g = torch.optim.Adam(model_g.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
                 sc_g = torch.amp.GradScaler("cuda")
                 g_head = GraphedStep(lambda o, d, t: train_step(model_g, opt_g, sc_g, o, d, t, fused=fused), batches[0])

@@ -876,13 +876,28 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     // fixed order. As fp32 atomics into ONE blob-shaped workspace the flush was 512 workgroups x 7-11 K adds on the same 28-45 KB:
     // 35-50 us of serialised same-address atomics at the end of every launch whatever the batch (the whole kernel takes 67 / 89 us on
     // the 0.5 M-sample batches of the occupancy sampler), and sums that depended on arrival order.
+    // A stage with at most two tiles was split along the batch (waves 2, 3 hold the same tiles over the other half of the rows): the two halves
+    // meet in LDS first (the tiles' LDS is free by now), so a slot carries one copy of every tile — a quarter fewer slot bytes to write here and
+    // to read in k_mlp_dw_reduce (round 5).
     float *slot = ws + (uint64_t)blockIdx.x * ((NL + 1) * MLP_DW_SLOT_STAGE);
+    float *meet = reinterpret_cast<float *>(sD);           // [2 tiles][16 registers][64 lanes] fp32 = 8 KiB <= the four D tiles
 #pragma unroll
     for (int s = 0; s <= NL; s++) {
         const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN;
         const uint32_t IN = s < NL ? (uint32_t)HIDDEN : in_dim;
         const uint32_t ntile = ((OUT + 31) / 32) * ((IN + 31) / 32), ksplit = (ntile * 2 <= 4) ? 2u : 1u;
-        if (wave < ntile * ksplit) {
+        if (ksplit == 2u) {
+            __syncthreads();                                 // the previous stage's meeting buffer has been read
+            if (wave >= ntile && wave < 2u * ntile) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) meet[((wave - ntile) * 16 + reg) * 64 + lane] = dwacc[s][reg];
+            }
+            __syncthreads();
+            if (wave < ntile) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) slot[(s * 4 + wave) * 1024 + reg * 64 + lane] = dwacc[s][reg] + meet[(wave * 16 + reg) * 64 + lane];
+            }
+        } else if (wave < ntile) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) slot[(s * 4 + wave) * 1024 + reg * 64 + lane] = dwacc[s][reg];
         }
@@ -900,8 +915,8 @@ __global__ void __launch_bounds__(1024) k_mlp_dw_reduce(const float *__restrict_
     const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x / 64, w = (blockIdx.x / 16) % 4, reg = blockIdx.x % 16;       // stage, wave tile, accumulator register
     const uint32_t OUT = s == 0 ? 16u : (uint32_t)HIDDEN, IN = s < NL ? (uint32_t)HIDDEN : in_dim;
-    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = (ntile * 2 <= 4) ? 2u : 1u;
-    if (w >= ntile) return;                               // the second batch half of a tile (w >= ntile) is added by the tile's workgroup
+    const uint32_t NTi = (IN + 31) / 32, MTo = (OUT + 31) / 32, ntile = MTo * NTi, ksplit = 1u;      // a slot holds ONE copy of every tile (k_mlp_bwd_fused's flush)
+    if (w >= ntile) return;
     const uint32_t mt = w / NTi, nt = w % NTi, h = lane >> 5;
     const uint32_t o = 32 * mt + (uint32_t)acc_row((int)reg, (int)h), i = 32 * nt + (lane & 31);
     if (!(o < OUT) && !(32 * mt + (uint32_t)acc_row((int)reg, 1 - (int)h) < OUT)) return;      // rows past OUT in both lane halves (16-wide output stage)

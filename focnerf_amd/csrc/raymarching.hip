@@ -264,10 +264,13 @@ __global__ void __launch_bounds__(256) k_march_count_wave(const float *__restric
                               const uint8_t *__restrict__ grid, RmParams p, uint32_t max_steps, uint32_t N,
                               float *__restrict__ nears, float *__restrict__ fars,
                               const float *__restrict__ noises, int32_t *__restrict__ counts, float *__restrict__ tstrip,
-                              const float *__restrict__ aabb, float min_near) {
+                              const float *__restrict__ aabb, float min_near, const int32_t *__restrict__ counter_in) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (n >= N) return;                                    // whole wave
+    // the emit pass does the slot reservation itself (k_march_emit<.., true>): it takes the counter's entry values from a snapshot behind the
+    // counts, because its last workgroup overwrites the counter while others may not have started
+    if (counter_in && n == 0 && lane == 0) { counts[N] = counter_in[0]; counts[N + 1] = counter_in[1]; }
     const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
@@ -475,19 +478,50 @@ __device__ __forceinline__ void rm_sh16(float x, float y, float z, float (&o)[16
 // a ray, all equal. Every row of both arrays is written — rays that do not fit the list and the rows behind the last ray get zeros
 // (spare workgroups; `counter` from k_march_scan) — so the caller needs no zero fill.
 #define RM_PAD_BLOCKS 64u
-template <bool FIELD>
+// SCAN (round 5): the ordered slot reservation of k_march_scan done HERE, by every workgroup for itself — a workgroup's rays start at the sum
+// of the counts of all rays before them, 256 threads add those up (at most 16 384 ints, L2 resident) and the wave of ray n adds the counts of
+// the workgroup's earlier rays: the same integers as the one-workgroup scan, with no launch of its own (8.6 us + a launch gap of the configs[2]
+// step), no atomics and no ticket. The `rays` table is written here (lane 0 of each ray's wave), the counter by the workgroup of the last ray;
+// the entry values of the counter come from the snapshot the count pass left behind the counts (`counts[N], counts[N + 1]`).
+template <bool FIELD, bool SCAN>
 __global__ void __launch_bounds__(256) k_march_emit(const float *__restrict__ rays_o, const float *__restrict__ rays_d, RmParams p, uint32_t max_steps,
                                                     uint32_t N, uint32_t M, const float *__restrict__ nears, const float *__restrict__ noises,
-                                                    const int32_t *__restrict__ rays, const float *__restrict__ tstrip,
+                                                    int32_t *__restrict__ rays, const float *__restrict__ tstrip,
                                                     float *__restrict__ xyzs, float *__restrict__ dirs, float *__restrict__ deltas,
-                                                    _Float16 *__restrict__ sh, const int32_t *__restrict__ counter, uint32_t pad_align) {
+                                                    _Float16 *__restrict__ sh, int32_t *__restrict__ counter, uint32_t pad_align,
+                                                    const int32_t *__restrict__ counts) {
     typedef _Float16 rm_h8 __attribute__((ext_vector_type(8)));
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t scan_point = 0, scan_steps = 0, scan_total = 0;
+    if constexpr (SCAN) {
+        __shared__ int s_part[4];
+        const uint32_t first = min(blockIdx.x * 4u, N);            // spare workgroups (FIELD): all N rays lie before them
+        int part = 0;
+        for (uint32_t i = threadIdx.x; i < first; i += 256u) part += counts[i];
+        part = wave_sum_i(part);
+        if (lane == 0) s_part[threadIdx.x >> 6] = part;
+        __syncthreads();
+        const int before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const int base0 = counts[N], ray0 = counts[N + 1];
+        const uint32_t w = threadIdx.x >> 6;
+        int mine = 0, earlier = 0, here = 0;
+        for (uint32_t j = 0; j < 4u; j++) {
+            const int cj = first + j < N ? counts[first + j] : 0;
+            if (j < w) earlier += cj;
+            if (j == w) mine = cj;
+            here += cj;
+        }
+        scan_point = (uint32_t)(base0 + before + earlier);
+        scan_steps = (uint32_t)mine;
+        scan_total = (uint32_t)(base0 + before + (blockIdx.x * 4u < N ? here : 0));
+        if (n < N && lane == 0) { rays[n * 3] = (int32_t)n; rays[n * 3 + 1] = (int32_t)scan_point; rays[n * 3 + 2] = mine; }
+        if (blockIdx.x == (N + 3u) / 4u - 1u && threadIdx.x == 0) { counter[0] = (int32_t)scan_total; counter[1] = ray0 + (int32_t)N; }
+    }
     if constexpr (FIELD) {
         if (blockIdx.x >= (N + 3u) / 4u) {
             // pad_align > 0: the caller cuts the list to the samples marched, rounded up like raymarching.py:226 — nothing behind that is read
-            const uint32_t total = (uint32_t)counter[0], pb = blockIdx.x - (N + 3u) / 4u;
+            const uint32_t total = SCAN ? scan_total : (uint32_t)counter[0], pb = blockIdx.x - (N + 3u) / 4u;
             const uint64_t end = pad_align ? min((uint64_t)M, (uint64_t)total + (pad_align - total % pad_align)) : (uint64_t)M;
             for (uint64_t s = (uint64_t)total + pb * 256u + threadIdx.x; s < end; s += (uint64_t)RM_PAD_BLOCKS * 256u) {
                 xyzs[s * 3] = 0.0f; xyzs[s * 3 + 1] = 0.0f; xyzs[s * 3 + 2] = 0.0f;
@@ -498,8 +532,8 @@ __global__ void __launch_bounds__(256) k_march_emit(const float *__restrict__ ra
         }
     }
     if (n >= N) return;
-    const uint32_t point_index = (uint32_t)rays[n * 3 + 1];
-    const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
+    const uint32_t point_index = SCAN ? scan_point : (uint32_t)rays[n * 3 + 1];
+    const uint32_t num_steps = SCAN ? scan_steps : (uint32_t)rays[n * 3 + 2];
     if (num_steps == 0) return;
     if (point_index + num_steps > M) {                             // raymarching.cu:413
         if constexpr (FIELD) {
@@ -1251,19 +1285,28 @@ static int rm_march_train(const float *rays_o, const float *rays_d, const uint8_
         hipLaunchKernelGGL(k_march_count, dim3(foc_div_up(N, 64)), dim3(64), 0, st, rays_o, rays_d, grid, p, max_steps, N, nears, fars, noises, scratch, tstrip, aabb, min_near);
     else
         hipLaunchKernelGGL(p.dt_min <= p.dt_max ? k_march_count_wave<true> : k_march_count_wave<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d,
-                           grid, p, max_steps, N, nears, fars, noises, scratch, tstrip, aabb, min_near);
+                           grid, p, max_steps, N, nears, fars, noises, scratch, tstrip, aabb, min_near, (const int32_t *)counter);
     FOC_CHECK_LAUNCH("march_rays_train(count)");
     // The reference's callers always pass a freshly zeroed counter (legacy/nerf/renderer.py:281-283):
     // rays rows are written at index i (ray order); counter[0] is honoured as the base offset.
-    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, st, scratch, N, rays, counter);
-    FOC_CHECK_LAUNCH("march_rays_train(scan)");
+    // Batches of the wave form (<= 16 384 rays: every emit workgroup can afford to add up the counts before its rays) reserve their slots in
+    // the emit pass; larger ones keep the one-workgroup scan.
+    const bool scan_in_emit = !serial && N <= 16384u;     // (FOC_MARCH_SERIAL=0 can force the wave form on larger batches)
+    if (!scan_in_emit) {
+        hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, st, scratch, N, rays, counter);
+        FOC_CHECK_LAUNCH("march_rays_train(scan)");
+    }
     if (field) {
         p.norm_inv = 1.0f / (2.0f * bound);                // (x + bound) / (2 bound) as torch evaluates it: times the reciprocal (grid.py:149)
-        hipLaunchKernelGGL(k_march_emit<true>, dim3(foc_div_up(N, 4) + RM_PAD_BLOCKS), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays,
-                           tstrip, xyzs, (float *)nullptr, deltas, (_Float16 *)sh_rows, counter, pad_align);
+        auto emit = k_march_emit<true, false>;
+        if (scan_in_emit) emit = k_march_emit<true, true>;
+        hipLaunchKernelGGL(emit, dim3(foc_div_up(N, 4) + RM_PAD_BLOCKS), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs,
+                           (float *)nullptr, deltas, (_Float16 *)sh_rows, counter, pad_align, (const int32_t *)scratch);
     } else {
-        hipLaunchKernelGGL(k_march_emit<false>, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs,
-                           dirs, deltas, (_Float16 *)nullptr, (const int32_t *)nullptr, 0u);
+        auto emit = k_march_emit<false, false>;
+        if (scan_in_emit) emit = k_march_emit<false, true>;
+        hipLaunchKernelGGL(emit, dim3(foc_div_up(N, 4)), dim3(256), 0, st, rays_o, rays_d, p, max_steps, N, M, nears, noises, rays, tstrip, xyzs, dirs, deltas,
+                           (_Float16 *)nullptr, counter, 0u, (const int32_t *)scratch);
     }
     FOC_CHECK_LAUNCH("march_rays_train(emit)");
     return FOC_OK;
