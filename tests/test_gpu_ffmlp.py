@@ -82,7 +82,10 @@ def test_forward_random(I, Hd, nl):
     assert_half_close(out, ref_out, ulps=2.0 * (nl + 1), atol=4e-3, what="outputs")
     # against the WMMA-like half-accumulate model of the reference: same numbers up to fp16 accumulation error
     ref_h = oracle.ffmlp_forward(x, W, I, Hd, nl, 0, training=False, acc_mode=1)
-    assert np.abs(out.astype(np.float32) - ref_h.astype(np.float32)).max() < 0.05 * max(1.0, np.abs(ref_h.astype(np.float32)).max())
+    # measured on MI355X over the thirteen shapes (tools/measure_ffmlp_literal.py, gpurun_out/r5k_ffmlp_literal.txt): worst |difference| / max(1, |output|max)
+    # 1.74e-3 (256 -> 256 x 3), 5.3e-4 / 5.7e-4 on the two NeRF shapes; 4e-3 pins it with a margin of 2.3 (round 4 asserted 5e-2). The network-level
+    # figure is tests/test_gpu_network.py::test_end_to_end_distance_to_reference_literal_numerics
+    assert np.abs(out.astype(np.float32) - ref_h.astype(np.float32)).max() < 4e-3 * max(1.0, np.abs(ref_h.astype(np.float32)).max())
     assert np.array_equal(_run_forward(x, W, I, Hd, nl, 0, False), out), "inference and training kernels must agree bit for bit"
 
 

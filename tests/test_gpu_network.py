@@ -106,25 +106,37 @@ def literal_distance(B=131072, seed=1, weight_scale=1.0):
     return out
 
 
-# measured on MI355X (tools/measure_literal_distance.py, 131 072 samples) with a margin of ~1.5x on top
-# scale 1: rgb max / p99.9 4.88e-4 / 4.88e-4 (one fp16 ulp in [0.5, 1)), sigma max / p99.9 4.89e-4 / 3.66e-4 (gpurun_out/r5a_literal.json)
-LITERAL_BOUNDS = {"rgb_abs_max": 9.8e-4, "rgb_abs_p999": 7.4e-4, "sigma_rel_max": 7.5e-4, "sigma_rel_p999": 5.5e-4}
+# measured on MI355X (tools/measure_literal_distance.py, gpurun_out/r5d_literal.json), bounds = measured x ~1.5:
+#   initialisation-scale weights (|h0| <= 0.43, rgb logits <= 0.24), 131 072 samples: |dRGB| max / p99.9 4.88e-4 / 4.88e-4 (ONE fp16 ulp of a value in
+#   [0.5, 1)), |dsigma| / sigma max / p99.9 4.89e-4 / 3.66e-4; 89.8 % of the colours are the literal model's bits;
+#   weights x 16 (|h0| <= 6.2, rgb logits <= 27.5: a trained field's range), 32 768 samples: |dRGB| 5.37e-3 / 3.42e-3, |dsigma| / sigma 7.84e-3 / 5.84e-3
+#   (sigma = exp(h0): an ulp of a logit in [4, 8) is 3.9e-3 relative).
+LITERAL_CASES = {
+    1.0: (131072, {"rgb_abs_max": 9.8e-4, "rgb_abs_p999": 7.4e-4, "sigma_rel_max": 7.5e-4, "sigma_rel_p999": 5.5e-4},
+          {"rgb_identical_share": 0.95, "rgb_abs_max": 2 * 4.9e-4 + 1e-6, "sigma_rel_p999": 1.5e-4}),
+    16.0: (32768, {"rgb_abs_max": 8.0e-3, "rgb_abs_p999": 5.0e-3, "sigma_rel_max": 1.2e-2, "sigma_rel_p999": 8.5e-3},
+           {"rgb_identical_share": 0.95, "rgb_abs_max": 4.0e-3, "sigma_rel_p999": 1.5e-3}),
+}
 
 
-def test_end_to_end_distance_to_reference_literal_numerics():
+@pytest.mark.parametrize("weight_scale", [1.0, 16.0])
+def test_end_to_end_distance_to_reference_literal_numerics(weight_scale):
     """north_star asks for 1e-4 on RGB / sigma against the reference CUDA path. The reference accumulates in HALF (encoder corner sums, WMMA
     fragments); this library accumulates in fp32 and rounds each layer once, so the network outputs differ from a literal model of the reference by
-    fp16 rounding noise — one ulp of an rgb value near 0.5 is already 4.9e-4. This test states that distance as numbers and pins it: max and
-    99.9th percentile of |dRGB| and |dsigma| / sigma over 131 072 random samples of the BASELINE field, against measured-plus-margin bounds; against
-    the oracle chain in this library's own numerics the outputs are the oracle's bits almost everywhere."""
-    r = literal_distance()
+    fp16 rounding noise — one ulp of an rgb value near 0.5 is already 4.9e-4: the 1e-4 holds for the fp32 stages (composites given the same sigma /
+    rgb, sample positions, the encoder bit for bit against its own numerics) and NOT end to end. This test states the end-to-end distance as numbers
+    and pins it: max and 99.9th percentile of |dRGB| and |dsigma| / sigma over random samples of the BASELINE field — at the initialisation's weight
+    scale and with the weights scaled up to a trained field's logit range — against measured-plus-margin bounds; against the oracle chain in this
+    library's OWN numerics the outputs are the oracle's bits almost everywhere."""
+    B, bounds, own_bounds = LITERAL_CASES[weight_scale]
+    r = literal_distance(B, weight_scale=weight_scale)
     lit, own = r["literal"], r["fp32acc"]
-    for k, bound in LITERAL_BOUNDS.items():
+    for k, bound in bounds.items():
         assert lit[k] <= bound, f"{k}: {lit[k]:.3e} above the pinned bound {bound:.1e}"
         assert lit[k] > 0.05 * bound, f"{k}: {lit[k]:.3e} — the bound {bound:.1e} is stale (more than 20x too wide), re-measure"
     # this library's own numerics model: identical bits nearly everywhere, the rest one fp16 rounding of a logit away
-    assert own["rgb_identical_share"] > 0.95 and own["rgb_abs_max"] <= 2 * 4.9e-4 + 1e-6
-    assert own["sigma_rel_p999"] <= 1.5e-4
+    assert own["rgb_identical_share"] > own_bounds["rgb_identical_share"] and own["rgb_abs_max"] <= own_bounds["rgb_abs_max"]
+    assert own["sigma_rel_p999"] <= own_bounds["sigma_rel_p999"]
 
 
 def test_cuda_ray_training_reduces_loss():
