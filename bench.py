@@ -875,14 +875,14 @@ def main():
                         "foc_grid_encode_forward_counted": "grid_encode_forward_counted", "foc_grid_encode_forward": "grid_encode_forward"}
 
         def entry(name):
-            kernels, bound, bpu, fpu = ops.get(name, ([name], "hbm", None, None))
+            kernels, op_bound, bpu, fpu = ops.get(name, ([name], "hbm", None, None))
             launches, avg = ks_all[name]
             src = "LibTimer, 5 steps after the timed region"
             kt = ksum.get(timed_region.get(name, ""))
             if kt is not None:
                 avg, src = kt["avg_ms"], "KernelTimer, inside the timed region"
             e = {"kernels": kernels, "launches_per_step": launches / n_k, "avg_ms": round(avg, 4), "share_of_step": round(ranked.get(name, per_step[name]) / step_ms_now, 4),
-                 "bound": bound, "timed": src}
+                 "bound": op_bound, "timed": src}
             units = samples_per_step
             if bpu is not None:
                 e["algorithmic_bytes_per_unit"] = bpu
@@ -895,7 +895,7 @@ def main():
             return e
         result["kernels"] = {k: entry(k) for k in sorted(ks_all, key=lambda k: -ranked[k])}
         dom = max(ranked, key=lambda k: ranked[k])
-        kernels, bound, bpu, fpu = ops.get(dom, ([dom], "hbm", None, None))
+        kernels, op_bound, bpu, fpu = ops.get(dom, ([dom], "hbm", None, None))     # (not `bound`: that is the scene's box in this function)
         d = result["kernels"][dom]
         op_ms = d["avg_ms"]
         note = ("chosen among ALL C-ABI entry points of the step (`kernels`); timed with events on the launch stream around the C-ABI call (all kernels of "
@@ -904,7 +904,7 @@ def main():
             op_ms += share_ms
             note += (f"; avg_launch_ms = scatter + reduce ({d['avg_ms']:.4f} ms) + the op's count pass and scans, which ride in the forward launch "
                      f"(counted forward {count_share['counted_forward_ms']:.4f} ms - plain forward {count_share['plain_forward_ms']:.4f} ms, timed after the run)")
-        if bound == "mfma" and fpu is not None:
+        if op_bound == "mfma" and fpu is not None:
             achieved = fpu * samples_per_step / (op_ms * 1e-3) / 1e12
             result["roofline"] = {"kernel": f"{dom} = {'+'.join(kernels)}", "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(dom, kernels=kernels), "avg_launch_ms": op_ms,

@@ -193,3 +193,37 @@ def test_a_c_caller_with_hip_runtime_buffers_matches_the_oracle(tmp_path):
     exe = build_c_abi_consumer(tmp_path)
     r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_CONSUMER_OK gpu" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_line_has_every_leg_and_no_leg_reports_an_error():
+    """`python bench.py` as the driver runs it (fewer steps, no CPU baseline): ONE JSON line whose legs all measured something — a leg that raises is
+    caught inside bench.py and reported as {"error": ...}, which a green exit code would hide (round 5: a local variable of the roofline block shadowed
+    the scene's `bound` and took `combined_render`, the leg the N-rank scaling run is about, down with a TypeError)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--render-views", "2", "--combined-views", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+
+    def errors(node, path=""):
+        found = []
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k in ("error", "kernel_only_error"):
+                    found.append(f"{path}/{k}: {str(v)[:300]}")
+                else:
+                    found += errors(v, f"{path}/{k}")
+        return found
+    assert not errors(r), "\n".join(errors(r))
+    for leg in ("roofline", "kernels", "render", "render_with_fields", "dropin_ops_path", "graph_replay", "occupancy_path", "render_occupancy", "combined_render", "foc_network"):
+        assert leg in r, f"{leg} missing from the bench line: {sorted(r)}"
+    assert r["value"] > 1e8 and r["roofline"]["frac"] > 0.05 and len(r["kernels"]) >= 8
+    assert "mfma" in r["roofline"] and r["roofline"]["mfma"]["mlp_backward"]["frac"] > 0.05
+    assert r["roofline"]["render"]["hbm_real_frac"] is None or r["roofline"]["render"]["hbm_real_frac"] < r["roofline"]["render"]["frac"]
+    assert r["dropin_ops_path"]["render"]["value"] > 0 and r["combined_render"]["value"] > 0
