@@ -284,7 +284,7 @@ class ObjectCombiner:
 
     def render_view(self, field_fns, n_rays, nears, fars, T, bgs=(1.0, 0.0), max_ray_batch=16384, overlap=True):
         """`_render_view` (below), on a stream of this combiner's own while collectives are in flight. Measured with one rank on RCCL
-        (tools/time_rccl_one_rank.py): when RCCL's stream is the first stream a process uses after the default one —
+        (tools/time_rccl_one_rank.py, NOTEBOOK.md rounds 1-4 section 7): when RCCL's stream is the first stream a process uses after the default one —
         bench.py at N > 1, or a fresh COMBINED.py-style process — it shares a hardware queue with the DEFAULT stream, and an all-to-all
         "under" a field evaluation enqueued on the default stream runs strictly in turn with it (44.5 ms per view overlapped = not
         overlapped); with the evaluation on any other stream the two run side by side (43.1), whichever of the two was created first.

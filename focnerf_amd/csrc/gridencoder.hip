@@ -17,9 +17,11 @@
 //  * The [B, L*C] output variant assigns the L levels of one point to adjacent lanes, so a
 //    wave stores 256 contiguous bytes — the reference writes [L,B,C] and pays a permute copy
 //    in Python (grid.py:57).
-//  * Backward: fp16 tables use one packed global_atomic_pk_add_f16 per corner for C=2
-//    (both channels in one dword); fp32 tables use global_atomic_add_f32. Zero gradients
-//    are not issued (adding +-0 is a no-op).
+//  * Backward, D = 3 / C = 2 tables (every FOC network): NO scattered atomics — samples are partitioned into 8192-row segments per
+//    level (k_gbin_count or the counting workgroups of k_grid_fwd_counted -> k_gbin_scans -> k_gbin_scatter_pms writing two-corner /
+//    factored records) and each segment is summed on chip and written once (k_gbin_reduce); DESIGN.md section 4, derivation and measured
+//    variants in NOTEBOOK.md. Other shapes (k_grid_bwd): one packed global_atomic_pk_add_f16 per corner for fp16 C = 2 tables,
+//    global_atomic_add_f32 for fp32; zero gradients are not issued (adding +-0 is a no-op).
 // Compiled with -ffp-contract=off; explicit fmaf() mirrors oracle/oracle.c.
 #include "common.h"
 #include <math.h>
@@ -1409,7 +1411,7 @@ static uint32_t ge_small_levels(uint32_t L, const GeLevels &lv) {
     const int on = foc_opt(FOC_OPT_GRID_FUSE_SMALL);
     if (!on) return 0u;
     const uint32_t finest = on > 1 ? (uint32_t)on : 160u;            // a value above 1 is taken as the resolution threshold (A/B runs)
-    const uint32_t most = L / 2;                                     // most levels in the shared group (10 / 12 / 14 / 16 of 16 measured: DESIGN.md section 9)
+    const uint32_t most = L / 2;                                     // most levels in the shared group (10 / 12 / 14 / 16 of 16 measured: NOTEBOOK.md, rounds 1-4 section 9)
     uint32_t lc = 0;
     while (lc < most && lc < L && lv.resolution[lc] <= finest) lc++;
     return lc >= 2u ? lc : 0u;
@@ -1442,7 +1444,7 @@ static int ge_forward_launch(const float *inputs, const void *emb, const int32_t
         const uint32_t lc = lm_plain ? ge_small_levels(L, lv) : 0u;
         const uint32_t groups = lc >= 2u ? L - lc + 1u : L;
         // FOC_GRID_FWD_LDS=<bytes>: unused dynamic LDS per workgroup — caps the resident workgroups per CU (occupancy experiments: what the
-        // forward's gathers cost with fewer waves in flight)
+        // forward's gathers cost with fewer waves in flight, NOTEBOOK.md, rounds 1-4 section 9)
         const int pad_lds = 0;
         hipLaunchKernelGGL((k_grid_fwd_lbc<T, D, C>), dim3(lm_plain ? chunks * groups : ge_xcd_grid(chunks, L)), dim3(256), (size_t)pad_lds, st, inputs, (const T *)emb, offsets,
                            (T *)outputs, B, L, lv, (T *)dy_dx, gridtype, ac, interp, chunks, (uint32_t)lm_plain,

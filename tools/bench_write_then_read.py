@@ -1,6 +1,6 @@
 """Read bandwidth of torch.sum over a buffer that was just written (fill_) or just read, by size: up to 256 MiB both stay in the Infinity
 Cache (5.2 TB/s); beyond it a read of freshly written data streams at 3.0-3.1 TB/s, of clean data at 3.6-3.9 TB/s (MI355X). The binned grid
-backward's reduce reads 0.72 GB of records its scatter has just written: that is its bound."""
+backward's reduce reads 0.72 GB of records its scatter has just written: that is its bound (NOTEBOOK.md, rounds 1-4 §5)."""
 import torch
 big = torch.empty(1024 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda")
 for mb in (32, 64, 128, 192, 256, 384, 512, 1024):

@@ -1,4 +1,4 @@
-"""What ONE GPU can measure of the combiner's exchange: one rank on the `nccl` backend (= RCCL), the combiner issuing its
+"""What ONE GPU can measure of the combiner's exchange (NOTEBOOK.md, rounds 1-4 section 7): one rank on the `nccl` backend (= RCCL), the combiner issuing its
 collectives anyway (`ObjectCombiner(collectives_at_world_1=True)`), on the bench's own `combined_render` workload — an 800 x 800 view x 512
 samples, one FOC object, 16384-ray pieces of 134 MB. With one rank RCCL copies each piece on the device, on its own stream, while this
 library's kernels evaluate the next piece: the difference to the exchange-free view is the fixed cost of the collective machinery per piece
