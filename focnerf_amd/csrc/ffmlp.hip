@@ -26,6 +26,7 @@
 #include "activations.h"
 #include <stdlib.h>
 
+#include <type_traits>
 #include "mlp_common.h"
 
 // ---------------------------------------------------------------- M1: fused forward / inference
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
 // where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
 // and input rows are fetched while the current group is processed.
-template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE, bool RELU_CT>
+template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE, bool RELU_CT, bool IN32 = false>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
                                                              _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
@@ -476,7 +477,10 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 
     const uint32_t rows_per_group = 4 * RW;
     const uint32_t n_groups = (B + rows_per_group - 1) / rows_per_group;
-    constexpr int KS0M = HEAD ? 2 : 4;             // in_dim <= 64 on this path; input mode 2 is the 32-wide colour input by construction
+    // in_dim <= 64 on this path; the head's input is 32 wide by construction. IN32: in_dim <= 32 as a compile-time fact (the sigma network of
+    // every NeRF field): with the runtime width alone the prefetch held FOUR k-chunks per row and loaded the last existing chunk again for the
+    // two that do not exist — 8 of the planar form's 16 dword loads per lane and group, plus their registers and rotation moves (round 5)
+    constexpr int KS0M = (HEAD || IN32) ? 2 : 4;
     const uint32_t KS0 = HEAD ? 2u : in_dim / 16;
     // RECOMP: this wave's grad rows (D_0 tile order) and input rows (layer-0 B operand order) of the group about to be processed
     h8 g_nxt[(RW * 2 + 63) / 64];
@@ -558,27 +562,33 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
             }
             if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
-            if constexpr (HEAD) {
-                // the colour head's layer 0 starts from the object feature's share (a constant per neuron) when there is one
+            // The colour head's layer 0 starts from the object feature's share (a constant per neuron) when there is one, else — like every other
+            // input mode — from the inline-constant zero of the chain's first MFMA. Two wave-uniform branches: as ONE code path the start value was a
+            // select per accumulator register (32 v_mov per 128 rows of the head without an object feature, round 5).
+            auto layer0 = [&](auto from_zero) {
+#pragma unroll
+                for (int kc = 0; kc < KS0M; kc++) {
+                    if (kc == 0 || (uint32_t)kc < KS0) {         // in_dim >= 16: k-chunk 0 always exists
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) {
+                            const h8 a = ld_frag(ldsF, mt * KS0 + kc, lane);
+#pragma unroll
+                            for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], (kc == 0 && decltype(from_zero)::value) ? FZ : acc[mt][nb]);
+                        }
+                    }
+                }
+            };
+            bool from_bias = false;
+            if constexpr (HEAD) from_bias = has_obj;
+            if (from_bias) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
-                    f16v b0 = FZ;
-                    if (has_obj) b0 = ld_obj_bias(obj_bias, mt, h);
+                    const f16v b0 = ld_obj_bias(obj_bias, mt, h);
 #pragma unroll
                     for (int nb = 0; nb < NB; nb++) acc[mt][nb] = b0;
                 }
-            }
-#pragma unroll
-            for (int kc = 0; kc < KS0M; kc++) {
-                if (kc == 0 || (uint32_t)kc < KS0) {             // in_dim >= 16: k-chunk 0 always exists and starts the chain from the constant 0
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) {
-                        const h8 a = ld_frag(ldsF, mt * KS0 + kc, lane);
-#pragma unroll
-                        for (int nb = 0; nb < NB; nb++) acc[mt][nb] = mfma16(a, x_cur[kc][nb], (kc == 0 && !HEAD) ? FZ : acc[mt][nb]);
-                    }
-                }
-            }
+                layer0(std::false_type{});
+            } else layer0(std::true_type{});
 #pragma unroll
             for (int l = 0; l < NL; l++) {
 #pragma unroll
@@ -1350,6 +1360,9 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
                                  : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, false>))
                        : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0, false>;
+    if constexpr (HIDDEN == 64) {
+        if (recomp && relu && in_dim <= 32 && !head) kern = planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true, true>;
+    }
     if constexpr (HIDDEN == 64 && NL <= 3) {
         if (head) kern = head->out_width == 4u ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, false>)
                                                : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>);
