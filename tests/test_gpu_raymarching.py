@@ -154,6 +154,47 @@ def test_march_rays_train_random_occupancy_bit_exact(rm, bound, dt_gamma, max_st
         assert np.array_equal(to_np(got).view(np.uint32), ref.view(np.uint32)), f"{nm} differ"
 
 
+@pytest.mark.parametrize("N", [1, 3, 4, 5, 255, 1025, 4095, 16384, 16385])
+def test_slot_reservation_in_the_emit_pass_equals_the_one_workgroup_scan(rm, N):
+    """Round 5: batches of the wave form (<= 16 384 rays) reserve their sample slots inside the emit pass (every workgroup adds up the counts of the
+    rays before its own) instead of k_march_scan. Ray counts that 4 does not divide, a single ray, both sides of the switch, a counter that does NOT
+    start at zero (its entry values reach the emit pass through a snapshot the count pass takes) — against the oracle and against the forced
+    one-ray-per-lane form, which keeps the scan kernel: `rays`, `counter` and every sample bit for bit."""
+    from focnerf_amd import _lib
+    from focnerf_amd.backend import _raymarching as be
+    max_steps, dt_gamma = 256, 1 / 128
+    s, n_ref, f_ref, _ = _march_case(2, 2048, dt_gamma, True, seed=7)
+    rep = (N + 2047) // 2048
+    ro, rd = s["rays_o"].repeat(rep, 1)[:N].contiguous(), s["rays_d"].repeat(rep, 1)[:N].contiguous()
+    nr, fr = np.tile(n_ref, rep)[:N].copy(), np.tile(f_ref, rep)[:N].copy()
+    noises = torch.rand(N, generator=torch.Generator().manual_seed(N))
+    C, H = s["cascade"], 128
+    M = N * 64 + 128
+    xr, dr, lr, rr, cr = oracle.march_rays_train(ro.numpy(), rd.numpy(), s["bits"].numpy(), s["bound"], dt_gamma, max_steps, C, H, M, nr, fr, noises.numpy())
+    assert int(cr[0]) > 0 or N < 8
+
+    def run(base):
+        xyzs = torch.zeros(M + base, 3, device="cuda"); dirs = torch.zeros(M + base, 3, device="cuda"); deltas = torch.zeros(M + base, 2, device="cuda")
+        rays = torch.full((N, 3), -7, dtype=torch.int32, device="cuda")
+        counter = torch.tensor([base, 0], dtype=torch.int32, device="cuda")
+        be.march_rays_train(ro.cuda(), rd.cuda(), s["bits"].cuda(), s["bound"], dt_gamma, max_steps, N, C, H, M + base, torch.from_numpy(nr).cuda(),
+                            torch.from_numpy(fr).cuda(), xyzs, dirs, deltas, rays, counter, noises.cuda())
+        return to_np(xyzs), to_np(dirs), to_np(deltas), to_np(rays), to_np(counter)
+    for base in (0, 37):
+        got = run(base)
+        with _lib.option("FOC_MARCH_SERIAL", 1):               # one ray per lane + k_march_scan
+            ser = run(base)
+        for a, b, nm in zip(got, ser, ("xyzs", "dirs", "deltas", "rays", "counter")):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{nm}: emit-pass reservation differs from the scan kernel (N={N}, base={base})"
+        x, d, l, r, c = got
+        assert np.array_equal(c, [cr[0] + base, N])
+        assert np.array_equal(r[:, 0], rr[:, 0]) and np.array_equal(r[:, 2], rr[:, 2]) and np.array_equal(r[:, 1], rr[:, 1] + base)
+        total = int(cr[0])
+        assert np.array_equal(x[base:base + total].view(np.uint32), xr[:total].view(np.uint32))
+        assert np.array_equal(l[base:base + total].view(np.uint32), lr[:total].view(np.uint32))
+        assert not x[:base].any() and not x[base + total:].any()                       # nothing written outside the reserved range
+
+
 def test_march_rays_train_wrapper_semantics(rm):
     """mean_count / align / force_all_rays sizing rules of raymarching.py:196-229."""
     N = 1024
