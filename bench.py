@@ -144,6 +144,7 @@ def step_op_table():
         "foc_grid_encode_forward": (["k_grid_fwd_lbc"], "hbm", 588.0, None),
         "foc_ffmlp_forward_planar": (["k_mlp_fwd"], "mfma", 64.0 + 32.0, fs),
         "foc_color_head_forward": (["k_mlp_fwd"], "mfma", 32.0 + 8.0, fc),
+        "foc_field_forward_train": (["k_field_fwd_train"], "mfma", 64.0 + 32.0 + 8.0, fs + fc),      # both networks' training forward in one kernel
         "foc_fixed_tail_forward": (["k_fs_tail_fwd"], "hbm", 40.0 + 12.0, None),
         "foc_fixed_tail_backward": (["k_fs_tail_bwd"], "hbm", 28.0 + 34.0, None),
         "foc_color_head_backward": (bwd_kernels, "mfma", 8.0 + 32.0 + 32.0, 2.0 * fc),
@@ -921,7 +922,7 @@ def main():
                                   "units_per_launch": samples_per_step, "algorithmic_bytes_per_unit": bpu, "note": note}
         # the MFMA side of the step: both networks' backward and forward against the dense fp16 matrix peak, on USEFUL flops
         mf = {}
-        for label, names in (("mlp_backward", ("foc_ffmlp_backward_planar", "foc_color_head_backward")), ("mlp_forward", ("foc_ffmlp_forward_planar", "foc_color_head_forward"))):
+        for label, names in (("mlp_backward", ("foc_ffmlp_backward_planar", "foc_color_head_backward")), ("mlp_forward", ("foc_field_forward_train", "foc_ffmlp_forward_planar", "foc_color_head_forward"))):
             have = [n for n in names if n in ks_all]
             if not have:
                 continue
@@ -930,7 +931,7 @@ def main():
             mf[label] = {"entry_points": {n: result["kernels"][n]["avg_ms"] for n in have}, "ms_per_step": round(ms, 4), "useful_flops_per_step": fl,
                          "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1), "peak_TFLOPs": MFMA_F16_PEAK_TFLOPS,
                          "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)}
-        util = pmc_mfma_utilisation(["k_mlp_bwd", "k_mlp_fwd"])
+        util = pmc_mfma_utilisation(["k_mlp_bwd", "k_mlp_fwd", "k_field_fwd"])
         if util is not None:
             mf["mfma_pipe_utilisation_from_committed_profile"] = util
         mf["note"] = ("useful flops = 2 x 36 864 per sample backward (dX and dW products; the forward the fused backward re-evaluates is NOT counted, so the "

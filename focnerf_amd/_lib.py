@@ -136,6 +136,7 @@ SIGNATURES = {
     "foc_fixed_head_forward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_fixed_head_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, u32, c_vp]),
     "foc_color_head_forward": (i32, [c_vp, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, u32, c_vp, c_vp]),
+    "foc_field_forward_train": (i32, [c_vp, c_vp, u32, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, c_vp, u32, c_vp, c_vp]),
     "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_vp]),
     "foc_fixed_composite_forward": (i32, [c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp]),
     "foc_fixed_composite_backward": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp, c_vp]),

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restric
 // first one initialises waits for it instead of reading defaults; foc_set_option from one thread is seen by launches issued afterwards
 struct FocOptionRow { const char *name; std::atomic<int> value; };
 static FocOptionRow foc_option_table[FOC_OPT_COUNT] = {
-    {"FOC_MLP_BWD_FUSED", 1}, {"FOC_GB_MERGE_MAX_RES", 480}, {"FOC_GB_FACTORED", 1}, {"FOC_GB_TAIL_SPLIT", 16}, {"FOC_GRID_FUSE_SMALL", 1},
+    {"FOC_MLP_BWD_FUSED", 1}, {"FOC_FIELD_FWD_FUSED", 1}, {"FOC_GB_MERGE_MAX_RES", 480}, {"FOC_GB_FACTORED", 1}, {"FOC_GB_TAIL_SPLIT", 16}, {"FOC_GRID_FUSE_SMALL", 1},
     {"FOC_GRID_PAIRS", 1}, {"FOC_GRID_FAST", 1}, {"FOC_MARCH_SERIAL", -1}, {"FOC_MARCH_RAYS_ROW_MAX", 131072}, {"FOC_OCC_MARCH_FORM", -1},
     {"FOC_OCC_SAMPLE_MAJOR", 1}, {"FOC_OCC_FIELD_PIECE", 1 << 23},
 };

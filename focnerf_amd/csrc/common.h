@@ -17,6 +17,7 @@ void foc_set_error(const char *fmt, ...);
 // foc_set_option (tests, A/B runs) — no getenv on any call path.
 enum FocOpt {
     FOC_OPT_MLP_BWD_FUSED,        // 1: single-pass fused MLP backward where it applies; 0: the two-kernel form (stored activations)
+    FOC_OPT_FIELD_FWD_FUSED,      // 1: training forward of both networks in one kernel (field_fwd.hip); 0: foc_ffmlp_forward_planar + foc_color_head_forward (parity aid)
     FOC_OPT_GB_MERGE_MAX_RES,     // binned grid backward: levels up to this resolution merge runs of equal cells (default 480)
     FOC_OPT_GB_FACTORED,          // 1: 8-byte factored records on the unmerged hashed levels; 0: 12-byte two-corner records everywhere
     FOC_OPT_GB_TAIL_SPLIT,        // scatter: most workgroups a tile of the last partial round is dealt out to (16; 1 = whole tiles only)

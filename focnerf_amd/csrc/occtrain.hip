@@ -236,11 +236,21 @@ int foc_occ_train_forward(const FocOccTrainNode *n, void *stream) {
     rc = foc_grid_encode_forward_counted(n->enc_in, n->embeddings, n->offsets, n->planes, M, 3, 2, n->levels, n->per_level_scale_log2, n->base_resolution, n->gridtype,
                                          n->align_corners, n->interp, n->table_dtype, n->offsets_host, n->grid_workspace, n->grid_workspace_bytes, stream);
     if (rc != FOC_OK) return rc;
-    rc = foc_ffmlp_forward_planar(n->planes, n->w_sigma, M, n->sigma_input_dim, 16, n->sigma_hidden, n->sigma_layers, n->sigma_activation, n->sigma_output_activation,
-                                  n->h, stream);
-    if (rc != FOC_OK) return rc;
-    rc = foc_color_head_forward(n->h, n->sh_rows, 1, n->w_color, M, n->color_hidden, n->color_layers, n->color_activation, n->c, n->c_width, nullptr, stream);
-    if (rc != FOC_OK) return rc;
+    // both networks in one kernel when the shapes are FOC's (csrc/field_fwd.hip: bit for bit the two calls below)
+    const uint32_t lk = n->sigma_layers * 10 + n->color_layers;
+    if (n->sigma_input_dim == 32 && n->sigma_hidden == 64 && n->color_hidden == 64 && (lk == 22 || lk == 23 || lk == 33) &&
+        n->sigma_activation == n->color_activation && (n->sigma_activation == 0 || n->sigma_activation == 6) && n->sigma_output_activation == 6 &&
+        foc_opt(FOC_OPT_FIELD_FWD_FUSED)) {
+        rc = foc_field_forward_train(n->planes, n->w_sigma, n->sigma_layers, n->sh_rows, 1, n->w_color, n->color_layers, 64, n->sigma_activation, M, n->h, n->c,
+                                     n->c_width, nullptr, stream);
+        if (rc != FOC_OK) return rc;
+    } else {
+        rc = foc_ffmlp_forward_planar(n->planes, n->w_sigma, M, n->sigma_input_dim, 16, n->sigma_hidden, n->sigma_layers, n->sigma_activation, n->sigma_output_activation,
+                                      n->h, stream);
+        if (rc != FOC_OK) return rc;
+        rc = foc_color_head_forward(n->h, n->sh_rows, 1, n->w_color, M, n->color_hidden, n->color_layers, n->color_activation, n->c, n->c_width, nullptr, stream);
+        if (rc != FOC_OK) return rc;
+    }
     return foc_occ_tail_forward(n->h, n->c, n->c_width, n->deltas, n->rays, M, n->n_rays, n->T_thresh, n->density_scale, n->bg_ray, n->bg_scalar, n->nears, n->fars,
                                 n->weights_sum, n->image_raw, n->image, n->depth, stream);
 }

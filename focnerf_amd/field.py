@@ -99,11 +99,24 @@ def scope_cached(key, owner, make):
     return v
 
 
+def colour_forward_fusable(sigma_net, color_net, obj=False):
+    """Shapes `foc_field_forward_train` serves (csrc/field_fwd.hip): both networks' training forward in one kernel — bit for bit
+    `foc_ffmlp_forward_planar` + `foc_color_head_forward`. FOC_FUSED_FWD=0: the two calls (parity aid)."""
+    return (isinstance(sigma_net, FFMLP) and isinstance(color_net, FFMLP) and sigma_net.input_dim == 32 and sigma_net.hidden_dim == 64
+            and color_net.hidden_dim == 64 and color_net.input_dim == (48 if obj else 32) and sigma_net.padded_output_dim == 16
+            and (sigma_net.num_layers, color_net.num_layers) in ((2, 2), (2, 3), (3, 3)) and sigma_net.activation == color_net.activation
+            and sigma_net.activation in (0, 6) and sigma_net.output_activation == 6 and os.environ.get("FOC_FUSED_FWD", "1") != "0")
+
+
 class _hashgrid_mlp(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, x, embeddings, weights, offsets, enc_cfg, mlp_cfg, training):
+    def forward(ctx, x, embeddings, weights, offsets, enc_cfg, mlp_cfg, training, colour=None):
         # x [B,3] fp32 in [0,1]; embeddings [rows,2]; weights: FFMLP blob
+        # colour = (colour weights, ray_sh [B / T, 16] half, T, colour layers, c_width, obj_feat or None): the colour network's forward runs in the
+        # SAME kernel as the sigma network's (foc_field_forward_train) and its logits come back as a second, non-differentiable output — the
+        # node that owns the colour network (fixedstep._render_tail) takes them instead of launching foc_color_head_forward, and computes every
+        # gradient of the colour network in its own backward as before
         S, H, gridtype, align_corners, interp = enc_cfg
         input_dim, hidden_dim, num_layers, activation, output_activation = mlp_cfg
         x = x.contiguous().float()
@@ -118,16 +131,29 @@ class _hashgrid_mlp(Function):
         if ticket is None:
             _gridencoder.grid_encode_forward(x, emb, offsets, enc, B, 3, 2, L, S, H, None, gridtype, align_corners, interp)
         h = torch.empty(B, 16, device=x.device, dtype=torch.half)
-        _ffmlp.ffmlp_forward_planar(enc, w, B, input_dim, 16, hidden_dim, num_layers, activation, output_activation, h)
+        c = None
+        if colour is not None:
+            from ._lib import lib, ptr, stream_of, check
+            cweights, ray_sh, T, c_layers, c_width, obj_feat = colour
+            wc = _half_of(cweights)
+            obj16 = obj_feat.detach().reshape(-1).half().contiguous() if obj_feat is not None else None
+            c = torch.empty(B, c_width, device=x.device, dtype=torch.half)
+            check(lib.foc_field_forward_train(ptr(enc), ptr(w), num_layers, ptr(ray_sh), int(T), ptr(wc), int(c_layers), 64, int(activation), B, ptr(h), ptr(c),
+                                              int(c_width), ptr(obj16), stream_of(enc)), "field_forward_train")
+        else:
+            _ffmlp.ffmlp_forward_planar(enc, w, B, input_dim, 16, hidden_dim, num_layers, activation, output_activation, h)
         if training:
             ctx.save_for_backward(x, emb, w, offsets, enc)
             ctx.cfg = (enc_cfg, mlp_cfg, B, L)
             ctx.ticket = ticket
-        return h
+        if c is None:
+            return h
+        ctx.mark_non_differentiable(c)
+        return h, c
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, grad_h):
+    def backward(ctx, grad_h, _grad_c=None):
         x, emb, w, offsets, enc = ctx.saved_tensors
         (S, H, gridtype, align_corners, interp), (input_dim, hidden_dim, num_layers, activation, output_activation), B, L = ctx.cfg
         grad_h = grad_h.contiguous().half()
@@ -137,7 +163,7 @@ class _hashgrid_mlp(Function):
         g_emb = torch.zeros_like(emb)
         _gridencoder.grid_encode_backward(g_enc, x, emb, offsets, g_emb, B, 3, 2, L, S, H, None, None, gridtype, align_corners, interp, grad_bl=False,
                                           precount=ctx.ticket)
-        return None, g_emb, g_w, None, None, None, None
+        return None, g_emb, g_w, None, None, None, None, None
 
 
 def infer_fusable(model):

@@ -167,7 +167,9 @@ class _render_tail(Function):
 
     @staticmethod
     def forward(ctx, h, cweights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation, obj_feat=None,
-                want_sumsq=False):
+                want_sumsq=False, c_pre=None):
+        # c_pre [M,4] half: the colour logits already computed from this h, these weights and this ray_sh by the encoder -> sigma node's fused
+        # forward (field._hashgrid_mlp with `colour`, foc_field_forward_train: the bits foc_color_head_forward would give) — then no launch here
         from .field import _half_of
         h = h.contiguous()
         assert h.dtype == torch.float16 and h.shape == (N * T, 16)
@@ -176,13 +178,17 @@ class _render_tail(Function):
         st = stream_of(h)
         w16 = _half_of(cweights)
         # of the colour network's 16 padded outputs only the rgb logits are ever read: they travel as [M,4] rows (as does their gradient)
-        c = torch.empty(M, _C_WIDTH, dtype=torch.float16, device=dev)
         obj16 = None
         if obj_feat is not None:
             obj16 = obj_feat.detach().reshape(-1).half().contiguous()
             assert obj16.numel() == 16 and w16.numel() == 64 * (48 + 64 * (int(num_layers) - 1) + 16)
-        check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), _C_WIDTH, ptr(obj16), st),
-              "color_head_forward")
+        if c_pre is not None:
+            assert c_pre.dtype == torch.float16 and c_pre.shape == (M, _C_WIDTH) and c_pre.is_contiguous()
+            c = c_pre
+        else:
+            c = torch.empty(M, _C_WIDTH, dtype=torch.float16, device=dev)
+            check(lib.foc_color_head_forward(ptr(h), ptr(ray_sh), T, ptr(w16), M, 64, int(num_layers), int(activation), ptr(c), _C_WIDTH, ptr(obj16), st),
+                  "color_head_forward")
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         trans = torch.empty(M, dtype=torch.float32, device=dev)
         weights = torch.empty(M, dtype=torch.float32, device=dev)
@@ -232,7 +238,7 @@ class _render_tail(Function):
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
                                           ptr(g_w), ptr(wsb), _C_WIDTH, ptr(obj16), ptr(g_obj32), st), "color_head_backward")
         g_obj = g_obj32.to(obj_dtype).view(obj_shape) if g_obj32 is not None else None
-        return (grad_h, g_w) + (None,) * 12 + (g_obj, None)
+        return (grad_h, g_w) + (None,) * 12 + (g_obj, None, None)
 
 
 class _masked_norm(Function):
@@ -319,24 +325,31 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
         return results
 
     enc = model.encoder
-    from .field import field_fusable, _hashgrid_mlp
+    from .field import field_fusable, _hashgrid_mlp, colour_forward_fusable
+    c_pre = obj_feat = None
+    uses_obj = getattr(model, "uses_object_feature", False)
     with torch.autocast("cuda", dtype=torch.float16):
+        if uses_obj:                                                      # FOC network (network_foc.py): encoded YOLO feature in the colour input
+            obj_feat = model.encode_object_feature(yolo_details, dev)
         if field_fusable(enc, model.sigma_net):
             import numpy as np
             mlp = model.sigma_net
+            # with the fused tail the colour network's forward rides in the sigma network's kernel (its logits reach _render_tail as `c_pre`)
+            colour = None
+            if want_tail and colour_forward_fusable(mlp, model.color_net, uses_obj):
+                colour = (model.color_net.weights, ray_sh, T, model.color_net.num_layers, _C_WIDTH, obj_feat)
             h = _hashgrid_mlp.apply(enc_in, enc.embeddings, mlp.weights, enc.offsets,
                                     (float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners, enc.interp_id),
                                     (mlp.input_dim, mlp.hidden_dim, mlp.num_layers, mlp.activation, mlp.output_activation),
-                                    mlp.training and torch.is_grad_enabled())
+                                    mlp.training and torch.is_grad_enabled(), colour)
+            if colour is not None:
+                h, c_pre = h
         else:
             feats = grid_encode(enc_in, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, enc.gridtype_id,
                                 enc.align_corners, enc.interp_id)
             h = model.sigma_net(feats)                                    # [M,16] half
         if h.shape[1] != 16:                                              # FFMLP slices to output_dim (= 16 here: 1 + geo_feat_dim 15)
             raise RuntimeError("render_fixed_steps expects a 16-wide sigma head (1 + geo_feat_dim = 16)")
-        obj_feat = None
-        if getattr(model, "uses_object_feature", False):                  # FOC network (network_foc.py): encoded YOLO feature in the colour input
-            obj_feat = model.encode_object_feature(yolo_details, dev)
         fused_tail = want_tail
         # nerf/renderer.py:163-165: in training with an object mask, the norm of the densities of the rays outside it
         want_crit = model.training and yolo_details is not None and yolo_details[0] is not None
@@ -345,7 +358,7 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
             cn = model.color_net
             bg_ray, bg_scalar = _background(bg_color, N, dev)
             outs = _render_tail.apply(h, cn.weights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, model.density_scale, weight_thresh,
-                                      cn.num_layers, cn.activation, obj_feat, want_crit and yolo_details[0].numel() == N)
+                                      cn.num_layers, cn.activation, obj_feat, want_crit and yolo_details[0].numel() == N, c_pre)
             image, weights_sum, depth, sigma, weights, c = outs[:6]
             if len(outs) == 7:
                 # a per-ray mask: the samples' sum of sigma^2 comes out of the tail kernel (no [M]-sized torch expression, no boolean-mask

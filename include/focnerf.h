@@ -45,7 +45,7 @@ int         foc_abi_version(void);
 /* Thread-local message of the last non-zero return on this thread ("" if none). */
 const char *foc_last_error(void);
 /* Tuning / test switches (csrc/common.h FocOpt): ints with a default, initialised once from the environment variable of the same name
- * (FOC_MLP_BWD_FUSED, FOC_GB_MERGE_MAX_RES, FOC_GB_FACTORED, FOC_GB_TAIL_SPLIT, FOC_GRID_FUSE_SMALL, FOC_GRID_PAIRS, FOC_GRID_FAST,
+ * (FOC_MLP_BWD_FUSED, FOC_FIELD_FWD_FUSED, FOC_GB_MERGE_MAX_RES, FOC_GB_FACTORED, FOC_GB_TAIL_SPLIT, FOC_GRID_FUSE_SMALL, FOC_GRID_PAIRS, FOC_GRID_FAST,
  * FOC_MARCH_SERIAL, FOC_MARCH_RAYS_ROW_MAX, FOC_OCC_MARCH_FORM, FOC_OCC_SAMPLE_MAJOR, FOC_OCC_FIELD_PIECE — INTEGRATION.md has the table)
  * and changeable at run time; no entry point reads the environment per call. Unknown name: FOC_E_INVALID. */
 int foc_set_option(const char *name, int value);
@@ -428,6 +428,17 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
                             const void *grad_h0, const void *weights, uint32_t B, uint32_t hidden_dim,
                             uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights,
                             void *workspace, uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream);
+
+/* The TRAINING forward of the whole field in ONE kernel (csrc/field_fwd.hip): foc_ffmlp_forward_planar on the encoder's planes ->
+ * h [B,16] fp16 (written: the compositing tail and the backward read it) -> foc_color_head_forward fed from h and ray_sh, back to back in
+ * registers — nerf/network_ff.py:51-75 as ffmlp.cu:331-407 evaluates it twice. Results are BIT FOR BIT those of the two separate calls
+ * (same operands in the same k positions and order for every MFMA); h is not read back for the colour network (-32 B per sample, one
+ * launch). planes [16][B] half2 (input width 32), hidden_dim 64, (sigma_layers, color_layers) in {(2,2), (2,3), (3,3)}, activation relu(0) /
+ * none(6); ray_sh / samples_per_ray / out_width / obj_feat as foc_color_head_forward. The backward stays the two calls
+ * foc_color_head_backward -> foc_ffmlp_backward_planar (they re-evaluate the activations from h and the planes). */
+int foc_field_forward_train(const void *planes, const void *sigma_weights, uint32_t sigma_layers, const void *ray_sh, uint32_t samples_per_ray,
+                            const void *color_weights, uint32_t color_layers, uint32_t hidden_dim, uint32_t activation, uint32_t B,
+                            void *h, void *c, uint32_t out_width, const void *obj_feat, void *stream);
 
 /* ffmlp.cu:721-740  allocate_splitk(size) / free_splitk(): the reference creates side
  * streams for its CUTLASS split-K GEMMs. Weight gradients here are produced inside the

@@ -477,3 +477,39 @@ def test_occ_render_step_with_object_feature():
             results[sm] = (ws, dp, im)
     for a, b in zip(results["1"], results["0"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("nls,nlc", [(2, 2), (2, 3), (3, 3)])
+@pytest.mark.parametrize("out_width,T,with_obj,act", [(4, 512, False, 0), (16, 1, False, 0), (4, 7, True, 0), (16, 64, False, 6)])
+def test_field_forward_train_is_bitwise_the_two_calls(nls, nlc, out_width, T, with_obj, act):
+    """foc_field_forward_train (round 5, csrc/field_fwd.hip: sigma network on the planes -> h -> colour network fed from h and the per-ray SH rows, one
+    kernel) against foc_ffmlp_forward_planar + foc_color_head_forward: h AND the colour logits bit for bit — ragged batch (the last tile and the last
+    ray are partial), one SH row per sample / per 7 / per 512 samples, [B,4] and [B,16] logits, FOC's object feature, activation none. The colour
+    network's second k-chunk (columns 1..16 of the h row) is assembled from the accumulator tile with v_permlane32_swap instead of re-read from
+    memory: this test is what pins that exchange."""
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    g = torch.Generator(device="cuda").manual_seed(1000 * nls + 100 * nlc + T)
+    B = 40000 + 17
+    n_rays = (B + T - 1) // T
+    planes = ((torch.rand(16, B, 2, generator=g, device="cuda") - 0.5) * 2).half()
+    w_s = (torch.randn(64 * (32 + 64 * (nls - 1) + 16), generator=g, device="cuda") * 0.25).half()
+    ld0 = 48 if with_obj else 32
+    w_c = (torch.randn(64 * (ld0 + 64 * (nlc - 1) + 16), generator=g, device="cuda") * 0.25).half()
+    ray_sh = (torch.randn(n_rays, 16, generator=g, device="cuda") * 0.5).half()
+    obj = (torch.randn(16, generator=g, device="cuda") * 0.8).half() if with_obj else None
+    st = stream_of(planes)
+    h1 = torch.empty(B, 16, dtype=torch.float16, device="cuda")
+    c1 = torch.full((B, out_width), 3.0, dtype=torch.float16, device="cuda")
+    check(lib.foc_ffmlp_forward_planar(ptr(planes), ptr(w_s), B, 32, 16, 64, nls, act, 6, ptr(h1), st), "sigma forward")
+    check(lib.foc_color_head_forward(ptr(h1), ptr(ray_sh), T, ptr(w_c), B, 64, nlc, act, ptr(c1), out_width, ptr(obj), st), "colour forward")
+    h2 = torch.full((B + 8, 16), 5.0, dtype=torch.float16, device="cuda")
+    c2 = torch.full((B + 8, out_width), 5.0, dtype=torch.float16, device="cuda")
+    check(lib.foc_field_forward_train(ptr(planes), ptr(w_s), nls, ptr(ray_sh), T, ptr(w_c), nlc, 64, act, B, ptr(h2), ptr(c2), out_width, ptr(obj), st), "fused forward")
+    torch.cuda.synchronize()
+    assert torch.all(h2[B:] == 5.0) and torch.all(c2[B:] == 5.0), "rows past B were written"
+    assert h1.float().abs().max() > 0.5 and c1.float().abs().max() > 0.1, "degenerate test data"
+    assert torch.equal(h2[:B].view(torch.int16), h1.view(torch.int16)), "h differs from foc_ffmlp_forward_planar"
+    assert torch.equal(c2[:B].view(torch.int16), c1.view(torch.int16)), "colour logits differ from foc_color_head_forward"
+    # refusals on the host
+    assert lib.foc_field_forward_train(ptr(planes), ptr(w_s), 4, ptr(ray_sh), T, ptr(w_c), 3, 64, 0, B, ptr(h2), ptr(c2), out_width, None, st) == 1
+    assert lib.foc_field_forward_train(ptr(planes), ptr(w_s), 2, ptr(ray_sh), T, ptr(w_c), 3, 32, 0, B, ptr(h2), ptr(c2), out_width, None, st) == 1

@@ -8,7 +8,7 @@ cd "$R/focnerf_amd/csrc"
 obj=/tmp/foc_variant_${name}.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-pass-failed "$@" -c "$src" -o "$obj"
 objs=""
-for o in raymarching gridencoder gridencoder_nd freqencoder ffmlp ffmlp_wide combine fixedstep head densitygrid occrender occtrain; do
+for o in raymarching gridencoder gridencoder_nd freqencoder ffmlp ffmlp_wide field_fwd combine fixedstep head densitygrid occrender occtrain; do
   if [ "$o.hip" = "$src" ]; then objs="$objs $obj"; else objs="$objs _obj/$o.o"; fi
 done
 mkdir -p "$R/_ab"
