@@ -428,10 +428,13 @@ __global__ void __launch_bounds__(256) k_mlp_dw_finalize(const float *__restrict
 // and keeps them in registers in the chained layout: they are the ReLU masks as they are, and are written into the LDS A tiles
 // where the stored form loads them from HBM. Traffic: grad + inputs (+ grad_inputs), 0.1-0.16 KB/sample. The next group's grad
 // and input rows are fetched while the current group is processed.
-template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE, bool RELU_CT, bool IN32 = false>
+// LEAN (round 5): no backward_buffer and input gradients wanted, both as compile-time facts — what every training step asks for. With the runtime
+// pointers each stage carried a cold stored-form block, guarded stores and a runtime dX loop: a dozen branches per group, and nothing is scheduled
+// across a branch (k_field_fwd_train lost a factor 1.2 to exactly that, NOTEBOOK 5.4).
+template <int HIDDEN, int NL, int NB, bool RECOMP, int IMODE, bool RELU_CT, bool IN32 = false, bool LEAN = false>
 __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *__restrict__ grad, const _Float16 *__restrict__ inputs,
                                                              const _Float16 *__restrict__ weights, const _Float16 *__restrict__ fwd_buf,
-                                                             _Float16 *__restrict__ bwd_buf, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
+                                                             _Float16 *__restrict__ bwd_buf_arg, _Float16 *__restrict__ grad_inputs, float *__restrict__ ws,
                                                              uint32_t B, uint32_t in_dim, int relu_rt, uint32_t lds_w_halfs, MlpHead hd) {
     // RELU_CT: the activation as a compile-time fact (every NeRF network is ReLU): with the runtime flag the compiler evaluated BOTH forms of
     // every activation / gate and selected per register (224 v_cndmask per 128 rows); `false` keeps the runtime flag (activation 'none')
@@ -446,7 +449,8 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
     static_assert(!HEAD || RECOMP, "the head input modes have no stored-activation form");
     constexpr int WD = (HIDDEN < 32 ? 32 : HIDDEN) + 8;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    const bool with_dx = grad_inputs != nullptr;
+    const bool with_dx = LEAN ? true : grad_inputs != nullptr;
+    _Float16 *const bwd_buf = LEAN ? nullptr : bwd_buf_arg;
     // row width of W0 in the blob and in the weight-gradient workspace: in_dim, or 48 for the colour head with an object feature (MlpHead)
     uint32_t ld0 = in_dim;
     bool has_obj = false;
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const uint32_t MT0 = (in_dim + 31) / 32;
+    const uint32_t MT0 = (HEAD || IN32) ? 1u : (in_dim + 31) / 32;
     const uint32_t f_hidden = MT, f_dx = MT + (NL - 1) * MT * KC;
     _Float16 *myD = sD + wave * RW * WD, *myA = sA + wave * RW * WA;
 
@@ -560,7 +564,9 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) x_cur[1][nb] = head_shift(__builtin_bit_cast(u32x4, x_nxt[1][nb]), h == 0 ? hx_nxt[nb] : 0u);
             }
-            if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
+            // (LEAN: the last group fetches itself again instead of branching around the loads)
+            if (LEAN) fetch_group(min(grp + gridDim.x, n_groups - 1u));
+            else if (grp + gridDim.x < n_groups) fetch_group(grp + gridDim.x);
             // ---- forward re-evaluation: layer 0 from the inputs, hidden layers chained (k_mlp_fwd's order of operations)
             // The colour head's layer 0 starts from the object feature's share (a constant per neuron) when there is one, else — like every other
             // input mode — from the inline-constant zero of the chain's first MFMA. Two wave-uniform branches: as ONE code path the start value was a
@@ -790,7 +796,7 @@ __global__ void __launch_bounds__(MLP_BLOCK, 2) k_mlp_bwd_fused(const _Float16 *
 #ifdef FOC_TIMING_NO_DW
                 if (B == 0xFFFFFFFFu)                      // timing build: the weight-gradient section never runs
 #endif
-                if (wave < ntile * ksplit) {
+                if (HIDDEN == 64 || wave < ntile * ksplit) {       // hidden 64: every stage has 4 (tile, batch half) pairs, one per wave
                     // The MFMA sections (weight gradients, then the delta chain) run at raised issue priority: the other wave on this SIMD belongs to
                     // the other workgroup and is somewhere else in its group — when both can issue, the one feeding the matrix pipe goes first and
                     // the other one's conversions / LDS writes fill the gaps. rocprofv3 averages, same box: 186.6 + 141.7 -> 181.2 + 139.7 us
@@ -1360,12 +1366,18 @@ static int mlp_bwd_fused_launch(const void *grad, const void *inputs, const void
     auto kern = recomp ? (planar ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, false>)
                                  : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, false>))
                        : k_mlp_bwd_fused<HIDDEN, NL, NB, false, 0, false>;
+    const bool lean = !bwd_buf && dx;
     if constexpr (HIDDEN == 64) {
-        if (recomp && relu && in_dim <= 32 && !head) kern = planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true, true>;
+        if (recomp && relu && in_dim <= 32 && !head) {
+            if (lean) kern = planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true, true, true>;
+            else kern = planar ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 1, true, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 0, true, true>;
+        }
     }
     if constexpr (HIDDEN == 64 && NL <= 3) {
-        if (head) kern = head->out_width == 4u ? (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, false>)
-                                               : (relu ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>);
+        if (head) kern = head->out_width == 4u ? (relu ? (lean ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, true, false, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, true>)
+                                                       : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 3, false>)
+                                               : (relu ? (lean ? k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true, false, true> : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, true>)
+                                                       : k_mlp_bwd_fused<HIDDEN, NL, NB, true, 2, false>);
     }
     else FOC_REQUIRE(!head, FOC_E_INVALID, "color_head_backward: hidden_dim must be 64 and num_layers 2 or 3");
     if (lds_launch > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
