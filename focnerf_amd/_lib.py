@@ -55,6 +55,7 @@ class FocOccTrainNode(ctypes.Structure):
         ("grad_image", c_vp), ("grad_ws", c_vp),
         ("grad_c", c_vp), ("grad_h0", c_vp), ("grad_h", c_vp), ("grad_planes", c_vp), ("grad_w_color", c_vp), ("grad_w_sigma", c_vp),
         ("grad_embeddings", c_vp), ("mlp_workspace", c_vp),
+        ("mlp_workspace_bytes", u64),
     ]
 
 
@@ -117,10 +118,10 @@ SIGNATURES = {
     "foc_ffmlp_forward": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_ffmlp_inference": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp, c_vp]),
     "foc_ffmlp_backward": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32,
-                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                 c_vp, c_vp, c_vp, c_vp, u64, c_vp]),
     "foc_ffmlp_backward_workspace_bytes": (u64, [u32, u32, u32]),
     "foc_ffmlp_forward_planar": (i32, [c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, c_vp, c_vp]),
-    "foc_ffmlp_backward_planar": (i32, [c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32, c_vp, c_vp, c_vp, c_vp]),
+    "foc_ffmlp_backward_planar": (i32, [c_vp, c_vp, c_vp, u32, u32, u32, u32, u32, u32, u32, i32, c_vp, c_vp, c_vp, u64, c_vp]),
     "foc_allocate_splitk": (i32, [u64]),
     "foc_free_splitk": (i32, []),
     "foc_combine_select": (i32, [c_vp, c_vp, c_vp, c_vp, u64, c_vp]),
@@ -137,7 +138,7 @@ SIGNATURES = {
     "foc_fixed_head_backward": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, u32, c_vp]),
     "foc_color_head_forward": (i32, [c_vp, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, u32, c_vp, c_vp]),
     "foc_field_forward_train": (i32, [c_vp, c_vp, u32, c_vp, u32, c_vp, u32, u32, u32, u32, c_vp, c_vp, u32, c_vp, c_vp]),
-    "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u32, c_vp, c_vp, c_vp]),
+    "foc_color_head_backward": (i32, [c_vp, c_vp, c_vp, u32, c_vp, c_vp, u32, u32, u32, u32, c_vp, c_vp, c_vp, u64, u32, c_vp, c_vp, c_vp]),
     "foc_fixed_composite_forward": (i32, [c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp]),
     "foc_fixed_composite_backward": (i32, [c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_sample_head_forward": (i32, [c_vp, c_vp, u64, c_vp, c_vp, c_vp, u32, c_vp]),

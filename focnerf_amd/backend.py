@@ -327,10 +327,11 @@ class _ffmlp:
                        calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
         ts = (grad, inputs, weights, forward_buffer, backward_buffer, grad_inputs, grad_weights)
         require_cuda(*ts); _half(*ts); _contig(*ts)
-        ws = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), grad.device)
+        ws_bytes = lib.foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers)
+        ws = _scratch.get("ffmlp_ws", ws_bytes, grad.device)
         check(lib.foc_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim, output_dim, hidden_dim, num_layers,
                                      activation, output_activation, int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
-                                     ptr(grad_weights), ptr(ws), stream_of(grad)), "ffmlp_backward")
+                                     ptr(grad_weights), ptr(ws), ws.numel(), stream_of(grad)), "ffmlp_backward")
 
     @staticmethod
     def ffmlp_forward_planar(inputs_planar, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, outputs):
@@ -347,7 +348,7 @@ class _ffmlp:
         ws = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), grad.device)
         check(lib.foc_ffmlp_backward_planar(ptr(grad), ptr(inputs_planar), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
                                             activation, output_activation, int(bool(calc_grad_inputs)), ptr(grad_inputs_planar),
-                                            ptr(grad_weights), ptr(ws), stream_of(grad)), "ffmlp_backward_planar")
+                                            ptr(grad_weights), ptr(ws), ws.numel(), stream_of(grad)), "ffmlp_backward_planar")
 
     @staticmethod
     def allocate_splitk(size):

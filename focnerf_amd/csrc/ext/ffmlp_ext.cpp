@@ -17,9 +17,10 @@ void ffmlp_inference(const at::Tensor inputs, const at::Tensor weights, const ui
 }
 void ffmlp_backward(const at::Tensor grad, const at::Tensor inputs, const at::Tensor weights, const at::Tensor forward_buffer, const uint32_t B, const uint32_t input_dim, const uint32_t output_dim, const uint32_t hidden_dim, const uint32_t num_layers, const uint32_t activation, const uint32_t output_activation, const bool calc_grad_inputs, at::Tensor backward_buffer, at::Tensor grad_inputs, at::Tensor grad_weights) {
     check_half({&grad, &inputs, &weights, &forward_buffer, &backward_buffer, &grad_inputs, &grad_weights});
-    void *ws = foc_scratch("ffmlp_ws", foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), grad);
+    const uint64_t ws_bytes = foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers);
+    void *ws = foc_scratch("ffmlp_ws", ws_bytes, grad);
     foc_ok(foc_ffmlp_backward(grad.data_ptr(), inputs.data_ptr(), weights.data_ptr(), forward_buffer.data_ptr(), B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                              calc_grad_inputs ? 1 : 0, backward_buffer.data_ptr(), grad_inputs.data_ptr(), grad_weights.data_ptr(), ws, foc_stream(grad)), "ffmlp_backward");
+                              calc_grad_inputs ? 1 : 0, backward_buffer.data_ptr(), grad_inputs.data_ptr(), grad_weights.data_ptr(), ws, ws_bytes, foc_stream(grad)), "ffmlp_backward");
 }
 void allocate_splitk(size_t size) { foc_ok(foc_allocate_splitk((uint64_t)size), "allocate_splitk"); }
 void free_splitk() { foc_ok(foc_free_splitk(), "free_splitk"); }

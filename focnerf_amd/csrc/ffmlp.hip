@@ -1509,7 +1509,8 @@ uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_
 
 static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                          uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
-                         int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, int planar, void *stream) {
+                         int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, uint64_t workspace_bytes, int planar,
+                         void *stream) {
     // backward_buffer may be NULL: the fused kernel keeps activation gradients on chip; forward_buffer may be NULL: the fused kernel
     // then re-evaluates the activations from the inputs (the two-kernel path checks both again)
     int rc = mlp_check("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation);
@@ -1522,6 +1523,10 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
     }
     FOC_REQUIRE(grad && inputs && weights && grad_weights && workspace, FOC_E_INVALID, "ffmlp_backward: null pointer");
     FOC_REQUIRE(!calc_grad_inputs || grad_inputs, FOC_E_INVALID, "ffmlp_backward: calc_grad_inputs set but grad_inputs is null");
+    FOC_REQUIRE(workspace_bytes >= foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers), FOC_E_INVALID,
+                "ffmlp_backward: workspace of %llu bytes, foc_ffmlp_backward_workspace_bytes(%u, %u, %u) asks for %llu (ABI 2: blob image + per-workgroup slots)",
+                (unsigned long long)workspace_bytes, input_dim, hidden_dim, num_layers,
+                (unsigned long long)foc_ffmlp_backward_workspace_bytes(input_dim, hidden_dim, num_layers));
     const int relu = (int)activation;                     // the reference's activation code (0 = ReLU ... 6 = None), handed on as it is
     hipStream_t st = (hipStream_t)stream;
     void *gi = calc_grad_inputs ? grad_inputs : nullptr;
@@ -1543,10 +1548,11 @@ static int mlp_bwd_entry(const void *grad, const void *inputs, const void *weigh
 
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights, const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
-                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, void *stream) {
+                       int calc_grad_inputs, void *backward_buffer, void *grad_inputs, void *grad_weights, void *workspace, uint64_t workspace_bytes,
+                       void *stream) {
     FocDeviceGuard foc_guard_(stream, grad);
     return mlp_bwd_entry(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                         calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, 0, stream);
+                         calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, workspace, workspace_bytes, 0, stream);
 }
 
 int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -1557,10 +1563,10 @@ int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uin
 
 int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                               uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
-                              void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream) {
+                              void *grad_inputs_planar, void *grad_weights, void *workspace, uint64_t workspace_bytes, void *stream) {
     FocDeviceGuard foc_guard_(stream, grad);
     return mlp_bwd_entry(grad, inputs_planar, weights, nullptr, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                         calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, 1, stream);
+                         calc_grad_inputs, nullptr, grad_inputs_planar, grad_weights, workspace, workspace_bytes, 1, stream);
 }
 
 int foc_nerf_field_inference(const void *enc, int enc_planar, const float *dirs, uint32_t dir_div, uint32_t dir_block, uint32_t n_dirs,
@@ -1602,7 +1608,7 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
 
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray, const void *grad_h0, const void *weights,
                             uint32_t B, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights, void *workspace,
-                            uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream) {
+                            uint64_t workspace_bytes, uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream) {
     FocDeviceGuard foc_guard_(stream, grad);
     int rc = mlp_check("color_head_backward", B, 32, 16, hidden_dim, num_layers, activation, 6);
     if (rc) return rc;
@@ -1616,6 +1622,10 @@ int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh,
         return FOC_OK;
     }
     FOC_REQUIRE(grad && h && ray_sh && weights && grad_h && grad_weights && workspace, FOC_E_INVALID, "color_head_backward: null pointer");
+    // with an object feature the slots start behind a 48-wide blob image: the buffer must have been sized for input_dim 48
+    FOC_REQUIRE(workspace_bytes >= foc_ffmlp_backward_workspace_bytes(obj_feat ? HEAD_OBJ_LD : 32u, 64, num_layers), FOC_E_INVALID,
+                "color_head_backward: workspace of %llu bytes, foc_ffmlp_backward_workspace_bytes(%u, 64, %u) asks for %llu", (unsigned long long)workspace_bytes,
+                obj_feat ? HEAD_OBJ_LD : 32u, num_layers, (unsigned long long)foc_ffmlp_backward_workspace_bytes(obj_feat ? HEAD_OBJ_LD : 32u, 64, num_layers));
     FOC_REQUIRE(out_width == 16 || out_width == 4, FOC_E_INVALID, "color_head_backward: out_width must be 16 or 4 (got %u)", out_width);
     FOC_REQUIRE(activation == FOC_ACT_RELU || activation == FOC_ACT_NONE, FOC_E_INVALID, "color_head_backward: hidden activation must be relu(0) or none(6)");
     const MlpHead hd{(const _Float16 *)ray_sh, (const _Float16 *)grad_h0, samples_per_ray, out_width, (const _Float16 *)obj_feat};

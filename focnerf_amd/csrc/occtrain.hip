@@ -263,10 +263,10 @@ int foc_occ_train_backward(const FocOccTrainNode *n, void *stream) {
                                n->density_scale, n->bg_ray, n->bg_scalar, n->grad_c, n->grad_h0, stream);
     if (rc != FOC_OK) return rc;
     rc = foc_color_head_backward(n->grad_c, n->h, n->sh_rows, 1, n->grad_h0, n->w_color, M, n->color_hidden, n->color_layers, n->color_activation, n->grad_h,
-                                 n->grad_w_color, n->mlp_workspace, n->c_width, nullptr, nullptr, stream);
+                                 n->grad_w_color, n->mlp_workspace, n->mlp_workspace_bytes, n->c_width, nullptr, nullptr, stream);
     if (rc != FOC_OK) return rc;
     rc = foc_ffmlp_backward_planar(n->grad_h, n->planes, n->w_sigma, M, n->sigma_input_dim, 16, n->sigma_hidden, n->sigma_layers, n->sigma_activation,
-                                   n->sigma_output_activation, 1, n->grad_planes, n->grad_w_sigma, n->mlp_workspace, stream);
+                                   n->sigma_output_activation, 1, n->grad_planes, n->grad_w_sigma, n->mlp_workspace, n->mlp_workspace_bytes, stream);
     if (rc != FOC_OK) return rc;
     return (n->precounted ? foc_grid_encode_backward_binned_counted : foc_grid_encode_backward_binned)(
         n->grad_planes, n->enc_in, n->embeddings, n->offsets, n->grad_embeddings, M, 3, 2, n->levels, n->per_level_scale_log2, n->base_resolution, nullptr, nullptr,

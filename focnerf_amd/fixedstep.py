@@ -236,7 +236,7 @@ class _render_tail(Function):
         wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(48 if has_obj else 32, 64, num_layers), dev)
         g_obj32 = torch.empty(16, dtype=torch.float32, device=dev) if has_obj and ctx.needs_input_grad[14] else None
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
-                                          ptr(g_w), ptr(wsb), _C_WIDTH, ptr(obj16), ptr(g_obj32), st), "color_head_backward")
+                                          ptr(g_w), ptr(wsb), wsb.numel(), _C_WIDTH, ptr(obj16), ptr(g_obj32), st), "color_head_backward")
         g_obj = g_obj32.to(obj_dtype).view(obj_shape) if g_obj32 is not None else None
         return (grad_h, g_w) + (None,) * 12 + (g_obj, None, None)
 

@@ -197,7 +197,7 @@ class _occ_train(Function):
             nd.grad_image, nd.grad_ws = _a(g_image), _a(g_ws)
             nd.grad_c, nd.grad_h0, nd.grad_h = gblock.data_ptr(), gblock.data_ptr() + 2 * M * _C_WIDTH, _a(grad_h)
             nd.grad_planes, nd.grad_w_color, nd.grad_w_sigma, nd.grad_embeddings = _a(g_planes), _a(g_wcol), _a(g_wsig), _a(g_emb)
-            nd.mlp_workspace, nd.grid_workspace, nd.grid_workspace_bytes = _a(mws), _a(gws), ctx.plan[0]
+            nd.mlp_workspace, nd.mlp_workspace_bytes, nd.grid_workspace, nd.grid_workspace_bytes = _a(mws), mws.numel(), _a(gws), ctx.plan[0]
             nd.precounted = int(_gridencoder._precount_valid(ctx.ticket, enc_in, M, L, FOC_F16, gws))
             check(lib.foc_occ_train_backward(ctypes.byref(nd), st), "occ_train_backward")
             _gridencoder._invalidate_precount(dev)          # the header now belongs to this pass (and a used ticket is spent)
@@ -210,7 +210,7 @@ class _occ_train(Function):
         grad_h = torch.empty_like(h)
         wsb = _scratch.get("ffmlp_ws", lib.foc_ffmlp_backward_workspace_bytes(32, 64, int(col_cfg[0])), dev)
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(sh), 1, ptr(grad_h0), ptr(wc16), M, 64, int(col_cfg[0]), int(col_cfg[1]), ptr(grad_h), ptr(g_wcol),
-                                          ptr(wsb), _C_WIDTH, None, None, st), "color_head_backward")
+                                          ptr(wsb), wsb.numel(), _C_WIDTH, None, None, st), "color_head_backward")
         g_planes = torch.empty_like(planes)
         _ffmlp.ffmlp_backward_planar(grad_h, planes, ws16, M, sig_cfg[0], 16, sig_cfg[1], sig_cfg[2], sig_cfg[3], 6, True, g_planes, g_wsig)
         _gridencoder.grid_encode_backward(g_planes, enc_in, emb16, offsets, g_emb, M, 3, 2, L, S, H, None, None, gridtype, align_corners, interp, grad_bl=False,

@@ -39,7 +39,8 @@ extern "C" {
  *   2 (round 5): the workspace of foc_ffmlp_backward / _backward_planar / foc_color_head_backward is
  *     [fp32 image of the weight blob | one slot of partial weight-gradient tiles per workgroup of the launch], written without a zero fill and
  *     tens of MB large — a buffer sized by version 1's blob formula (input_dim, hidden_dim, num_layers -> ~50 KB) is too small: size it with
- *     foc_ffmlp_backward_workspace_bytes(); input_dim up to 256 at every hidden width. */
+ *     foc_ffmlp_backward_workspace_bytes(); the three entry points take the buffer's size (`workspace_bytes`) and refuse one that is too small;
+ *     FocOccTrainNode carries `mlp_workspace_bytes`; foc_field_forward_train is new; input_dim up to 256 at every hidden width. */
 #define FOC_ABI_VERSION 2
 int         foc_abi_version(void);
 /* Thread-local message of the last non-zero return on this thread ("" if none). */
@@ -364,14 +365,15 @@ int foc_ffmlp_inference(const void *inputs, const void *weights, uint32_t B, uin
  * [fp32 image of the weight blob: the split-K sums of the two-kernel form, the object-conditioned head's finalize] followed, for the shapes
  * the single-pass kernel serves (hidden_dim <= 64, input_dim <= 64, 2..4 layers), by up to 1024 per-workgroup slots of
  * (num_layers + 1) x 4096 fp32 partial weight-gradient tiles that a second kernel sums in a fixed order (33 - 80 MB; the reference's CUTLASS
- * split-K workspace, cutlass_matmul.h:335-363, is a process-global map instead). Every caller queries the size; for the colour head with
- * an object feature ask for input_dim 48 (the slots start behind a 48-wide blob image). */
+ * split-K workspace, cutlass_matmul.h:335-363, is a process-global map instead). `workspace_bytes` = the size of the caller's buffer: a
+ * buffer smaller than foc_ffmlp_backward_workspace_bytes() is refused (FOC_E_INVALID) instead of being written past its end; for the colour
+ * head with an object feature ask for input_dim 48 (the slots start behind a 48-wide blob image). */
 int foc_ffmlp_backward(const void *grad, const void *inputs, const void *weights,
                        const void *forward_buffer, uint32_t B, uint32_t input_dim,
                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                        uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                        void *backward_buffer, void *grad_inputs, void *grad_weights,
-                       void *workspace, void *stream);
+                       void *workspace, uint64_t workspace_bytes, void *stream);
 uint64_t foc_ffmlp_backward_workspace_bytes(uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
 
 /* Planar-input forms for the encoder -> MLP pair. `inputs_planar` is [input_dim/2][B] half2 planes: exactly the
@@ -386,7 +388,7 @@ int foc_ffmlp_forward_planar(const void *inputs_planar, const void *weights, uin
 int foc_ffmlp_backward_planar(const void *grad, const void *inputs_planar, const void *weights, uint32_t B,
                               uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                               uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
-                              void *grad_inputs_planar, void *grad_weights, void *workspace, void *stream);
+                              void *grad_inputs_planar, void *grad_weights, void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* Inference of the whole NeRF field per sample in one kernel (nerf/network_ff.py:51-75): sigma network on the hash-grid
  * encoding `enc` ([B,32] fp16 row-major, or the encoder's [16,B,2] planes when enc_planar), trunc_exp, degree-4 SH of the
@@ -427,7 +429,7 @@ int foc_color_head_forward(const void *h, const void *ray_sh, uint32_t samples_p
 int foc_color_head_backward(const void *grad, const void *h, const void *ray_sh, uint32_t samples_per_ray,
                             const void *grad_h0, const void *weights, uint32_t B, uint32_t hidden_dim,
                             uint32_t num_layers, uint32_t activation, void *grad_h, void *grad_weights,
-                            void *workspace, uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream);
+                            void *workspace, uint64_t workspace_bytes, uint32_t out_width, const void *obj_feat, float *grad_obj, void *stream);
 
 /* The TRAINING forward of the whole field in ONE kernel (csrc/field_fwd.hip): foc_ffmlp_forward_planar on the encoder's planes ->
  * h [B,16] fp16 (written: the compositing tail and the backward read it) -> foc_color_head_forward fed from h and ray_sh, back to back in
@@ -596,6 +598,7 @@ typedef struct FocOccTrainNode {
     int32_t precounted;
     const float *grad_image, *grad_ws;
     void *grad_c, *grad_h0, *grad_h, *grad_planes, *grad_w_color, *grad_w_sigma, *grad_embeddings, *mlp_workspace;
+    uint64_t mlp_workspace_bytes;       /* size of mlp_workspace: >= foc_ffmlp_backward_workspace_bytes() of both networks */
 } FocOccTrainNode;
 int foc_occ_train_forward(const FocOccTrainNode *node, void *stream);
 int foc_occ_train_backward(const FocOccTrainNode *node, void *stream);

@@ -52,6 +52,16 @@ def test_argument_validation_needs_no_gpu():
     assert rc == 1 and b"input_dim" in lib.foc_last_error()
     rc = lib.foc_freq_encode_forward(one, 4, 3, 4, 26, one, None)
     assert rc == 1
+    # ABI 2: the MLP backward's workspace travels with its size; a buffer sized by version 1's blob formula (~50 KB) is refused, not overrun
+    need = lib.foc_ffmlp_backward_workspace_bytes(32, 64, 2)
+    assert need > 10 * 1024 * 1024
+    rc = lib.foc_ffmlp_backward(one, one, one, None, 128, 32, 16, 64, 2, 0, 6, 1, None, one, one, one, 64 * (32 + 64 + 16) * 4, None)
+    assert rc == 1 and b"workspace of" in lib.foc_last_error()
+    rc = lib.foc_ffmlp_backward_planar(one, one, one, 128, 32, 16, 64, 2, 0, 6, 1, one, one, one, need - 1, None)
+    assert rc == 1 and b"workspace of" in lib.foc_last_error()
+    # the colour head with an object feature needs the 48-wide sizing: a buffer sized for 32 inputs is refused
+    rc = lib.foc_color_head_backward(one, one, one, 1, None, one, 128, 64, 2, 0, one, one, one, lib.foc_ffmlp_backward_workspace_bytes(32, 64, 2), 4, one, None, None)
+    assert rc == 1 and b"workspace of" in lib.foc_last_error()
 
 
 def test_occ_train_node_struct_matches_the_header_and_is_validated_on_the_host():

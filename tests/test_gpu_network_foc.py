@@ -90,7 +90,7 @@ def test_color_head_with_object_feature_vs_oracle(layers, out_width, T, N):
     g_w = torch.empty(n_w, dtype=torch.float16, device="cuda")
     g_obj = torch.empty(16, dtype=torch.float32, device="cuda")
     ws = torch.empty(lib.foc_ffmlp_backward_workspace_bytes(48, 64, layers), dtype=torch.uint8, device="cuda")
-    check(lib.foc_color_head_backward(ptr(grad), ptr(h), ptr(ray_sh), T, ptr(g_h0), ptr(W), B, 64, layers, 0, ptr(grad_h), ptr(g_w), ptr(ws), out_width,
+    check(lib.foc_color_head_backward(ptr(grad), ptr(h), ptr(ray_sh), T, ptr(g_h0), ptr(W), B, 64, layers, 0, ptr(grad_h), ptr(g_w), ptr(ws), ws.numel(), out_width,
                                       ptr(obj), ptr(g_obj), st), "bwd")
     torch.cuda.synchronize()
 

@@ -38,10 +38,10 @@ def main():
     st = stream_of(h)
 
     def sigma():
-        check(lib.foc_ffmlp_backward_planar(ptr(grad_h), ptr(planes), ptr(w_s), M, 32, 16, 64, 2, 0, 6, 1, ptr(gplanes), ptr(gw_s), ptr(ws_s), st), "sigma bwd")
+        check(lib.foc_ffmlp_backward_planar(ptr(grad_h), ptr(planes), ptr(w_s), M, 32, 16, 64, 2, 0, 6, 1, ptr(gplanes), ptr(gw_s), ptr(ws_s), ws_s.numel(), st), "sigma bwd")
 
     def colour():
-        check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w_c), M, 64, 3, 0, ptr(gh), ptr(gw_c), ptr(ws_c), 4, None, None, st),
+        check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w_c), M, 64, 3, 0, ptr(gh), ptr(gw_c), ptr(ws_c), ws_c.numel(), 4, None, None, st),
               "colour bwd")
     out = {"rows": M, "lib": os.path.basename(os.environ.get("FOCNERF_LIB_PATH", "libfocnerf_hip.so"))}
     for name, fn in (("sigma", sigma), ("colour", colour)):
