@@ -129,6 +129,7 @@ SIGNATURES = {
     "foc_combine_unpack": (i32, [c_vp, u32, c_vp, c_vp, c_vp, u64, c_vp]),
     "foc_combine_select_composite": (i32, [c_vp, u32, c_vp, c_vp, u32, u32, c_vp, u32, c_vp, c_vp, c_vp, c_vp]),
     "foc_combine_select4": (i32, [c_vp, c_vp, u64, c_vp]),
+    "foc_mo_select": (i32, [c_vp, c_vp, c_vp, c_vp, u64, u32, u32, c_vp]),
     "foc_fixed_field_pack": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, f32, u32, u32, f32, f32, c_vp, c_vp, c_vp, c_vp, u32, c_vp]),
     "foc_composite_fixed_steps": (i32, [c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp]),
     "foc_fixed_sample": (i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, u32, u32, f32, c_vp, c_vp, c_vp, u32, c_vp]),

@@ -102,6 +102,20 @@ class HipCombineOps:
         check(lib.foc_combine_select4(ptr(field4), ptr(acc4), field4.numel() // 4, stream_of(acc4)), "combine_select4")
 
 
+    @staticmethod
+    def mo_select(sigma_new, feat_new, sigma_best, feat_best):
+        """In place on (sigma_best [n], feat_best [n,w]): MONeRFNetwork's running max (multiobjectnetwork.py:66-82; the new object takes ties)."""
+        from ._lib import lib, ptr, stream_of, check, require_cuda
+        require_cuda(sigma_new, feat_new, sigma_best, feat_best)
+        ts = (sigma_new, feat_new, sigma_best, feat_best)
+        if (len({t.dtype for t in ts}) != 1 or sigma_new.dtype not in (torch.float16, torch.float32) or not all(t.is_contiguous() for t in ts)
+                or sigma_new.shape != sigma_best.shape or feat_new.shape != feat_best.shape or feat_new.dim() != sigma_new.dim() + 1
+                or feat_new.shape[:-1] != sigma_new.shape):
+            raise RuntimeError("mo_select: contiguous sigma [...], feat [..., w] pairs of one dtype (float16 or float32) expected")
+        check(lib.foc_mo_select(ptr(sigma_new), ptr(feat_new), ptr(sigma_best), ptr(feat_best), sigma_new.numel(), feat_new.shape[-1],
+                                sigma_new.element_size(), stream_of(sigma_best)), "mo_select")
+
+
 def composite_fixed_steps(sigmas, rgbs, nears, fars, bg, ops=HipCombineOps):
     """image_depth_generation of COMBINED.py:141-200: [N,T] sigmas, [N,T,3] rgbs -> image [N,4] (rgb + sum w*sigma, clamped), depth [N]."""
     return ops.composite(sigmas.contiguous().float(), rgbs.contiguous().float(), nears.contiguous().float(), fars.contiguous().float(), bg)

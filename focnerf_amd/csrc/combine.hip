@@ -190,6 +190,31 @@ __global__ void __launch_bounds__(256) k_combine_select4(const float4 *__restric
     }
 }
 
+// MONeRFNetwork's running select (nerf/multiobjectnetwork.py:66-82): torch.max over stack([new, best]) and take_along_dim of the rows that
+// travel with the density (geo_feat [n,15] or colour [n,3]). torch.max returns the FIRST maximal index and treats NaN as maximal, and the
+// new object is stacked first: the new object wins ties (the opposite of COMBINED.py's strict '>') and a NaN density of either side stays.
+// One wave per 64 samples: the lanes decide their sample, the ballot is the row mask, and the wave copies the 64 x width elements of the
+// taken rows as one contiguous run (rows are 30 or 6 bytes in fp16: no lane-per-row accesses).
+template <typename T>
+__global__ void __launch_bounds__(256) k_mo_select(const T *__restrict__ sig_new, const T *__restrict__ feat_new, T *__restrict__ sig_best,
+                                                   T *__restrict__ feat_best, uint64_t n, uint32_t width) {
+    const uint64_t s0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;          // wave-uniform
+    if (s0 >= n) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool take = false;
+    if (s0 + lane < n) {
+        const T a_raw = sig_new[s0 + lane];
+        const float a = (float)a_raw, b = (float)sig_best[s0 + lane];
+        take = (a != a) || (b == b && a >= b);
+        if (take) sig_best[s0 + lane] = a_raw;
+    }
+    const uint64_t rows = __ballot(take);
+    const uint32_t live = (uint32_t)(n - s0 < 64u ? n - s0 : 64u);
+    const uint64_t base = s0 * width;
+    for (uint32_t e = lane; e < live * width; e += 64u)
+        if ((rows >> (e / width)) & 1ull) feat_best[base + e] = feat_new[base + e];
+}
+
 // ---------------------------------------------------------------- options (common.h FocOpt)
 #include <stdlib.h>
 #include <string.h>
@@ -275,6 +300,25 @@ int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stre
     hipLaunchKernelGGL(k_combine_select4, dim3(foc_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(field4),
                        reinterpret_cast<float4 *>(acc4), n);
     FOC_CHECK_LAUNCH("combine_select4");
+    return FOC_OK;
+}
+
+int foc_mo_select(const void *sigma_new, const void *feat_new, void *sigma_best, void *feat_best, uint64_t n, uint32_t feat_width,
+                  uint32_t elem_bytes, void *stream) {
+    FocDeviceGuard foc_guard_(stream, sigma_new);
+    FOC_REQUIRE(elem_bytes == 2 || elem_bytes == 4, FOC_E_INVALID, "mo_select: elem_bytes must be 2 (half) or 4 (float), got %u", elem_bytes);
+    FOC_REQUIRE(feat_width >= 1 && feat_width <= 64, FOC_E_INVALID, "mo_select: feat_width %u outside 1..64", feat_width);
+    FOC_REQUIRE(n == 0 || (sigma_new && feat_new && sigma_best && feat_best), FOC_E_INVALID, "mo_select: null pointer");
+    FOC_REQUIRE(n < (1ull << 38), FOC_E_INVALID, "mo_select: n too large");
+    if (n == 0) return FOC_OK;
+    const dim3 grid((uint32_t)((n + 255u) / 256u));
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(k_mo_select<__half>, grid, dim3(256), 0, (hipStream_t)stream, (const __half *)sigma_new, (const __half *)feat_new,
+                           (__half *)sigma_best, (__half *)feat_best, n, feat_width);
+    else
+        hipLaunchKernelGGL(k_mo_select<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)sigma_new, (const float *)feat_new,
+                           (float *)sigma_best, (float *)feat_best, n, feat_width);
+    FOC_CHECK_LAUNCH("mo_select");
     return FOC_OK;
 }
 

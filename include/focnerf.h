@@ -485,6 +485,16 @@ int foc_combine_select_composite(const float *const *fields4, uint32_t K, const 
 /* acc4 <- select(acc4, field4) on n packed samples (same rule; acc4 holds the earlier objects). */
 int foc_combine_select4(const float *field4, float *acc4, uint64_t n, void *stream);
 
+/* MONeRFNetwork's running select (reference: nerf/multiobjectnetwork.py:66-82 — torch.max over stack([new, best]) with
+ * take_along_dim of the rows that travel with the density: geo_feat [n,15] in density(), colour [n,3] in color()).
+ * In place: where the new object takes sample i, sigma_best[i] = sigma_new[i] and feat_best[i,:] = feat_new[i,:].
+ * The rule is torch.max's: the first maximal index wins and the new object is stacked first, so the NEW object takes
+ * ties (COMBINED.py's select keeps the earlier one); NaN counts as maximal (a NaN of either side stays, the new one's
+ * on both). sigma and feat have the same element type: elem_bytes 2 (half, under autocast) or 4 (float);
+ * feat_width 1..64 elements per row, rows contiguous. */
+int foc_mo_select(const void *sigma_new, const void *feat_new, void *sigma_best, void *feat_best, uint64_t n,
+                  uint32_t feat_width, uint32_t elem_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Fixed-step render path as fused ops. No reference binding: these replace the torch
  * code of nerf/renderer.py:145-221 (== COMBINED.py:451-534) and the glue of nerf/network_ff.py:51-134

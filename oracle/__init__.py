@@ -278,6 +278,15 @@ def combine_select(dens, rgb, max_dens, best_rgb):
     return max_dens, best_rgb
 
 
+def mo_select(sigma_new, feat_new, sigma_best, feat_best):
+    """nerf/multiobjectnetwork.py:66-82 on arrays of one dtype (float16 or float32): returns the updated (sigma_best, feat_best)."""
+    a, b = _c(sigma_new, np.float32), _c(sigma_best, np.float32)            # half -> float is exact: the comparison is the same
+    take = np.zeros(a.size, np.uint8)
+    lib().orc_mo_select_mask(_p(a), _p(b), _p(take), u64(a.size))
+    take = take.astype(bool).reshape(np.shape(sigma_new))
+    return np.where(take, sigma_new, sigma_best), np.where(take[..., None], feat_new, feat_best)
+
+
 def composite_fixed_steps(sigmas, rgbs, nears, fars, bg, clamp01=True, want_weights=False):
     sigmas, rgbs, nears, fars = _c(sigmas, np.float32), _c(rgbs, np.float32), _c(nears, np.float32), _c(fars, np.float32)
     N, T = sigmas.shape
