@@ -167,7 +167,7 @@ class _render_tail(Function):
 
     @staticmethod
     def forward(ctx, h, cweights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, density_scale, thresh, num_layers, activation, obj_feat=None,
-                want_sumsq=False, c_pre=None):
+                want_sumsq=False, c_pre=None, w16_pre=None):
         # c_pre [M,4] half: the colour logits already computed from this h, these weights and this ray_sh by the encoder -> sigma node's fused
         # forward (field._hashgrid_mlp with `colour`, foc_field_forward_train: the bits foc_color_head_forward would give) — then no launch here
         from .field import _half_of
@@ -176,7 +176,7 @@ class _render_tail(Function):
         assert ray_sh.dtype == torch.float16 and ray_sh.shape == (N, 16) and ray_sh.is_contiguous()
         dev, M = h.device, N * T
         st = stream_of(h)
-        w16 = _half_of(cweights)
+        w16 = w16_pre if w16_pre is not None else _half_of(cweights)     # w16_pre: the half copy the fused forward already made of THESE weights
         # of the colour network's 16 padded outputs only the rgb logits are ever read: they travel as [M,4] rows (as does their gradient)
         obj16 = None
         if obj_feat is not None:
@@ -238,7 +238,7 @@ class _render_tail(Function):
         check(lib.foc_color_head_backward(ptr(grad_c), ptr(h), ptr(ray_sh), T, ptr(grad_h0), ptr(w16), M, 64, num_layers, activation, ptr(grad_h),
                                           ptr(g_w), ptr(wsb), wsb.numel(), _C_WIDTH, ptr(obj16), ptr(g_obj32), st), "color_head_backward")
         g_obj = g_obj32.to(obj_dtype).view(obj_shape) if g_obj32 is not None else None
-        return (grad_h, g_w) + (None,) * 12 + (g_obj, None, None)
+        return (grad_h, g_w) + (None,) * 12 + (g_obj, None, None, None)
 
 
 class _masked_norm(Function):
@@ -335,9 +335,11 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
             import numpy as np
             mlp = model.sigma_net
             # with the fused tail the colour network's forward rides in the sigma network's kernel (its logits reach _render_tail as `c_pre`)
-            colour = None
+            colour = wc16 = None
             if want_tail and colour_forward_fusable(mlp, model.color_net, uses_obj):
-                colour = (model.color_net.weights, ray_sh, T, model.color_net.num_layers, _C_WIDTH, obj_feat)
+                from .field import _half_of
+                wc16 = _half_of(model.color_net.weights)                  # ONE half copy per step for both nodes that read the colour weights
+                colour = (wc16, ray_sh, T, model.color_net.num_layers, _C_WIDTH, obj_feat)
             h = _hashgrid_mlp.apply(enc_in, enc.embeddings, mlp.weights, enc.offsets,
                                     (float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id, enc.align_corners, enc.interp_id),
                                     (mlp.input_dim, mlp.hidden_dim, mlp.num_layers, mlp.activation, mlp.output_activation),
@@ -358,7 +360,8 @@ def render_fixed_steps(model, rays_o, rays_d, yolo_details=None, num_steps=512, 
             cn = model.color_net
             bg_ray, bg_scalar = _background(bg_color, N, dev)
             outs = _render_tail.apply(h, cn.weights, ray_sh, nears, fars, noise, bg_ray, bg_scalar, N, T, model.density_scale, weight_thresh,
-                                      cn.num_layers, cn.activation, obj_feat, want_crit and yolo_details[0].numel() == N, c_pre)
+                                      cn.num_layers, cn.activation, obj_feat, want_crit and yolo_details[0].numel() == N, c_pre,
+                                      wc16 if c_pre is not None else None)
             image, weights_sum, depth, sigma, weights, c = outs[:6]
             if len(outs) == 7:
                 # a per-ray mask: the samples' sum of sigma^2 comes out of the tail kernel (no [M]-sized torch expression, no boolean-mask
