@@ -2,7 +2,7 @@
 """Which torch-native ops run inside one headline training step, with their input shapes and GPU time (torch.profiler): the part of the
 step that is not this library's kernels — optimizer, GradScaler, loss, and the casts / fills of the wrappers.
 
-    python tools/step_op_table.py [steps]
+    python tools/step_op_table.py [steps] [occ]        # occ: the occupancy-grid step (configs[2]) instead of the headline step
 """
 import os
 import sys
@@ -15,20 +15,24 @@ import bench                                                     # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    occ = len(sys.argv) > 2 and sys.argv[2] == "occ"
     dev = torch.device("cuda:0")
-    model = bench.build_model(1, dev, seed=0).train()
+    model = bench.build_model(2 if occ else 1, dev, cuda_ray=occ, seed=0).train()
     opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
     scaler = torch.amp.GradScaler("cuda")
-    poses, intr = bench.make_training_rays(dev, 1, 8, 0)
+    poses, intr = bench.make_training_rays(dev, 2 if occ else 1, 8, 0)
     gen = torch.Generator().manual_seed(1)
     batches = [bench.sample_batch(poses, intr, dev, gen) for _ in range(4)]
-    for i in range(6):
-        bench.train_step(model, opt, scaler, *batches[i % 4])
+    step = bench.cuda_ray_train_step if occ else bench.train_step
+    for i in range(17 if occ else 6):
+        step(model, opt, scaler, *batches[i % 4])
+        if occ and i == 15:
+            model.mean_count = int(model.step_counter[:16, 0].sum().item() / 16)
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         for i in range(steps):
-            bench.train_step(model, opt, scaler, *batches[i % 4])
+            step(model, opt, scaler, *batches[i % 4])
         torch.cuda.synchronize()
     rows = []
     for e in prof.key_averages(group_by_input_shape=True):
