@@ -25,14 +25,33 @@ def build(force=False):
 
 
 _lib = None
+_lib_nofma = None
+_use_nofma = False
 
 
 def lib():
-    global _lib
+    global _lib, _lib_nofma
     if _lib is None:
         build()
         _lib = ctypes.CDLL(LIB_PATH)
+    if _use_nofma:
+        if _lib_nofma is None:
+            _lib_nofma = ctypes.CDLL(os.path.join(_HERE, "_build", "liboracle_nofma.so"))
+        return _lib_nofma
     return _lib
+
+
+class no_fma_policy:
+    """`with oracle.no_fma_policy(): ...` — the calls inside run the ORC_NO_FMA build (no contraction at all: the other end of the unpinned
+    nvcc policy, oracle.c). For tests/test_fma_policy.py, which measures how far the two ends are apart; never the checker of the HIP path."""
+
+    def __enter__(self):
+        global _use_nofma
+        self.prev, _use_nofma = _use_nofma, True
+
+    def __exit__(self, *exc):
+        global _use_nofma
+        _use_nofma = self.prev
 
 
 def _p(a):
