@@ -479,6 +479,31 @@ def test_occ_render_step_with_object_feature():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B", [1, 31, 64, 65, 129, 8191])
+def test_field_forward_train_small_and_ragged_batches(B):
+    """The same bitwise comparison on batches below / at / just above one 64-row tile and one workgroup's share (the prefetch of the tile behind
+    the last one is clamped to the batch: nothing past row B - 1 may be read into a result or written)."""
+    from focnerf_amd._lib import lib, ptr, stream_of, check
+    g = torch.Generator(device="cuda").manual_seed(77 + B)
+    T = 5
+    n_rays = (B + T - 1) // T
+    planes = ((torch.rand(16, B, 2, generator=g, device="cuda") - 0.5) * 2).half()
+    w_s = (torch.randn(64 * (32 + 64 + 16), generator=g, device="cuda") * 0.25).half()
+    w_c = (torch.randn(64 * (32 + 128 + 16), generator=g, device="cuda") * 0.25).half()
+    ray_sh = (torch.randn(n_rays, 16, generator=g, device="cuda") * 0.5).half()
+    st = stream_of(planes)
+    h1 = torch.empty(B, 16, dtype=torch.float16, device="cuda")
+    c1 = torch.empty(B, 4, dtype=torch.float16, device="cuda")
+    check(lib.foc_ffmlp_forward_planar(ptr(planes), ptr(w_s), B, 32, 16, 64, 2, 0, 6, ptr(h1), st), "sigma forward")
+    check(lib.foc_color_head_forward(ptr(h1), ptr(ray_sh), T, ptr(w_c), B, 64, 3, 0, ptr(c1), 4, None, st), "colour forward")
+    h2 = torch.full((B + 64, 16), 5.0, dtype=torch.float16, device="cuda")
+    c2 = torch.full((B + 64, 4), 5.0, dtype=torch.float16, device="cuda")
+    check(lib.foc_field_forward_train(ptr(planes), ptr(w_s), 2, ptr(ray_sh), T, ptr(w_c), 3, 64, 0, B, ptr(h2), ptr(c2), 4, None, st), "fused forward")
+    torch.cuda.synchronize()
+    assert torch.all(h2[B:] == 5.0) and torch.all(c2[B:] == 5.0), "rows past B were written"
+    assert torch.equal(h2[:B].view(torch.int16), h1.view(torch.int16)) and torch.equal(c2[:B].view(torch.int16), c1.view(torch.int16))
+
+
 @pytest.mark.parametrize("nls,nlc", [(2, 2), (2, 3), (3, 3)])
 @pytest.mark.parametrize("out_width,T,with_obj,act", [(4, 512, False, 0), (16, 1, False, 0), (4, 7, True, 0), (16, 64, False, 6)])
 def test_field_forward_train_is_bitwise_the_two_calls(nls, nlc, out_width, T, with_obj, act):
